@@ -1,0 +1,175 @@
+/*
+ * vsom_hip.h -- C ABI of libvsom_hip.so: the MI355X (gfx950) implementation of the VSOM
+ * training hot path (BMU search + Gaussian-neighbourhood mean / sigma^2 update).
+ *
+ * The reference (PereUbu7/Variational-Self-Organizing-Maps) has no FFI layer: callers link
+ * libsom and use `class Som` (include/SOM.hpp:39-189).  This header is the boundary a
+ * maintainer binds instead of src/Som.cpp's CPU loops; every entry point names the reference
+ * member function it replaces.  Host-side `Som` / `Transformation` mirrors that call these
+ * entry points live in variational-self-organizing-maps_amd/host/ (C++) and
+ * variational-self-organizing-maps_amd/som.py (ctypes).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++ or torch types.
+ *  - every function returns 0 on success, a negative vsom_status otherwise; the message is
+ *    available from vsom_last_error() (thread-local).  Nothing throws across the ABI.
+ *  - model state is row-major N x D fp32 (N = width*height, node index = y*width + x,
+ *    D = Transformation::Length(J)); samples are row-major B x J fp32.
+ *  - "host" pointers are ordinary host memory, copied synchronously; "dev" pointers are
+ *    device memory on the context's GPU.
+ *  - all work is enqueued on the context's HIP stream (vsom_set_stream adopts an external
+ *    one, e.g. torch's current stream); entry points that return values to the host
+ *    synchronise that stream, the *_async ones do not.
+ *  - there is no CPU fallback: if no gfx950 device / code object is usable, vsom_create fails.
+ */
+#ifndef VSOM_HIP_H
+#define VSOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vsom_ctx vsom_ctx;
+
+typedef enum vsom_status {
+    VSOM_OK = 0,
+    VSOM_ERR_INVALID = -1, /* bad argument / state (e.g. no chunk loaded)          */
+    VSOM_ERR_HIP = -2,     /* HIP runtime error, text in vsom_last_error()         */
+    VSOM_ERR_NOMEM = -3,
+    VSOM_ERR_UNSUPPORTED = -4
+} vsom_status;
+
+/* Transformation factories: src/Transformation.cpp:3-39 / 41-77 / 79-167 */
+typedef enum vsom_transform {
+    VSOM_STANDARD = 0,
+    VSOM_MEDIAN = 1,
+    VSOM_CLR = 2
+} vsom_transform;
+
+/* Som::WeigthDecayFunction: include/SOM.hpp:70-75 */
+typedef enum vsom_decay {
+    VSOM_EXPONENTIAL = 0,
+    VSOM_INVERSE_PROPORTIONAL = 1,
+    VSOM_BATCHMAP = 2
+} vsom_decay;
+
+/* BMU search strategy of the full search (results are identical) */
+typedef enum vsom_bmu_mode {
+    VSOM_BMU_AUTO = 0,      /* MFMA shortlist + exact-order refinement when applicable */
+    VSOM_BMU_EXACT = 1,     /* brute-force exact-order VALU kernel                     */
+    VSOM_BMU_SHORTLIST = 2  /* force the MFMA shortlist path                           */
+} vsom_bmu_mode;
+
+/* selectors for vsom_device_ptr / vsom_get_timing */
+typedef enum vsom_buffer {
+    VSOM_BUF_MAP = 0,      /* float   [N][D]                                    */
+    VSOM_BUF_SIGMA = 1,    /* float   [N][D]                                    */
+    VSOM_BUF_S = 2,        /* float   [N][D]                                    */
+    VSOM_BUF_WEIGHT = 3,   /* float   [N]                                       */
+    VSOM_BUF_HITS = 4,     /* uint64  [N]                                       */
+    VSOM_BUF_LASTBMU = 5,  /* uint64  [chunk capacity]                          */
+    VSOM_BUF_SQRES = 6,    /* float   [chunk capacity]  ||Comparer(x,M[bmu])||^2 */
+    VSOM_BUF_CHUNK = 7     /* float   [B][J] staged samples                     */
+} vsom_buffer;
+
+typedef enum vsom_timer {
+    VSOM_T_STAGE = 0,      /* chunk re-layout kernels                           */
+    VSOM_T_BMU = 1,        /* full / local BMU search kernels                   */
+    VSOM_T_FINISH = 2,     /* bmuHits + MSE                                     */
+    VSOM_T_CW = 3,         /* neighbourhood weight chain (w, w/W) kernel        */
+    VSOM_T_UPDATE = 4,     /* mean / sigma^2 chain kernel                       */
+    VSOM_T_ONLINE = 5,     /* online (trainSingle) kernels                      */
+    VSOM_T_COUNT = 6
+} vsom_timer;
+
+const char *vsom_last_error(void);
+/* number of visible HIP devices (0 when none / no driver) */
+int vsom_device_count(void);
+
+/* ---- lifetime -------------------------------------------------------------------------
+ * Som::Som(width,height,depth,Transformation) + Som::Construct (SOM.hpp:83-87,
+ * Som.cpp:11-48): all state zero.  in_len = J (sample length); D = Length(J).          */
+int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height,
+                uint32_t in_len, int transform);
+void vsom_destroy(vsom_ctx *ctx);
+/* adopt an external hipStream_t (NULL = back to the context's own stream) */
+int vsom_set_stream(vsom_ctx *ctx, void *hip_stream);
+int vsom_synchronize(vsom_ctx *ctx);
+int vsom_set_bmu_mode(vsom_ctx *ctx, int mode);
+uint32_t vsom_depth(const vsom_ctx *ctx);   /* D */
+uint32_t vsom_nodes(const vsom_ctx *ctx);   /* N */
+
+/* ---- state (Som::map / sigmaMap / SMap / weightMap / bmuHits, SOM.hpp:56-61) -----------
+ * NULL pointers are skipped.  Replaces getNeuron/getSigmaNeuron/getWeigthMap/getBmuHits
+ * (Som.cpp:164-212) and the element writes of randomInitialize/load (Som.cpp:977-997).    */
+int vsom_set_state(vsom_ctx *ctx, const float *map, const float *sigma, const float *S,
+                   const float *weight, const uint64_t *bmu_hits);
+int vsom_get_state(vsom_ctx *ctx, float *map, float *sigma, float *S, float *weight,
+                   uint64_t *bmu_hits);
+
+/* ---- chunk (DataSet::loadNextDataFromStream, DataSet.cpp:118-160) ----------------------
+ * Stages B samples and zeroes lastBMU (DataSet.cpp:136-137).                              */
+int vsom_upload_chunk(vsom_ctx *ctx, const float *x_host, size_t B);
+/* same, samples already resident in HBM (no PCIe copy) */
+int vsom_set_chunk_device(vsom_ctx *ctx, const float *x_dev, size_t B);
+/* DataSet::getLastBMU (DataSet.cpp:60-69) */
+int vsom_get_last_bmu(vsom_ctx *ctx, uint64_t *out_host);
+int vsom_set_last_bmu(vsom_ctx *ctx, const uint64_t *in_host);
+int vsom_get_sqres(vsom_ctx *ctx, float *out_host);
+
+/* ---- search ----------------------------------------------------------------------------
+ * Som::findBmu for every sample of the chunk (Som.cpp:291-309, distance :124-141);
+ * writes lastBMU / sqres on the device; optional host copies.                             */
+int vsom_bmu_batch(vsom_ctx *ctx, uint64_t *idx_out_host, float *dist_out_host);
+/* Som::findLocalBmu from the current lastBMU of every sample (Som.cpp:335-454) */
+int vsom_bmu_local_batch(vsom_ctx *ctx, uint64_t *idx_out_host, float *dist_out_host);
+/* Som::euclidianWeightedDist(pos, v, ...) for `count` (node, sample-row) pairs of the chunk */
+int vsom_distances(vsom_ctx *ctx, const uint64_t *nodes_host, const uint64_t *rows_host,
+                   size_t count, float *dist_out_host);
+
+/* ---- batch epoch: Som::trainBatchSomEpoch (Som.cpp:756-879) ----------------------------
+ * phase 1 (:762-806) over samples [s0,s1): BMU (findBmu when is_first else findLocalBmu)
+ *   + per-sample ||residual||^2;  finish: bmuHits += 1, fp32 MSE in sample order;
+ * phase 2 (:809-876) over nodes [n0,n1): new map, sigmaMap, weightMap rows.
+ * vsom_batch_epoch = phase1(0,B) + finish + phase2(0,N); mse_out may be NULL.
+ * The split entry points exist for node/sample sharding across GPUs (multi-GPU).*/
+int vsom_batch_phase1_async(vsom_ctx *ctx, size_t s0, size_t s1, int is_first);
+int vsom_batch_finish_async(vsom_ctx *ctx);
+int vsom_batch_phase2_async(vsom_ctx *ctx, double sigma, size_t n0, size_t n1);
+int vsom_batch_epoch_async(vsom_ctx *ctx, double sigma, int is_first);
+int vsom_batch_epoch(vsom_ctx *ctx, double sigma, int is_first, float *mse_out);
+/* MSE of the last finish (synchronises) */
+int vsom_get_mse(vsom_ctx *ctx, float *mse_out);
+
+/* ---- online path -----------------------------------------------------------------------
+ * Som::trainSingle (Som.cpp:885-947) on one host vector; residual_out has
+ * vsom_residual_len() floats (may be NULL).  *last_bmu in/out.                            */
+uint32_t vsom_residual_len(const vsom_ctx *ctx);
+int vsom_train_single(vsom_ctx *ctx, const float *v_host, double eta, double sigma,
+                      uint64_t *last_bmu, int decay_fn, float *residual_out,
+                      float *dist_out, uint64_t *bmu_out);
+/* inner loop of Som::trainBasicSom over the staged chunk (Som.cpp:1159-1171): B sequential
+ * trainSingle steps + addBmu (:1189-1192) + MSE, without leaving the device.              */
+int vsom_train_online_chunk(vsom_ctx *ctx, double eta, double sigma, int decay_fn,
+                            float *mse_out);
+
+/* ---- static helper: Som::calculateNeighbourhoodWeight (Som.cpp:949-975) ---------------- */
+double vsom_neighbourhood_weight(size_t cx, size_t cy, size_t bx, size_t by, double sigma);
+
+/* ---- interop / measurement -------------------------------------------------------------*/
+/* raw device pointer of a context buffer (for RCCL / torch.distributed collectives) */
+void *vsom_device_ptr(vsom_ctx *ctx, int which);
+size_t vsom_chunk_size(const vsom_ctx *ctx);
+/* per-kernel-group HIP-event timing on the context stream */
+int vsom_enable_timing(vsom_ctx *ctx, int on);
+/* accumulated milliseconds and launch counts since the last reset (synchronises) */
+int vsom_get_timing(vsom_ctx *ctx, float *ms_out /*[VSOM_T_COUNT]*/,
+                    uint32_t *count_out /*[VSOM_T_COUNT]*/, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
