@@ -163,6 +163,10 @@ double vsom_neighbourhood_weight(size_t cx, size_t cy, size_t bx, size_t by, dou
 /* raw device pointer of a context buffer (for RCCL / torch.distributed collectives) */
 void *vsom_device_ptr(vsom_ctx *ctx, int which);
 size_t vsom_chunk_size(const vsom_ctx *ctx);
+/* row pitch in floats of the MAP/SIGMA/S device buffers (>= D; CLR: [A | pad | B | pad]) and
+ * of the staged CHUNK buffer */
+uint32_t vsom_pitch(const vsom_ctx *ctx);
+uint32_t vsom_chunk_pitch(const vsom_ctx *ctx);
 /* per-kernel-group HIP-event timing on the context stream */
 int vsom_enable_timing(vsom_ctx *ctx, int on);
 /* accumulated milliseconds and launch counts since the last reset (synchronises) */

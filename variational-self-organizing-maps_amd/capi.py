@@ -1,0 +1,286 @@
+"""ctypes binding of libvsom_hip.so (include/vsom_hip.h).
+
+This is the product path: it loads the in-tree HIP library and fails loudly when the
+library or a gfx950 device is missing -- there is no CPU fallback and nothing here touches
+oracle/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvsom_hip.so")
+
+STANDARD, MEDIAN, CLR = 0, 1, 2
+EXPONENTIAL, INVERSE_PROPORTIONAL, BATCHMAP = 0, 1, 2
+BMU_AUTO, BMU_EXACT, BMU_SHORTLIST = 0, 1, 2
+BUF_MAP, BUF_SIGMA, BUF_S, BUF_WEIGHT, BUF_HITS, BUF_LASTBMU, BUF_SQRES, BUF_CHUNK = range(8)
+T_STAGE, T_BMU, T_FINISH, T_CW, T_UPDATE, T_ONLINE, T_COUNT = range(7)
+TIMER_NAMES = ["stage", "bmu", "finish", "cw", "update", "online"]
+
+# every symbol include/vsom_hip.h declares (tests/test_capi_symbols.py checks the header too)
+SYMBOLS = [
+    "vsom_last_error", "vsom_device_count", "vsom_create", "vsom_destroy", "vsom_set_stream",
+    "vsom_synchronize", "vsom_set_bmu_mode", "vsom_depth", "vsom_nodes", "vsom_set_state",
+    "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_get_last_bmu",
+    "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_bmu_local_batch",
+    "vsom_distances", "vsom_batch_phase1_async", "vsom_batch_finish_async",
+    "vsom_batch_phase2_async", "vsom_batch_epoch_async", "vsom_batch_epoch", "vsom_get_mse",
+    "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk",
+    "vsom_neighbourhood_weight", "vsom_device_ptr", "vsom_chunk_size", "vsom_pitch",
+    "vsom_chunk_pitch", "vsom_enable_timing", "vsom_get_timing",
+]
+
+
+class VsomError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libvsom_hip.so for gfx950 with csrc/build.sh (hipcc cross-compiles on CPU)."""
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    if force:
+        for f in os.listdir(os.path.join(_HERE, "csrc")):
+            if f.endswith(".o"):
+                os.remove(os.path.join(_HERE, "csrc", f))
+    subprocess.check_call(["bash", script, LIB_PATH], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VsomError(f"{LIB_PATH} is missing: run __graft_entry__.build() "
+                        "(variational-self-organizing-maps_amd/csrc/build.sh)")
+    L = C.CDLL(LIB_PATH)
+    vp, fp, u64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+    L.vsom_last_error.restype = C.c_char_p
+    L.vsom_device_count.restype = C.c_int
+    L.vsom_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.vsom_destroy.argtypes = [vp]
+    L.vsom_destroy.restype = None
+    L.vsom_set_stream.argtypes = [vp, vp]
+    L.vsom_synchronize.argtypes = [vp]
+    L.vsom_set_bmu_mode.argtypes = [vp, C.c_int]
+    for name in ("vsom_depth", "vsom_nodes", "vsom_residual_len", "vsom_pitch", "vsom_chunk_pitch"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = C.c_uint32
+    L.vsom_chunk_size.argtypes = [vp]
+    L.vsom_chunk_size.restype = C.c_size_t
+    L.vsom_set_state.argtypes = [vp, fp, fp, fp, fp, u64p]
+    L.vsom_get_state.argtypes = [vp, fp, fp, fp, fp, u64p]
+    L.vsom_upload_chunk.argtypes = [vp, fp, C.c_size_t]
+    L.vsom_set_chunk_device.argtypes = [vp, vp, C.c_size_t]
+    L.vsom_get_last_bmu.argtypes = [vp, u64p]
+    L.vsom_set_last_bmu.argtypes = [vp, u64p]
+    L.vsom_get_sqres.argtypes = [vp, fp]
+    L.vsom_bmu_batch.argtypes = [vp, u64p, fp]
+    L.vsom_bmu_local_batch.argtypes = [vp, u64p, fp]
+    L.vsom_distances.argtypes = [vp, u64p, u64p, C.c_size_t, fp]
+    L.vsom_batch_phase1_async.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_int]
+    L.vsom_batch_finish_async.argtypes = [vp]
+    L.vsom_batch_phase2_async.argtypes = [vp, C.c_double, C.c_size_t, C.c_size_t]
+    L.vsom_batch_epoch_async.argtypes = [vp, C.c_double, C.c_int]
+    L.vsom_batch_epoch.argtypes = [vp, C.c_double, C.c_int, fp]
+    L.vsom_get_mse.argtypes = [vp, fp]
+    L.vsom_train_single.argtypes = [vp, fp, C.c_double, C.c_double, u64p, C.c_int, fp, fp, u64p]
+    L.vsom_train_online_chunk.argtypes = [vp, C.c_double, C.c_double, C.c_int, fp]
+    L.vsom_neighbourhood_weight.argtypes = [C.c_size_t] * 4 + [C.c_double]
+    L.vsom_neighbourhood_weight.restype = C.c_double
+    L.vsom_device_ptr.argtypes = [vp, C.c_int]
+    L.vsom_device_ptr.restype = vp
+    L.vsom_enable_timing.argtypes = [vp, C.c_int]
+    L.vsom_get_timing.argtypes = [vp, fp, C.POINTER(C.c_uint32), C.c_int]
+    _lib = L
+    return L
+
+
+def _f(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+def check(rc):
+    if rc != 0:
+        raise VsomError(f"libvsom_hip error {rc}: {lib().vsom_last_error().decode(errors='replace')}")
+
+
+def device_count():
+    return int(lib().vsom_device_count())
+
+
+def neighbourhood_weight(cx, cy, bx, by, sigma):
+    return float(lib().vsom_neighbourhood_weight(cx, cy, bx, by, float(sigma)))
+
+
+class Context:
+    """RAII wrapper of a vsom_ctx (one per GPU)."""
+
+    def __init__(self, width, height, in_len, transform=STANDARD, device=0):
+        self._h = C.c_void_p()
+        check(lib().vsom_create(C.byref(self._h), int(device), int(width), int(height), int(in_len),
+                                int(transform)))
+        self.width, self.height, self.in_len = int(width), int(height), int(in_len)
+        self.transform, self.device = int(transform), int(device)
+        self.depth = int(lib().vsom_depth(self._h))
+        self.n_nodes = int(lib().vsom_nodes(self._h))
+        self.residual_len = int(lib().vsom_residual_len(self._h))
+        self.pitch = int(lib().vsom_pitch(self._h))
+
+    def close(self):
+        if self._h:
+            lib().vsom_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- plumbing ------------------------------------------------------
+    def set_stream(self, hip_stream_ptr):
+        check(lib().vsom_set_stream(self._h, C.c_void_p(hip_stream_ptr or 0)))
+
+    def synchronize(self):
+        check(lib().vsom_synchronize(self._h))
+
+    def set_bmu_mode(self, mode):
+        check(lib().vsom_set_bmu_mode(self._h, int(mode)))
+
+    def device_ptr(self, which):
+        return int(lib().vsom_device_ptr(self._h, int(which)) or 0)
+
+    @property
+    def chunk_size(self):
+        return int(lib().vsom_chunk_size(self._h))
+
+    # ---- state ---------------------------------------------------------
+    def set_state(self, map=None, sigma=None, S=None, weight=None, hits=None):
+        n, d = self.n_nodes, self.depth
+
+        def f2(a, shape):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            assert a.size == int(np.prod(shape)), (a.shape, shape)
+            return a
+
+        m, s, ss, w = f2(map, (n, d)), f2(sigma, (n, d)), f2(S, (n, d)), f2(weight, (n,))
+        h = None if hits is None else np.ascontiguousarray(hits, dtype=np.uint64)
+        check(lib().vsom_set_state(self._h, _f(m), _f(s), _f(ss), _f(w), _u(h)))
+
+    def get_state(self, map=True, sigma=True, S=True, weight=True, hits=True):
+        n, d = self.n_nodes, self.depth
+        m = np.empty((n, d), np.float32) if map else None
+        s = np.empty((n, d), np.float32) if sigma else None
+        ss = np.empty((n, d), np.float32) if S else None
+        w = np.empty(n, np.float32) if weight else None
+        h = np.empty(n, np.uint64) if hits else None
+        check(lib().vsom_get_state(self._h, _f(m), _f(s), _f(ss), _f(w), _u(h)))
+        return {"map": m, "sigma": s, "S": ss, "weight": w, "hits": h}
+
+    # ---- chunk ---------------------------------------------------------
+    def upload_chunk(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        assert X.ndim == 2 and X.shape[1] == self.in_len, (X.shape, self.in_len)
+        check(lib().vsom_upload_chunk(self._h, _f(X), X.shape[0]))
+
+    def set_chunk_device(self, dev_ptr, B):
+        check(lib().vsom_set_chunk_device(self._h, C.c_void_p(int(dev_ptr)), int(B)))
+
+    def get_last_bmu(self):
+        out = np.empty(self.chunk_size, np.uint64)
+        check(lib().vsom_get_last_bmu(self._h, _u(out)))
+        return out
+
+    def set_last_bmu(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        assert idx.size == self.chunk_size
+        check(lib().vsom_set_last_bmu(self._h, _u(idx)))
+
+    def get_sqres(self):
+        out = np.empty(self.chunk_size, np.float32)
+        check(lib().vsom_get_sqres(self._h, _f(out)))
+        return out
+
+    # ---- search --------------------------------------------------------
+    def bmu_batch(self):
+        B = self.chunk_size
+        idx, dist = np.empty(B, np.uint64), np.empty(B, np.float32)
+        check(lib().vsom_bmu_batch(self._h, _u(idx), _f(dist)))
+        return idx, dist
+
+    def bmu_local_batch(self):
+        B = self.chunk_size
+        idx, dist = np.empty(B, np.uint64), np.empty(B, np.float32)
+        check(lib().vsom_bmu_local_batch(self._h, _u(idx), _f(dist)))
+        return idx, dist
+
+    def distances(self, nodes, rows):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        assert nodes.size == rows.size
+        out = np.empty(nodes.size, np.float32)
+        check(lib().vsom_distances(self._h, _u(nodes), _u(rows), nodes.size, _f(out)))
+        return out
+
+    # ---- batch epoch ---------------------------------------------------
+    def batch_phase1_async(self, s0, s1, is_first):
+        check(lib().vsom_batch_phase1_async(self._h, int(s0), int(s1), int(bool(is_first))))
+
+    def batch_finish_async(self):
+        check(lib().vsom_batch_finish_async(self._h))
+
+    def batch_phase2_async(self, sigma, n0, n1):
+        check(lib().vsom_batch_phase2_async(self._h, float(sigma), int(n0), int(n1)))
+
+    def batch_epoch_async(self, sigma, is_first):
+        check(lib().vsom_batch_epoch_async(self._h, float(sigma), int(bool(is_first))))
+
+    def batch_epoch(self, sigma, is_first):
+        mse = C.c_float()
+        check(lib().vsom_batch_epoch(self._h, float(sigma), int(bool(is_first)), C.byref(mse)))
+        return np.float32(mse.value)
+
+    def get_mse(self):
+        mse = C.c_float()
+        check(lib().vsom_get_mse(self._h, C.byref(mse)))
+        return np.float32(mse.value)
+
+    # ---- online --------------------------------------------------------
+    def train_single(self, v, eta, sigma, last_bmu, decay_fn):
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        assert v.size == self.in_len
+        res = np.empty(self.residual_len, np.float32)
+        lb, bmu, dist = C.c_uint64(int(last_bmu)), C.c_uint64(), C.c_float()
+        check(lib().vsom_train_single(self._h, _f(v), float(eta), float(sigma), C.byref(lb),
+                                      int(decay_fn), _f(res), C.byref(dist), C.byref(bmu)))
+        return int(bmu.value), res, np.float32(dist.value), int(lb.value)
+
+    def train_online_chunk(self, eta, sigma, decay_fn):
+        mse = C.c_float()
+        check(lib().vsom_train_online_chunk(self._h, float(eta), float(sigma), int(decay_fn),
+                                            C.byref(mse)))
+        return np.float32(mse.value)
+
+    # ---- measurement ---------------------------------------------------
+    def enable_timing(self, on=True):
+        check(lib().vsom_enable_timing(self._h, int(bool(on))))
+
+    def get_timing(self, reset=True):
+        ms = (C.c_float * T_COUNT)()
+        cnt = (C.c_uint32 * T_COUNT)()
+        check(lib().vsom_get_timing(self._h, ms, cnt, int(bool(reset))))
+        return {TIMER_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(T_COUNT)}

@@ -1,0 +1,497 @@
+// vsom_bmu.hip -- BMU search kernels (gfx950).
+//
+//  bmu_tile_kernel   : Som::findBmu (Som.cpp:291-309) for a 64-sample x 64-node tile per
+//                      workgroup; every distance is evaluated in the reference's fp32 order
+//                      (8 class accumulators + Eigen's reduction tree) on the VALU.
+//  bmu_reduce_kernel : per-sample argmin over the node tiles (strict <, lowest index, NaN
+//                      rules of Som.cpp:293-304).
+//  bmu_local_kernel  : Som::findLocalBmu (Som.cpp:335-454), one wavefront per sample,
+//                      8 candidates x 8 accumulator classes across the 64 lanes.
+//  pair_dist_kernel  : Som::euclidianWeightedDist for arbitrary (node,row) pairs.
+//  finish_kernel     : bmuHits[idx] += 1 and the fp32 MSE running sum in sample order
+//                      (Som.cpp:777-781).
+//  stage kernels     : chunk re-layout (zero-padded rows; CLR x'/y' expansion).
+#include "vsom_device.hpp"
+
+// ------------------------------------------------------------------------------------------
+// chunk staging
+// ------------------------------------------------------------------------------------------
+__global__ void stage_rows_kernel(const float *__restrict__ x, int J, int B,
+                                  float *__restrict__ xs, int xpitch)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)B * xpitch;
+    if (i >= total)
+        return;
+    int s = (int)(i / xpitch), d = (int)(i % xpitch);
+    xs[i] = d < J ? x[(size_t)s * J + d] : 0.f;
+}
+
+// x'_p = x[i(p)], y'_p = x[j(p)]  (Transformation.cpp:94-101)
+__global__ void stage_pairs_kernel(const float *__restrict__ x, int J, int B, int P,
+                                   const int *__restrict__ pi, const int *__restrict__ pj,
+                                   float *__restrict__ xp, float *__restrict__ yp, int ppitch)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)B * ppitch;
+    if (i >= total)
+        return;
+    int s = (int)(i / ppitch), p = (int)(i % ppitch);
+    float a = 0.f, b = 0.f;
+    if (p < P) {
+        a = x[(size_t)s * J + pi[p]];
+        b = x[(size_t)s * J + pj[p]];
+    }
+    xp[i] = a;
+    yp[i] = b;
+}
+
+__global__ void zero_u64_kernel(u64 *p, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        p[i] = 0;
+}
+
+int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B)
+{
+    TimerScope ts(c, VSOM_T_STAGE);
+    if (B == 0)
+        return VSOM_OK;
+    {
+        size_t total = B * c->xpitch;
+        hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           c->stream, x_dev, (int)c->J, (int)B, c->Xs, (int)c->xpitch);
+    }
+    if (c->transform == VSOM_CLR) {
+        size_t total = B * c->part_pitch;
+        hipLaunchKernelGGL(stage_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           c->stream, x_dev, (int)c->J, (int)B, (int)c->part_len, c->pair_i,
+                           c->pair_j, c->XP, c->YP, (int)c->part_pitch);
+    }
+    // DataSet::loadNextDataFromStream zeroes lastBMU (DataSet.cpp:136-137)
+    hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream,
+                       c->lastbmu, B);
+    VSOM_HIP_CHECK(hipGetLastError());
+    return VSOM_OK;
+}
+
+static DistArgs make_dist_args(const vsom_ctx *c)
+{
+    DistArgs a;
+    if (c->transform == VSOM_CLR) {
+        a.xa = c->XP;
+        a.xb = c->YP;
+        a.ldx = (int)c->part_pitch;
+        a.ma = c->map;
+        a.mb = c->map + c->part_pitch;
+    } else {
+        a.xa = c->Xs;
+        a.xb = c->Xs;
+        a.ldx = (int)c->xpitch;
+        a.ma = c->map;
+        a.mb = c->map;
+    }
+    a.ldm = (int)c->pitch;
+    a.L = (int)c->part_len;
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------
+// full search: 64 x 64 tile per workgroup, 4 x 4 pairs x 8 class accumulators per thread
+// ------------------------------------------------------------------------------------------
+#define TILE 64
+#define LDT 36   // LDS row stride in floats: 16-B aligned, lane rows land on distinct 4-bank slots
+
+template <bool CLR>
+__global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, int s1, int N,
+                                                          u64 *__restrict__ partial, int pstride,
+                                                          unsigned char *__restrict__ nan0)
+{
+    __shared__ __attribute__((aligned(16))) float sx[TILE * LDT];
+    __shared__ __attribute__((aligned(16))) float sm[TILE * LDT];
+    __shared__ __attribute__((aligned(16))) float sy[CLR ? TILE * LDT : 4];
+    __shared__ __attribute__((aligned(16))) float sb[CLR ? TILE * LDT : 4];
+
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int nbase = blockIdx.x * TILE;
+    const int sbase = s0 + blockIdx.y * TILE;
+    const int L = a.L, L8 = L & ~7;
+    const int nchunks = (L + VSOM_TK - 1) / VSOM_TK;
+
+    float acc[4][4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                acc[i][j][k] = 0.f;
+
+    int dk = 0;
+    for (int ch = 0; ch < nchunks; ++ch, dk += VSOM_TK) {
+        if (ch > 0)
+            __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int f = tid + 256 * i;
+            int row = f >> 3, c4 = (f & 7) * 4;
+            int s = sbase + row, n = nbase + row;
+            float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vm = vx, vy = vx, vb = vx;
+            if (s < s1) {
+                vx = *reinterpret_cast<const float4 *>(a.xa + (size_t)s * a.ldx + dk + c4);
+                if (CLR)
+                    vy = *reinterpret_cast<const float4 *>(a.xb + (size_t)s * a.ldx + dk + c4);
+            }
+            if (n < N) {
+                vm = *reinterpret_cast<const float4 *>(a.ma + (size_t)n * a.ldm + dk + c4);
+                if (CLR)
+                    vb = *reinterpret_cast<const float4 *>(a.mb + (size_t)n * a.ldm + dk + c4);
+            }
+            *reinterpret_cast<float4 *>(&sx[row * LDT + c4]) = vx;
+            *reinterpret_cast<float4 *>(&sm[row * LDT + c4]) = vm;
+            if (CLR) {
+                *reinterpret_cast<float4 *>(&sy[row * LDT + c4]) = vy;
+                *reinterpret_cast<float4 *>(&sb[row * LDT + c4]) = vb;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < VSOM_TK; kk += 8) {
+            if (dk + kk < L8) {   // whole 8-blocks only; the remainder is handled in Eigen's order below
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float4 xv[4], mv[4], yv[4], bv[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        xv[i] = *reinterpret_cast<const float4 *>(&sx[(ty + 16 * i) * LDT + kk + 4 * h]);
+                        mv[i] = *reinterpret_cast<const float4 *>(&sm[(tx + 16 * i) * LDT + kk + 4 * h]);
+                        if (CLR) {
+                            yv[i] = *reinterpret_cast<const float4 *>(&sy[(ty + 16 * i) * LDT + kk + 4 * h]);
+                            bv[i] = *reinterpret_cast<const float4 *>(&sb[(tx + 16 * i) * LDT + kk + 4 * h]);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float r0 = vsom_resid<CLR>(xv[i].x, CLR ? yv[i].x : 0.f, mv[j].x, CLR ? bv[j].x : 0.f);
+                            float r1 = vsom_resid<CLR>(xv[i].y, CLR ? yv[i].y : 0.f, mv[j].y, CLR ? bv[j].y : 0.f);
+                            float r2 = vsom_resid<CLR>(xv[i].z, CLR ? yv[i].z : 0.f, mv[j].z, CLR ? bv[j].z : 0.f);
+                            float r3 = vsom_resid<CLR>(xv[i].w, CLR ? yv[i].w : 0.f, mv[j].w, CLR ? bv[j].w : 0.f);
+                            float p0 = r0 * r0, p1 = r1 * r1, p2 = r2 * r2, p3 = r3 * r3;
+                            acc[i][j][4 * h + 0] = acc[i][j][4 * h + 0] + p0;
+                            acc[i][j][4 * h + 1] = acc[i][j][4 * h + 1] + p1;
+                            acc[i][j][4 * h + 2] = acc[i][j][4 * h + 2] + p2;
+                            acc[i][j][4 * h + 3] = acc[i][j][4 * h + 3] + p3;
+                        }
+                }
+            }
+        }
+    }
+
+    // reduction tree + remainder (the last chunk is still in LDS)
+    const int rem = L - L8;
+    const int roff = L8 - (nchunks - 1) * VSOM_TK;   // column of element L8 inside the last chunk
+    float dist[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float q0 = acc[i][j][0] + acc[i][j][4];
+            float q1 = acc[i][j][1] + acc[i][j][5];
+            float q2 = acc[i][j][2] + acc[i][j][6];
+            float q3 = acc[i][j][3] + acc[i][j][7];
+            const int xr = (ty + 16 * i) * LDT + roff, mr = (tx + 16 * j) * LDT + roff;
+            int t = 0;
+            if (rem >= 4) {
+                float r0 = vsom_resid<CLR>(sx[xr + 0], CLR ? sy[xr + 0] : 0.f, sm[mr + 0], CLR ? sb[mr + 0] : 0.f);
+                float r1 = vsom_resid<CLR>(sx[xr + 1], CLR ? sy[xr + 1] : 0.f, sm[mr + 1], CLR ? sb[mr + 1] : 0.f);
+                float r2 = vsom_resid<CLR>(sx[xr + 2], CLR ? sy[xr + 2] : 0.f, sm[mr + 2], CLR ? sb[mr + 2] : 0.f);
+                float r3 = vsom_resid<CLR>(sx[xr + 3], CLR ? sy[xr + 3] : 0.f, sm[mr + 3], CLR ? sb[mr + 3] : 0.f);
+                float p0 = r0 * r0, p1 = r1 * r1, p2 = r2 * r2, p3 = r3 * r3;
+                q0 = q0 + p0;
+                q1 = q1 + p1;
+                q2 = q2 + p2;
+                q3 = q3 + p3;
+                t = 4;
+            }
+            float t02 = q0 + q2, t13 = q1 + q3;
+            float res = t02 + t13;
+            for (; t < rem; ++t) {
+                float r = vsom_resid<CLR>(sx[xr + t], CLR ? sy[xr + t] : 0.f, sm[mr + t], CLR ? sb[mr + t] : 0.f);
+                float p = r * r;
+                res = res + p;
+            }
+            dist[i][j] = res;
+        }
+
+    // node 0's NaN flag: `cur < NaN` is never true, so a NaN at node 0 pins the BMU to 0 (Som.cpp:293-299)
+    if (blockIdx.x == 0 && tx == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int s = sbase + ty + 16 * i;
+            if (s < s1)
+                nan0[s] = (dist[i][0] != dist[i][0]) ? 1 : 0;
+        }
+    }
+
+    __syncthreads();   // everyone is done with sx before it is reused for the keys
+    u64 *keys = reinterpret_cast<u64 *>(sx);   // 64 samples x 16 tx
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u64 kmin = ~0ull;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int n = nbase + tx + 16 * j;
+            u64 k = n < N ? vsom_key(dist[i][j], (uint32_t)n) : ~0ull;
+            kmin = k < kmin ? k : kmin;
+        }
+        keys[(ty + 16 * i) * 16 + tx] = kmin;
+    }
+    __syncthreads();
+    if (tid < TILE) {
+        int s = sbase + tid;
+        if (s < s1) {
+            u64 kmin = ~0ull;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                u64 k = keys[tid * 16 + t];
+                kmin = k < kmin ? k : kmin;
+            }
+            partial[(size_t)blockIdx.x * pstride + s] = kmin;
+        }
+    }
+}
+
+__global__ void bmu_reduce_kernel(const u64 *__restrict__ partial, int pstride, int ntiles,
+                                  const unsigned char *__restrict__ nan0, int s0, int s1,
+                                  u64 *__restrict__ lastbmu, float *__restrict__ sqres)
+{
+    int s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= s1)
+        return;
+    u64 kmin = ~0ull;
+    for (int t = 0; t < ntiles; ++t) {
+        u64 k = partial[(size_t)t * pstride + s];
+        kmin = k < kmin ? k : kmin;
+    }
+    if (nan0[s]) {
+        lastbmu[s] = 0;
+        sqres[s] = __uint_as_float(0x7FC00000u);
+    } else {
+        lastbmu[s] = kmin & 0xFFFFFFFFull;
+        sqres[s] = __uint_as_float((uint32_t)(kmin >> 32));
+    }
+}
+
+int launch_bmu_full_exact(vsom_ctx *c, size_t s0, size_t s1)
+{
+    if (s1 <= s0)
+        return VSOM_OK;
+    const int ntn = (int)((c->N + TILE - 1) / TILE);
+    const int nts = (int)((s1 - s0 + TILE - 1) / TILE);
+    size_t need = (size_t)ntn * c->Bcap;
+    if (need > c->partial_cap) {
+        if (c->partial)
+            VSOM_HIP_CHECK(hipFree(c->partial));
+        c->partial = nullptr;
+        VSOM_HIP_CHECK(hipMalloc(&c->partial, need * sizeof(u64)));
+        c->partial_cap = need;
+    }
+    DistArgs a = make_dist_args(c);
+    dim3 grid((unsigned)ntn, (unsigned)nts);
+    if (c->transform == VSOM_CLR)
+        hipLaunchKernelGGL(bmu_tile_kernel<true>, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
+                           (int)c->N, c->partial, (int)c->Bcap, c->nan0);
+    else
+        hipLaunchKernelGGL(bmu_tile_kernel<false>, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
+                           (int)c->N, c->partial, (int)c->Bcap, c->nan0);
+    hipLaunchKernelGGL(bmu_reduce_kernel, dim3((unsigned)((s1 - s0 + 255) / 256)), dim3(256), 0,
+                       c->stream, c->partial, (int)c->Bcap, ntn, c->nan0, (int)s0, (int)s1, c->lastbmu,
+                       c->sqres);
+    VSOM_HIP_CHECK(hipGetLastError());
+    return VSOM_OK;
+}
+
+int launch_bmu_full(vsom_ctx *c, size_t s0, size_t s1)
+{
+    TimerScope ts(c, VSOM_T_BMU);
+    return launch_bmu_full_exact(c, s0, s1);
+}
+
+// ------------------------------------------------------------------------------------------
+// local search: Som::findLocalBmu, unsigned (size_t) arithmetic kept literal
+// ------------------------------------------------------------------------------------------
+template <bool CLR>
+__global__ __launch_bounds__(256) void bmu_local_kernel(DistArgs a, int s0, int s1, u64 width,
+                                                        u64 height, u64 *__restrict__ lastbmu,
+                                                        float *__restrict__ sqres)
+{
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63, g = lane >> 3, k = lane & 7;
+    const int s = s0 + wave;
+    if (s >= s1)
+        return;   // wave-uniform
+    const float *xa = a.xa + (size_t)s * a.ldx;
+    const float *xb = a.xb + (size_t)s * a.ldx;
+    const u64 m1 = ~0ull;   // -1uz
+    // firstSearchX / firstSearchY (Som.cpp:341-342)
+    const u64 fsx = (g == 0 || g >= 6) ? m1 : ((g == 1 || g == 5) ? 0ull : 1ull);
+    const u64 fsy = (g <= 2) ? 1ull : ((g == 3 || g == 7) ? 0ull : m1);
+
+    u64 lastBMU = lastbmu[s];
+    float minDist = vsom_group_dist<CLR>(xa, xb, a.ma + (size_t)lastBMU * a.ldm,
+                                         a.mb + (size_t)lastBMU * a.ldm, a.L, k);
+    minDist = __shfl(minDist, 0);
+    u64 minIndex = lastBMU;
+    u64 lastMeasured = lastBMU;
+
+    for (;;) {
+        const u64 lmX = lastMeasured % width, lmY = lastMeasured / width;
+        const u64 lbX = lastBMU % width, lbY = lastBMU / width;
+        if (lastMeasured == lastBMU) {   // first try: 8 neighbours, wrap-then-clamp (Som.cpp:362-385)
+            u64 cx = lmX + fsx;
+            cx = cx < width - 1 ? cx : width - 1;
+            u64 cy = lmY + fsy;
+            cy = cy < height - 1 ? cy : height - 1;
+            u64 node = cy * width + cx;
+            float d = vsom_group_dist<CLR>(xa, xb, a.ma + (size_t)node * a.ldm,
+                                           a.mb + (size_t)node * a.ldm, a.L, k);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float di = __shfl(d, i * 8);
+                u64 ni = __shfl(node, i * 8);
+                if (di < minDist) {
+                    minDist = di;
+                    minIndex = ni;
+                }
+            }
+            if (minIndex == lastBMU)
+                break;
+            lastMeasured = minIndex;
+        } else {
+            if (lmX - lbX) {   // moving in X: 3 nodes ahead (Som.cpp:390-403)
+                u64 cx = lmX + lmX - lbX;
+                cx = cx < width - 1 ? cx : width - 1;
+                u64 off = (u64)(long long)((g < 3 ? g : 0) - 1);   // i = -1,0,1
+                u64 cy = lmY + off;
+                cy = cy < height - 1 ? cy : height - 1;
+                u64 node = cy * width + cx;
+                float d = vsom_group_dist<CLR>(xa, xb, a.ma + (size_t)node * a.ldm,
+                                               a.mb + (size_t)node * a.ldm, a.L, k);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    float di = __shfl(d, i * 8);
+                    u64 ni = __shfl(node, i * 8);
+                    if (di < minDist) {
+                        minDist = di;
+                        minIndex = ni;
+                    }
+                }
+            }
+            // moving in Y (Som.cpp:406-437): the reference's loop starts at SIZE_MAX and its
+            // condition `i < endX + 1` is false at once, so no node is evaluated.
+            (void)lbY;
+            if (minIndex == lastMeasured)
+                break;
+            lastBMU = lastMeasured;
+            lastMeasured = minIndex;
+        }
+    }
+    if (lane == 0) {
+        lastbmu[s] = minIndex;
+        sqres[s] = minDist;   // == ||Comparer(x, M[minIndex])||^2 (same reduction order)
+    }
+}
+
+int launch_bmu_local(vsom_ctx *c, size_t s0, size_t s1)
+{
+    TimerScope ts(c, VSOM_T_BMU);
+    if (s1 <= s0)
+        return VSOM_OK;
+    DistArgs a = make_dist_args(c);
+    size_t waves = s1 - s0;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    if (c->transform == VSOM_CLR)
+        hipLaunchKernelGGL(bmu_local_kernel<true>, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
+                           (u64)c->W, (u64)c->H, c->lastbmu, c->sqres);
+    else
+        hipLaunchKernelGGL(bmu_local_kernel<false>, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
+                           (u64)c->W, (u64)c->H, c->lastbmu, c->sqres);
+    VSOM_HIP_CHECK(hipGetLastError());
+    return VSOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// arbitrary (node,row) pairs: Som::euclidianWeightedDist
+// ------------------------------------------------------------------------------------------
+template <bool CLR>
+__global__ __launch_bounds__(256) void pair_dist_kernel(DistArgs a, const u64 *__restrict__ nodes,
+                                                        const u64 *__restrict__ rows, int count,
+                                                        float *__restrict__ out)
+{
+    const int gid = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 3);
+    const int k = threadIdx.x & 7;
+    const int p = gid < count ? gid : count - 1;
+    u64 node = nodes[p], row = rows[p];
+    float d = vsom_group_dist<CLR>(a.xa + (size_t)row * a.ldx, a.xb + (size_t)row * a.ldx,
+                                   a.ma + (size_t)node * a.ldm, a.mb + (size_t)node * a.ldm, a.L, k);
+    if (gid < count && k == 0)
+        out[gid] = d;
+}
+
+int launch_pair_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *rows_dev, size_t count,
+                     float *out_dev)
+{
+    if (count == 0)
+        return VSOM_OK;
+    DistArgs a = make_dist_args(c);
+    dim3 grid((unsigned)((count * 8 + 255) / 256));
+    if (c->transform == VSOM_CLR)
+        hipLaunchKernelGGL(pair_dist_kernel<true>, grid, dim3(256), 0, c->stream, a, nodes_dev,
+                           rows_dev, (int)count, out_dev);
+    else
+        hipLaunchKernelGGL(pair_dist_kernel<false>, grid, dim3(256), 0, c->stream, a, nodes_dev,
+                           rows_dev, (int)count, out_dev);
+    VSOM_HIP_CHECK(hipGetLastError());
+    return VSOM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// finish: bmuHits and MSE (Som.cpp:777-781 / 800-804), sample order fixed (Q13)
+// ------------------------------------------------------------------------------------------
+#define FIN_TILE 4096
+__global__ __launch_bounds__(256) void finish_kernel(const u64 *__restrict__ lastbmu,
+                                                     const float *__restrict__ sqres, int B,
+                                                     u64 *__restrict__ hits, float *__restrict__ mse)
+{
+    __shared__ float q[FIN_TILE];
+    const float fB = (float)B;
+    float run = 0.f;
+    for (int base = 0; base < B; base += FIN_TILE) {
+        int n = B - base < FIN_TILE ? B - base : FIN_TILE;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            u64 idx = lastbmu[base + i];
+            atomicAdd(&hits[idx], 1ull);
+            q[i] = sqres[base + i] / fB;   // residual.squaredNorm() / (float)epochSize
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < n; ++i)
+                run = run + q[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *mse = run;
+}
+
+int launch_finish(vsom_ctx *c)
+{
+    TimerScope ts(c, VSOM_T_FINISH);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, c->stream, c->lastbmu, c->sqres,
+                       (int)c->B, c->hits, c->mse);
+    VSOM_HIP_CHECK(hipGetLastError());
+    return VSOM_OK;
+}

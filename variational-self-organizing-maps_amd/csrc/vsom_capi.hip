@@ -1,0 +1,565 @@
+// vsom_capi.hip -- the extern "C" entry points declared in include/vsom_hip.h.
+#include "vsom_internal.hpp"
+
+#include <cstring>
+#include <cmath>
+#include <new>
+
+static thread_local std::string g_last_error;
+
+void vsom_set_error(const std::string &msg) { g_last_error = msg; }
+int vsom_fail(int code, const std::string &msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+TimerScope::TimerScope(vsom_ctx *ctx, int w) : c(ctx), which(w), on(ctx->timing)
+{
+    if (!on)
+        return;
+    if (!c->ev_pool.empty()) {
+        ev = c->ev_pool.back();
+        c->ev_pool.pop_back();
+    } else {
+        if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+    }
+    ev.which = which;
+    (void)hipEventRecord(ev.a, c->stream);
+}
+TimerScope::~TimerScope()
+{
+    if (!on)
+        return;
+    (void)hipEventRecord(ev.b, c->stream);
+    c->ev_live.push_back(ev);
+}
+
+static inline uint32_t roundup(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+#define CHECK_CTX(ctx)                                                 \
+    do {                                                               \
+        if (!(ctx))                                                    \
+            return vsom_fail(VSOM_ERR_INVALID, "null context");        \
+        hipError_t _e = hipSetDevice((ctx)->device);                   \
+        if (_e != hipSuccess)                                          \
+            return vsom_fail(VSOM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_e)); \
+    } while (0)
+
+extern "C" {
+
+const char *vsom_last_error(void) { return g_last_error.c_str(); }
+
+int vsom_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+static int free_all(vsom_ctx *c)
+{
+    void *ptrs[] = {c->map, c->sigma, c->S, c->weight, c->hits, c->Xs, c->XP, c->YP, c->Xraw,
+                    c->lastbmu, c->sqres, c->mse, c->bxy, c->pair_i, c->pair_j, c->partial, c->nan0,
+                    c->cw, c->lut, c->v_dev, c->res_dev, c->onl_state, c->onl_f};
+    for (void *p : ptrs)
+        if (p)
+            (void)hipFree(p);
+    if (c->lut_host)
+        (void)hipHostFree(c->lut_host);
+    for (auto &e : c->ev_live) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    for (auto &e : c->ev_pool) {
+        (void)hipEventDestroy(e.a);
+        (void)hipEventDestroy(e.b);
+    }
+    if (c->own_stream)
+        (void)hipStreamDestroy(c->own_stream);
+    return 0;
+}
+
+int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uint32_t in_len,
+                int transform)
+{
+    if (!out)
+        return vsom_fail(VSOM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (width == 0 || height == 0 || in_len == 0)
+        return vsom_fail(VSOM_ERR_INVALID, "width, height and in_len must be > 0");
+    if (transform < VSOM_STANDARD || transform > VSOM_CLR)
+        return vsom_fail(VSOM_ERR_INVALID, "unknown transformation kind");
+    if (transform == VSOM_CLR && in_len < 2)
+        return vsom_fail(VSOM_ERR_INVALID, "CombinatorialLinearRegression needs in_len >= 2");
+    if ((uint64_t)width * height > 0x7FFFFFFFull)
+        return vsom_fail(VSOM_ERR_INVALID, "map too large");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return vsom_fail(VSOM_ERR_HIP, "no HIP device available (libvsom_hip has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return vsom_fail(VSOM_ERR_INVALID, "device index out of range");
+    VSOM_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    VSOM_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return vsom_fail(VSOM_ERR_UNSUPPORTED,
+                         std::string("libvsom_hip is built for gfx950 only, device is ") + prop.gcnArchName);
+
+    vsom_ctx *c = new (std::nothrow) vsom_ctx();
+    if (!c)
+        return vsom_fail(VSOM_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    c->W = width;
+    c->H = height;
+    c->J = in_len;
+    c->N = width * height;
+    c->transform = transform;
+    // Transformation::Length (Transformation.cpp:31-35, 69-73, 162-165)
+    c->D = transform == VSOM_CLR ? in_len * (in_len - 1u) : in_len;
+    c->nparts = transform == VSOM_CLR ? 2 : 1;
+    c->part_len = c->D / c->nparts;
+    c->part_pitch = roundup(c->part_len, VSOM_TK);
+    c->pitch = c->nparts * c->part_pitch;
+    c->xpitch = roundup(c->J, VSOM_TK);
+
+    int rc = VSOM_OK;
+    do {
+        if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = vsom_fail(VSOM_ERR_HIP, "hipStreamCreate failed");
+            break;
+        }
+        c->stream = c->own_stream;
+        const size_t nd = (size_t)c->N * c->pitch;
+        if (hipMalloc(&c->map, nd * 4) != hipSuccess || hipMalloc(&c->sigma, nd * 4) != hipSuccess ||
+            hipMalloc(&c->S, nd * 4) != hipSuccess || hipMalloc(&c->weight, (size_t)c->N * 4) != hipSuccess ||
+            hipMalloc(&c->hits, (size_t)c->N * 8) != hipSuccess || hipMalloc(&c->mse, 16) != hipSuccess ||
+            hipMalloc(&c->onl_state, 64) != hipSuccess || hipMalloc(&c->onl_f, 64) != hipSuccess) {
+            rc = vsom_fail(VSOM_ERR_NOMEM, "hipMalloc of model state failed");
+            break;
+        }
+        (void)hipMemsetAsync(c->map, 0, nd * 4, c->stream);
+        (void)hipMemsetAsync(c->sigma, 0, nd * 4, c->stream);
+        (void)hipMemsetAsync(c->S, 0, nd * 4, c->stream);
+        (void)hipMemsetAsync(c->weight, 0, (size_t)c->N * 4, c->stream);
+        (void)hipMemsetAsync(c->hits, 0, (size_t)c->N * 8, c->stream);
+        (void)hipMemsetAsync(c->mse, 0, 16, c->stream);
+        if (transform == VSOM_CLR) {
+            // pair tables, i<j lexicographic (Transformation.cpp:94-101; tests/test1.cpp:18-43)
+            std::vector<int> pi(c->part_len), pj(c->part_len);
+            size_t p = 0;
+            for (uint32_t i = 0; i < in_len; ++i)
+                for (uint32_t j = i + 1; j < in_len; ++j) {
+                    pi[p] = (int)i;
+                    pj[p] = (int)j;
+                    ++p;
+                }
+            if (hipMalloc(&c->pair_i, p * 4) != hipSuccess || hipMalloc(&c->pair_j, p * 4) != hipSuccess) {
+                rc = vsom_fail(VSOM_ERR_NOMEM, "hipMalloc of pair tables failed");
+                break;
+            }
+            (void)hipMemcpy(c->pair_i, pi.data(), p * 4, hipMemcpyHostToDevice);
+            (void)hipMemcpy(c->pair_j, pj.data(), p * 4, hipMemcpyHostToDevice);
+        }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) {
+            rc = vsom_fail(VSOM_ERR_HIP, "initialisation failed");
+            break;
+        }
+    } while (0);
+    if (rc != VSOM_OK) {
+        std::string keep = g_last_error;
+        free_all(c);
+        delete c;
+        g_last_error = keep;
+        return rc;
+    }
+    *out = c;
+    return VSOM_OK;
+}
+
+void vsom_destroy(vsom_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_all(c);
+    delete c;
+}
+
+int vsom_set_stream(vsom_ctx *c, void *hip_stream)
+{
+    CHECK_CTX(c);
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return VSOM_OK;
+}
+
+int vsom_synchronize(vsom_ctx *c)
+{
+    CHECK_CTX(c);
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
+}
+
+int vsom_set_bmu_mode(vsom_ctx *c, int mode)
+{
+    if (!c || mode < VSOM_BMU_AUTO || mode > VSOM_BMU_SHORTLIST)
+        return vsom_fail(VSOM_ERR_INVALID, "bad bmu mode");
+    c->bmu_mode = mode;
+    return VSOM_OK;
+}
+
+uint32_t vsom_depth(const vsom_ctx *c) { return c ? c->D : 0; }
+uint32_t vsom_nodes(const vsom_ctx *c) { return c ? c->N : 0; }
+uint32_t vsom_residual_len(const vsom_ctx *c) { return c ? c->part_len : 0; }
+size_t vsom_chunk_size(const vsom_ctx *c) { return c ? c->B : 0; }
+
+// host [N][D] <-> device [N][pitch] (each part separately for CLR)
+static int copy_rows(vsom_ctx *c, float *dev, const float *host_in, float *host_out)
+{
+    for (uint32_t part = 0; part < c->nparts; ++part) {
+        float *d = dev + (size_t)part * c->part_pitch;
+        if (host_in) {
+            const float *h = host_in + (size_t)part * c->part_len;
+            VSOM_HIP_CHECK(hipMemcpy2DAsync(d, (size_t)c->pitch * 4, h, (size_t)c->D * 4,
+                                            (size_t)c->part_len * 4, c->N, hipMemcpyHostToDevice,
+                                            c->stream));
+        } else {
+            float *h = host_out + (size_t)part * c->part_len;
+            VSOM_HIP_CHECK(hipMemcpy2DAsync(h, (size_t)c->D * 4, d, (size_t)c->pitch * 4,
+                                            (size_t)c->part_len * 4, c->N, hipMemcpyDeviceToHost,
+                                            c->stream));
+        }
+    }
+    return VSOM_OK;
+}
+
+int vsom_set_state(vsom_ctx *c, const float *map, const float *sigma, const float *S,
+                   const float *weight, const uint64_t *bmu_hits)
+{
+    CHECK_CTX(c);
+    int rc;
+    if (map && (rc = copy_rows(c, c->map, map, nullptr)))
+        return rc;
+    if (sigma && (rc = copy_rows(c, c->sigma, sigma, nullptr)))
+        return rc;
+    if (S && (rc = copy_rows(c, c->S, S, nullptr)))
+        return rc;
+    if (weight)
+        VSOM_HIP_CHECK(hipMemcpyAsync(c->weight, weight, (size_t)c->N * 4, hipMemcpyHostToDevice, c->stream));
+    if (bmu_hits)
+        VSOM_HIP_CHECK(hipMemcpyAsync(c->hits, bmu_hits, (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
+}
+
+int vsom_get_state(vsom_ctx *c, float *map, float *sigma, float *S, float *weight, uint64_t *bmu_hits)
+{
+    CHECK_CTX(c);
+    int rc;
+    if (map && (rc = copy_rows(c, c->map, nullptr, map)))
+        return rc;
+    if (sigma && (rc = copy_rows(c, c->sigma, nullptr, sigma)))
+        return rc;
+    if (S && (rc = copy_rows(c, c->S, nullptr, S)))
+        return rc;
+    if (weight)
+        VSOM_HIP_CHECK(hipMemcpyAsync(weight, c->weight, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->stream));
+    if (bmu_hits)
+        VSOM_HIP_CHECK(hipMemcpyAsync(bmu_hits, c->hits, (size_t)c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
+}
+
+static int ensure_chunk_capacity(vsom_ctx *c, size_t B)
+{
+    if (B <= c->Bcap)
+        return VSOM_OK;
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    void **ptrs[] = {(void **)&c->Xs, (void **)&c->XP, (void **)&c->YP, (void **)&c->lastbmu,
+                     (void **)&c->sqres, (void **)&c->bxy, (void **)&c->nan0, (void **)&c->partial};
+    for (void **p : ptrs) {
+        if (*p)
+            (void)hipFree(*p);
+        *p = nullptr;
+    }
+    c->partial_cap = 0;
+    c->Bcap = 0;
+    size_t cap = (B + 63) / 64 * 64;
+    VSOM_HIP_CHECK(hipMalloc(&c->Xs, cap * c->xpitch * 4));
+    if (c->transform == VSOM_CLR) {
+        VSOM_HIP_CHECK(hipMalloc(&c->XP, cap * c->part_pitch * 4));
+        VSOM_HIP_CHECK(hipMalloc(&c->YP, cap * c->part_pitch * 4));
+    }
+    VSOM_HIP_CHECK(hipMalloc(&c->lastbmu, cap * 8));
+    VSOM_HIP_CHECK(hipMalloc(&c->sqres, cap * 4));
+    VSOM_HIP_CHECK(hipMalloc(&c->bxy, cap * sizeof(int2)));
+    VSOM_HIP_CHECK(hipMalloc(&c->nan0, cap));
+    VSOM_HIP_CHECK(hipMemset(c->lastbmu, 0, cap * 8));
+    VSOM_HIP_CHECK(hipMemset(c->sqres, 0, cap * 4));
+    VSOM_HIP_CHECK(hipMemset(c->nan0, 0, cap));
+    c->Bcap = cap;
+    return VSOM_OK;
+}
+
+int vsom_set_chunk_device(vsom_ctx *c, const float *x_dev, size_t B)
+{
+    CHECK_CTX(c);
+    if (B > 0 && !x_dev)
+        return vsom_fail(VSOM_ERR_INVALID, "x_dev is null");
+    if (B > 0x7FFFFFFFull)
+        return vsom_fail(VSOM_ERR_INVALID, "chunk too large");
+    int rc = ensure_chunk_capacity(c, B);
+    if (rc)
+        return rc;
+    c->B = B;
+    return launch_stage_chunk(c, x_dev, B);
+}
+
+int vsom_upload_chunk(vsom_ctx *c, const float *x_host, size_t B)
+{
+    CHECK_CTX(c);
+    if (B > 0 && !x_host)
+        return vsom_fail(VSOM_ERR_INVALID, "x_host is null");
+    size_t need = B * c->J;
+    if (need > c->Xraw_cap) {
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->Xraw)
+            (void)hipFree(c->Xraw);
+        c->Xraw = nullptr;
+        c->Xraw_cap = 0;
+        VSOM_HIP_CHECK(hipMalloc(&c->Xraw, need * 4));
+        c->Xraw_cap = need;
+    }
+    if (need)
+        VSOM_HIP_CHECK(hipMemcpyAsync(c->Xraw, x_host, need * 4, hipMemcpyHostToDevice, c->stream));
+    int rc = vsom_set_chunk_device(c, c->Xraw, B);
+    if (rc)
+        return rc;
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));   // x_host may be reused by the caller
+    return VSOM_OK;
+}
+
+int vsom_get_last_bmu(vsom_ctx *c, uint64_t *out_host)
+{
+    CHECK_CTX(c);
+    if (c->B && !out_host)
+        return vsom_fail(VSOM_ERR_INVALID, "null output");
+    if (c->B)
+        VSOM_HIP_CHECK(hipMemcpyAsync(out_host, c->lastbmu, c->B * 8, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
+}
+
+int vsom_set_last_bmu(vsom_ctx *c, const uint64_t *in_host)
+{
+    CHECK_CTX(c);
+    if (c->B && !in_host)
+        return vsom_fail(VSOM_ERR_INVALID, "null input");
+    for (size_t i = 0; i < c->B; ++i)
+        if (in_host[i] >= c->N)
+            return vsom_fail(VSOM_ERR_INVALID, "lastBMU index out of range");
+    if (c->B)
+        VSOM_HIP_CHECK(hipMemcpyAsync(c->lastbmu, in_host, c->B * 8, hipMemcpyHostToDevice, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
+}
+
+int vsom_get_sqres(vsom_ctx *c, float *out_host)
+{
+    CHECK_CTX(c);
+    if (c->B && !out_host)
+        return vsom_fail(VSOM_ERR_INVALID, "null output");
+    if (c->B)
+        VSOM_HIP_CHECK(hipMemcpyAsync(out_host, c->sqres, c->B * 4, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
+}
+
+static int copy_search_results(vsom_ctx *c, uint64_t *idx, float *dist)
+{
+    if (idx && c->B)
+        VSOM_HIP_CHECK(hipMemcpyAsync(idx, c->lastbmu, c->B * 8, hipMemcpyDeviceToHost, c->stream));
+    if (dist && c->B)
+        VSOM_HIP_CHECK(hipMemcpyAsync(dist, c->sqres, c->B * 4, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
+}
+
+int vsom_bmu_batch(vsom_ctx *c, uint64_t *idx_out_host, float *dist_out_host)
+{
+    CHECK_CTX(c);
+    int rc = launch_bmu_full(c, 0, c->B);
+    if (rc)
+        return rc;
+    return copy_search_results(c, idx_out_host, dist_out_host);
+}
+
+int vsom_bmu_local_batch(vsom_ctx *c, uint64_t *idx_out_host, float *dist_out_host)
+{
+    CHECK_CTX(c);
+    int rc = launch_bmu_local(c, 0, c->B);
+    if (rc)
+        return rc;
+    return copy_search_results(c, idx_out_host, dist_out_host);
+}
+
+int vsom_distances(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *rows_host, size_t count,
+                   float *dist_out_host)
+{
+    CHECK_CTX(c);
+    if (count == 0)
+        return VSOM_OK;
+    if (!nodes_host || !rows_host || !dist_out_host)
+        return vsom_fail(VSOM_ERR_INVALID, "null argument");
+    if (count > 0x0FFFFFFFull)
+        return vsom_fail(VSOM_ERR_INVALID, "too many pairs");
+    for (size_t i = 0; i < count; ++i)
+        if (nodes_host[i] >= c->N || rows_host[i] >= c->B)
+            return vsom_fail(VSOM_ERR_INVALID, "pair index out of range");
+    u64 *dn = nullptr, *dr = nullptr;
+    float *dd = nullptr;
+    int rc = VSOM_OK;
+    if (hipMalloc(&dn, count * 8) != hipSuccess || hipMalloc(&dr, count * 8) != hipSuccess ||
+        hipMalloc(&dd, count * 4) != hipSuccess) {
+        rc = vsom_fail(VSOM_ERR_NOMEM, "hipMalloc failed");
+    } else {
+        (void)hipMemcpyAsync(dn, nodes_host, count * 8, hipMemcpyHostToDevice, c->stream);
+        (void)hipMemcpyAsync(dr, rows_host, count * 8, hipMemcpyHostToDevice, c->stream);
+        rc = launch_pair_dist(c, dn, dr, count, dd);
+        if (rc == VSOM_OK) {
+            (void)hipMemcpyAsync(dist_out_host, dd, count * 4, hipMemcpyDeviceToHost, c->stream);
+            if (hipStreamSynchronize(c->stream) != hipSuccess)
+                rc = vsom_fail(VSOM_ERR_HIP, "distance kernel failed");
+        }
+    }
+    if (dn)
+        (void)hipFree(dn);
+    if (dr)
+        (void)hipFree(dr);
+    if (dd)
+        (void)hipFree(dd);
+    return rc;
+}
+
+int vsom_batch_phase1_async(vsom_ctx *c, size_t s0, size_t s1, int is_first)
+{
+    CHECK_CTX(c);
+    if (s0 > s1 || s1 > c->B)
+        return vsom_fail(VSOM_ERR_INVALID, "sample range out of bounds");
+    return is_first ? launch_bmu_full(c, s0, s1) : launch_bmu_local(c, s0, s1);
+}
+
+int vsom_batch_finish_async(vsom_ctx *c)
+{
+    CHECK_CTX(c);
+    if (c->B == 0)
+        return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
+    return launch_finish(c);
+}
+
+int vsom_batch_phase2_async(vsom_ctx *c, double sigma, size_t n0, size_t n1)
+{
+    CHECK_CTX(c);
+    if (n0 > n1 || n1 > c->N)
+        return vsom_fail(VSOM_ERR_INVALID, "node range out of bounds");
+    if (c->B == 0)
+        return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
+    return launch_phase2(c, sigma, n0, n1);
+}
+
+int vsom_batch_epoch_async(vsom_ctx *c, double sigma, int is_first)
+{
+    CHECK_CTX(c);
+    if (c->B == 0)
+        return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
+    int rc = vsom_batch_phase1_async(c, 0, c->B, is_first);
+    if (rc)
+        return rc;
+    if ((rc = launch_finish(c)))
+        return rc;
+    return launch_phase2(c, sigma, 0, c->N);
+}
+
+int vsom_get_mse(vsom_ctx *c, float *mse_out)
+{
+    CHECK_CTX(c);
+    if (!mse_out)
+        return vsom_fail(VSOM_ERR_INVALID, "null output");
+    VSOM_HIP_CHECK(hipMemcpyAsync(mse_out, c->mse, 4, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
+}
+
+int vsom_batch_epoch(vsom_ctx *c, double sigma, int is_first, float *mse_out)
+{
+    int rc = vsom_batch_epoch_async(c, sigma, is_first);
+    if (rc)
+        return rc;
+    if (mse_out)
+        return vsom_get_mse(c, mse_out);
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
+}
+
+void *vsom_device_ptr(vsom_ctx *c, int which)
+{
+    if (!c)
+        return nullptr;
+    switch (which) {
+    case VSOM_BUF_MAP: return c->map;
+    case VSOM_BUF_SIGMA: return c->sigma;
+    case VSOM_BUF_S: return c->S;
+    case VSOM_BUF_WEIGHT: return c->weight;
+    case VSOM_BUF_HITS: return c->hits;
+    case VSOM_BUF_LASTBMU: return c->lastbmu;
+    case VSOM_BUF_SQRES: return c->sqres;
+    case VSOM_BUF_CHUNK: return c->Xs;
+    default: return nullptr;
+    }
+}
+
+uint32_t vsom_pitch(const vsom_ctx *c) { return c ? c->pitch : 0; }
+uint32_t vsom_chunk_pitch(const vsom_ctx *c) { return c ? c->xpitch : 0; }
+
+int vsom_enable_timing(vsom_ctx *c, int on)
+{
+    if (!c)
+        return vsom_fail(VSOM_ERR_INVALID, "null context");
+    c->timing = on != 0;
+    return VSOM_OK;
+}
+
+int vsom_get_timing(vsom_ctx *c, float *ms_out, uint32_t *count_out, int reset)
+{
+    CHECK_CTX(c);
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (auto &e : c->ev_live) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->t_ms[e.which] += ms;
+            c->t_cnt[e.which] += 1;
+        }
+        c->ev_pool.push_back(e);
+    }
+    c->ev_live.clear();
+    for (int i = 0; i < VSOM_T_COUNT; ++i) {
+        if (ms_out)
+            ms_out[i] = c->t_ms[i];
+        if (count_out)
+            count_out[i] = c->t_cnt[i];
+        if (reset) {
+            c->t_ms[i] = 0.f;
+            c->t_cnt[i] = 0;
+        }
+    }
+    return VSOM_OK;
+}
+
+}   // extern "C"

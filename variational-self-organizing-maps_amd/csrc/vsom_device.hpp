@@ -1,0 +1,83 @@
+// vsom_device.hpp -- device helpers shared by the gfx950 kernels.
+//
+// Strict-arithmetic rules (the kernels must reproduce the reference's SSE2, non-FMA fp32
+// results bit for bit): this translation unit is compiled with -ffp-contract=off and
+// -fhip-fp32-correctly-rounded-divide-sqrt; f32 subnormals are kept (hipcc default mode).
+#pragma once
+#include "vsom_internal.hpp"
+
+// operands of one distance evaluation (Som::euclidianWeightedDist, Som.cpp:124-141)
+struct DistArgs {
+    const float *xa;   // sample rows: Xs (Standard/Median) or XP (CLR)
+    const float *xb;   // CLR: YP rows
+    int ldx;
+    const float *ma;   // model rows: map (A part for CLR)
+    const float *mb;   // CLR: B part (= map + part_pitch)
+    int ldm;
+    int L;             // comparer length: D (Standard/Median) or P = D/2 (CLR)
+};
+
+// residual element of Transformation::Comparer
+//   Standard/Median: model - value                     (Transformation.cpp:8,46)
+//   CLR: (A*x' + B) - y', one rounding per operation   (Transformation.cpp:104)
+template <bool CLR>
+__device__ __forceinline__ float vsom_resid(float x, float y, float m, float b)
+{
+    if (CLR) {
+        float t = m * x;
+        t = t + b;
+        t = t - y;
+        return t;
+    }
+    return m - x;
+}
+
+// order-preserving key for argmin with lowest-index tie break; NaN never wins (Som.cpp:299)
+__device__ __forceinline__ u64 vsom_key(float d, uint32_t node)
+{
+    uint32_t bits = (d != d) ? 0xFFFFFFFFu : __float_as_uint(d);
+    return ((u64)bits << 32) | (u64)node;
+}
+
+// Distance of one (sample,node) pair computed by a group of 8 consecutive lanes, lane k
+// owning Eigen's accumulator class k (elements d = k mod 8), followed by the reduction tree
+// of Eigen's SSE linear-vectorised redux:
+//   q_k = p0_k + p1_k ; [+ one more packet] ; (q0+q2)+(q1+q3) ; + scalar tail.
+// All 8 lanes return the same value.  xa/xb/ma/mb are the row pointers of the pair.
+template <bool CLR>
+__device__ __forceinline__ float vsom_group_dist(const float *xa, const float *xb,
+                                                 const float *ma, const float *mb, int L, int k)
+{
+    const int L8 = L & ~7;
+    float acc = 0.f;
+    for (int d = k; d < L8; d += 8) {
+        float r = vsom_resid<CLR>(xa[d], CLR ? xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
+        float p = r * r;
+        acc = acc + p;
+    }
+    float q = acc + __shfl_xor(acc, 4);          // p0_k + p1_k (commutative: same bits in k, k^4)
+    const int rem = L - L8;
+    if (rem >= 4) {
+        int d = L8 + (k & 3);
+        float r = vsom_resid<CLR>(xa[d], CLR ? xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
+        float p = r * r;
+        q = q + p;
+    }
+    float t = q + __shfl_xor(q, 2);              // (q0+q2) in lanes 0,2 ; (q1+q3) in lanes 1,3
+    float res = t + __shfl_xor(t, 1);            // (q0+q2)+(q1+q3)
+    for (int tt = (rem >= 4 ? 4 : 0); tt < rem; ++tt) {
+        int d = L8 + tt;
+        float r = vsom_resid<CLR>(xa[d], CLR ? xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
+        float p = r * r;
+        res = res + p;
+    }
+    return res;
+}
+
+// SomIndex(const Som&, size_t) (SomIndex.cpp:13-18): y divides by HEIGHT (Q10)
+__device__ __forceinline__ void vsom_somindex(u64 idx, u64 W, u64 H, int &x, int &y)
+{
+    u64 xm = idx % W;
+    x = (int)xm;
+    y = (int)((idx - xm) / H);
+}

@@ -1,0 +1,100 @@
+// vsom_internal.hpp -- shared declarations of libvsom_hip.so (gfx950 only).
+//
+// Layout in HBM (see DESIGN.md "Data layout"):
+//   model rows   : N x pitch fp32, pitch = nparts * part_pitch, part_pitch = roundup(part_len,32)
+//                  Standard/Median: one part of D floats; CLR: [A(P) | B(P)], P = D/2.
+//                  pad columns are kept at zero.
+//   samples      : Bcap x xpitch fp32 (xpitch = roundup(J,32), zero padded)
+//   CLR samples  : XP/YP Bcap x part_pitch (x'_p = x[i(p)], y'_p = x[j(p)], pairs i<j
+//                  lexicographic, Transformation.cpp:94-101)
+//   cw           : B x ldn float2 (c = w/W prefix, w) per (sample, node)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vsom_hip.h"
+
+typedef unsigned long long u64;
+
+#define VSOM_TK 32          // K-chunk of the tile kernels; row pitches are multiples of it
+
+struct vsom_ctx {
+    int device = 0;
+    uint32_t W = 0, H = 0, J = 0, D = 0, N = 0;
+    int transform = 0;
+    uint32_t nparts = 1, part_len = 0, part_pitch = 0, pitch = 0;
+    uint32_t xpitch = 0;
+    int bmu_mode = VSOM_BMU_AUTO;
+
+    hipStream_t own_stream = nullptr, stream = nullptr;
+
+    // model state
+    float *map = nullptr, *sigma = nullptr, *S = nullptr, *weight = nullptr;
+    u64 *hits = nullptr;
+
+    // chunk
+    size_t B = 0, Bcap = 0;
+    float *Xs = nullptr, *XP = nullptr, *YP = nullptr;
+    float *Xraw = nullptr;          // staging for host uploads (B x J, unpadded)
+    size_t Xraw_cap = 0;
+    u64 *lastbmu = nullptr;
+    float *sqres = nullptr;
+    float *mse = nullptr;           // [1]
+    int2 *bxy = nullptr;            // BMU coordinates per sample (SomIndex quirk)
+    int *pair_i = nullptr, *pair_j = nullptr;   // CLR pair tables [P]
+
+    // BMU tile-search scratch
+    u64 *partial = nullptr; size_t partial_cap = 0;
+    unsigned char *nan0 = nullptr;
+
+    // neighbourhood
+    float2 *cw = nullptr; size_t cw_cap = 0;
+    float *lut = nullptr; size_t lut_cap = 0; float *lut_host = nullptr;
+    double lut_sigma = -1.0; uint32_t lut_w = 0, lut_h = 0;
+
+    // online path scratch
+    float *v_dev = nullptr;         // one sample, padded
+    float *res_dev = nullptr;       // residual
+    u64 *onl_state = nullptr;       // [4]: bmu, lastbmu, ...
+    float *onl_f = nullptr;         // [4]: dist, mse
+
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int which; };
+    std::vector<Ev> ev_live;
+    std::vector<Ev> ev_pool;
+    float t_ms[VSOM_T_COUNT] = {0};
+    uint32_t t_cnt[VSOM_T_COUNT] = {0};
+};
+
+// error plumbing -----------------------------------------------------------------------------
+void vsom_set_error(const std::string &msg);
+int vsom_fail(int code, const std::string &msg);
+#define VSOM_HIP_CHECK(expr)                                                             \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess)                                                            \
+            return vsom_fail(VSOM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+struct TimerScope {
+    vsom_ctx *c; int which; vsom_ctx::Ev ev; bool on;
+    TimerScope(vsom_ctx *ctx, int w);
+    ~TimerScope();
+};
+
+// kernel launchers (each enqueues on ctx->stream and returns a vsom_status) -------------------
+int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B);
+int launch_bmu_full(vsom_ctx *c, size_t s0, size_t s1);           // findBmu for samples [s0,s1)
+int launch_bmu_local(vsom_ctx *c, size_t s0, size_t s1);          // findLocalBmu
+int launch_pair_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *rows_dev, size_t count,
+                     float *out_dev);
+int launch_finish(vsom_ctx *c);
+int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1);
+int launch_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn, size_t B,
+                        const float *x_dev_padded, bool single);
+int ensure_lut(vsom_ctx *c, double sigma);

@@ -1,0 +1,299 @@
+// vsom_update.hip -- phase 2 of Som::trainBatchSomEpoch (Som.cpp:809-876) on gfx950.
+//
+// For every node i (independent) and the samples j of the chunk in load order:
+//     w = (float)calculateNeighbourhoodWeight(node, bmu_j, sigma)       Som.cpp:851, 949-975
+//     W += w ; c = w / W                                                  :857, :864
+//     delta = Stepper(x_j, M) ; M = M + c*delta ; S = S + (w*delta)*delta  :861-867
+//   map[i] = M ; sigmaMap[i] = sqrt(S / W) ; weightMap[i] = W             :870-875
+//
+// Split into
+//   bxy_kernel   : SomIndex(*this, lastBMU[j]) once per sample               (:847-849)
+//   cw_kernel    : one thread per node walks the samples: LUT lookup of w (the double exp is
+//                  tabulated on the host over (|dx|,|dy|), bit-identical), the fp32 prefix sum
+//                  W and c = w/W -> cw[j][i] = (c, w).  N chains of length B.
+//   update_*     : the N*D chains.  Lane = node, RD consecutive dims in registers (M,S);
+//                  x_j[d] is wave-uniform and arrives through scalar loads (SGPR operands of
+//                  v_pk_* VALU ops), (c,w) is one coalesced 8-byte load per lane per sample.
+//                  Every fp32 operation is rounded separately (-ffp-contract=off), so the
+//                  result is bit-identical to the reference's SSE2 build.
+#include "vsom_device.hpp"
+#include <cmath>
+
+typedef const __attribute__((address_space(4))) float *vsom_cfp;   // forces s_load_* (scalar cache)
+
+__global__ void bxy_kernel(const u64 *__restrict__ lastbmu, int B, int W, int H,
+                           int2 *__restrict__ bxy)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B)
+        return;
+    int x, y;
+    vsom_somindex(lastbmu[j], (u64)W, (u64)H, x, y);
+    bxy[j] = make_int2(x, y);
+}
+
+// one thread per node of [n0,n1)
+__global__ __launch_bounds__(64) void cw_kernel(const int2 *__restrict__ bxy, int B, int n0, int n1,
+                                                int W, int H, const float *__restrict__ lut,
+                                                int lutw, float2 *__restrict__ cw, int ldn,
+                                                float *__restrict__ weight)
+{
+    const int nl = blockIdx.x * blockDim.x + threadIdx.x;
+    const int node = n0 + nl;
+    const bool valid = node < n1;
+    int cx = 0, cy = 0;
+    if (valid)
+        vsom_somindex((u64)node, (u64)W, (u64)H, cx, cy);   // SomIndex(*this, index) (Som.cpp:816)
+    float sumW = 0.f;                                        // :840
+    float2 *out = cw + (valid ? nl : 0);
+    for (int j = 0; j < B; ++j) {
+        int2 b = bxy[j];
+        int dx = cx - b.x, dy = cy - b.y;
+        dx = dx < 0 ? -dx : dx;
+        dy = dy < 0 ? -dy : dy;
+        float w = lut[dy * lutw + dx];   // (float)calculateNeighbourhoodWeight(...)  :851
+        sumW = sumW + w;                 // :857
+        float c = w / sumW;              // currentWeight / sumOfWeights  :864 (0/0 -> NaN, Q7)
+        if (valid)
+            out[(size_t)j * ldn] = make_float2(c, w);
+    }
+    if (valid)
+        weight[node] = sumW;   // :875
+}
+
+// Eigen scalar_sign_op<float>: NaN -> NaN, else (a>0)-(a<0) as float (Transformation.cpp:50)
+__device__ __forceinline__ float vsom_sign(float a)
+{
+    return a > 0.f ? 1.f : (a < 0.f ? -1.f : (a != a ? a : 0.f));
+}
+
+// Standard / Median: lane = node, RD dims per lane, 4 waves per workgroup = 4 dim slices
+template <int RD, bool MEDIAN>
+__global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ Xs, int ldx,
+                                                     const float2 *__restrict__ cw, int ldn, int B,
+                                                     int n0, int nloc, int D, int nslices,
+                                                     float *__restrict__ map,
+                                                     float *__restrict__ sigma, int pitch,
+                                                     const float *__restrict__ weight)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * 4 + wave;
+    if (slice >= nslices)
+        return;
+    const int d0 = slice * RD;
+    const int nl = blockIdx.x * 64 + lane;
+    const bool valid = nl < nloc;
+    const int nlc = valid ? nl : nloc - 1;
+
+    float M[RD], S[RD];
+#pragma unroll
+    for (int k = 0; k < RD; ++k) {
+        M[k] = 0.f;   // currentModel.setZero()       :843
+        S[k] = 0.f;   // currentModelSigma.setZero()  :844
+    }
+    const float2 *cwp = cw + nlc;
+    vsom_cfp xr = (vsom_cfp)(Xs + d0);
+    for (int j = 0; j < B; ++j) {
+        const float2 v = cwp[(size_t)j * ldn];
+        const float c = v.x, w = v.y;
+#pragma unroll
+        for (int k = 0; k < RD; ++k) {
+            float x = xr[k];
+            float dl = x - M[k];            // Stepper: value - model        (Transformation.cpp:12)
+            if (MEDIAN)
+                dl = vsom_sign(dl);         //          sign(value - model)  (Transformation.cpp:50)
+            float t = c * dl;
+            M[k] = M[k] + t;                // :864
+            float u = w * dl;
+            u = u * dl;
+            S[k] = S[k] + u;                // :867
+        }
+        xr += ldx;
+    }
+    if (valid) {
+        const size_t node = (size_t)(n0 + nl);
+        const float Wf = weight[node];
+#pragma unroll
+        for (int k = 0; k < RD; ++k) {
+            if (d0 + k < D) {
+                map[node * pitch + d0 + k] = M[k];                   // :870
+                sigma[node * pitch + d0 + k] = sqrtf(S[k] / Wf);     // :873
+            }
+        }
+    }
+}
+
+// CLR: lane = node, RP pairs per lane; model = [A | B] (Transformation.cpp:107-142)
+template <int RP>
+__global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict__ XP,
+                                                         const float *__restrict__ YP, int ldx,
+                                                         const float2 *__restrict__ cw, int ldn,
+                                                         int B, int n0, int nloc, int P, int ppitch,
+                                                         int nslices, float *__restrict__ map,
+                                                         float *__restrict__ sigma, int pitch,
+                                                         const float *__restrict__ weight)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * 4 + wave;
+    if (slice >= nslices)
+        return;
+    const int p0 = slice * RP;
+    const int nl = blockIdx.x * 64 + lane;
+    const bool valid = nl < nloc;
+    const int nlc = valid ? nl : nloc - 1;
+
+    float A[RP], Bv[RP], SA[RP], SB[RP];
+#pragma unroll
+    for (int k = 0; k < RP; ++k) {
+        A[k] = 0.f;
+        Bv[k] = 0.f;
+        SA[k] = 0.f;
+        SB[k] = 0.f;
+    }
+    const float2 *cwp = cw + nlc;
+    vsom_cfp xr = (vsom_cfp)(XP + p0);
+    vsom_cfp yr = (vsom_cfp)(YP + p0);
+    for (int j = 0; j < B; ++j) {
+        const float2 v = cwp[(size_t)j * ldn];
+        const float c = v.x, w = v.y;
+#pragma unroll
+        for (int k = 0; k < RP; ++k) {
+            float xp = xr[k], yp = yr[k];
+            float inner = A[k] * xp;       // A.*x' + B - y'   (Transformation.cpp:129)
+            inner = inner + Bv[k];
+            inner = inner - yp;
+            float m2 = -2.f * inner;       // -2*inner (exact)  :135-136
+            float aD = m2 * xp;            // aDelta            :135
+            float tA = c * aD;
+            float tB = c * m2;
+            float uA = w * aD;
+            uA = uA * aD;
+            float uB = w * m2;
+            uB = uB * m2;
+            A[k] = A[k] + tA;              // Som.cpp:864
+            Bv[k] = Bv[k] + tB;
+            SA[k] = SA[k] + uA;            // Som.cpp:867
+            SB[k] = SB[k] + uB;
+        }
+        xr += ldx;
+        yr += ldx;
+    }
+    if (valid) {
+        const size_t node = (size_t)(n0 + nl);
+        const float Wf = weight[node];
+#pragma unroll
+        for (int k = 0; k < RP; ++k) {
+            if (p0 + k < P) {
+                map[node * pitch + p0 + k] = A[k];
+                map[node * pitch + ppitch + p0 + k] = Bv[k];
+                sigma[node * pitch + p0 + k] = sqrtf(SA[k] / Wf);
+                sigma[node * pitch + ppitch + p0 + k] = sqrtf(SB[k] / Wf);
+            }
+        }
+    }
+}
+
+// Host: tabulate (float)calculateNeighbourhoodWeight over (|dx|,|dy|) (Som.cpp:949-975).
+// The argument of exp depends on (cx-bx)^2 and (cy-by)^2 only, so the table is bit-identical
+// to per-pair evaluation with the same libm.
+double vsom_neighbourhood_weight(size_t cx, size_t cy, size_t bx, size_t by, double sigma)
+{
+    if (sigma > 1.0) {
+        double cxd = (double)cx, cyd = (double)cy, bxd = (double)bx, byd = (double)by;
+        return std::exp(-((cxd - bxd) * (cxd - bxd) / 2.0 / sigma / sigma +
+                          (cyd - byd) * (cyd - byd) / 2.0 / sigma / sigma));
+    } else if (cx == bx && cy == by) {
+        return 1.0;
+    }
+    return 0.0;
+}
+
+int ensure_lut(vsom_ctx *c, double sigma)
+{
+    if (c->lut && c->lut_sigma == sigma)
+        return VSOM_OK;
+    // largest y that SomIndex(som, idx) can produce is (N-W)/H (Q10)
+    uint32_t ymax = c->N ? (c->N - c->W) / c->H : 0;
+    uint32_t lh = ymax + 1, lw = c->W;
+    size_t need = (size_t)lh * lw;
+    if (need > c->lut_cap) {
+        if (c->lut)
+            VSOM_HIP_CHECK(hipFree(c->lut));
+        if (c->lut_host)
+            VSOM_HIP_CHECK(hipHostFree(c->lut_host));
+        c->lut = nullptr;
+        c->lut_host = nullptr;
+        VSOM_HIP_CHECK(hipMalloc(&c->lut, need * sizeof(float)));
+        VSOM_HIP_CHECK(hipHostMalloc(&c->lut_host, need * sizeof(float)));
+        c->lut_cap = need;
+    } else {
+        // the previous async copy may still read lut_host
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    for (uint32_t dy = 0; dy < lh; ++dy)
+        for (uint32_t dx = 0; dx < lw; ++dx)
+            c->lut_host[(size_t)dy * lw + dx] = (float)vsom_neighbourhood_weight(dx, dy, 0, 0, sigma);
+    VSOM_HIP_CHECK(hipMemcpyAsync(c->lut, c->lut_host, need * sizeof(float), hipMemcpyHostToDevice,
+                                  c->stream));
+    c->lut_sigma = sigma;
+    c->lut_w = lw;
+    c->lut_h = lh;
+    return VSOM_OK;
+}
+
+int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
+{
+    if (n1 <= n0 || c->B == 0)
+        return VSOM_OK;
+    int rc = ensure_lut(c, sigma);
+    if (rc)
+        return rc;
+    const size_t nloc = n1 - n0;
+    const size_t ldn = (nloc + 63) / 64 * 64;
+    const size_t need = c->B * ldn;
+    if (need > c->cw_cap) {
+        if (c->cw)
+            VSOM_HIP_CHECK(hipFree(c->cw));
+        c->cw = nullptr;
+        VSOM_HIP_CHECK(hipMalloc(&c->cw, need * sizeof(float2)));
+        c->cw_cap = need;
+    }
+    {
+        TimerScope ts(c, VSOM_T_CW);
+        hipLaunchKernelGGL(bxy_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, c->stream,
+                           c->lastbmu, (int)c->B, (int)c->W, (int)c->H, c->bxy);
+        hipLaunchKernelGGL(cw_kernel, dim3((unsigned)((nloc + 63) / 64)), dim3(64), 0, c->stream,
+                           c->bxy, (int)c->B, (int)n0, (int)n1, (int)c->W, (int)c->H, c->lut,
+                           (int)c->lut_w, c->cw, (int)ldn, c->weight);
+        VSOM_HIP_CHECK(hipGetLastError());
+    }
+    {
+        TimerScope ts(c, VSOM_T_UPDATE);
+        const unsigned gx = (unsigned)((nloc + 63) / 64);
+        if (c->transform == VSOM_CLR) {
+            constexpr int RP = 8;
+            const int nsl = (int)((c->part_len + RP - 1) / RP);
+            dim3 grid(gx, (unsigned)((nsl + 3) / 4));
+            hipLaunchKernelGGL(update_clr_kernel<RP>, grid, dim3(256), 0, c->stream, c->XP, c->YP,
+                               (int)c->part_pitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
+                               (int)c->part_len, (int)c->part_pitch, nsl, c->map, c->sigma,
+                               (int)c->pitch, c->weight);
+        } else {
+            constexpr int RD = 16;
+            const int nsl = (int)((c->D + RD - 1) / RD);
+            dim3 grid(gx, (unsigned)((nsl + 3) / 4));
+            if (c->transform == VSOM_MEDIAN)
+                hipLaunchKernelGGL((update_kernel<RD, true>), grid, dim3(256), 0, c->stream, c->Xs,
+                                   (int)c->xpitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
+                                   (int)c->D, nsl, c->map, c->sigma, (int)c->pitch, c->weight);
+            else
+                hipLaunchKernelGGL((update_kernel<RD, false>), grid, dim3(256), 0, c->stream, c->Xs,
+                                   (int)c->xpitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
+                                   (int)c->D, nsl, c->map, c->sigma, (int)c->pitch, c->weight);
+        }
+        VSOM_HIP_CHECK(hipGetLastError());
+    }
+    return VSOM_OK;
+}
