@@ -1,0 +1,78 @@
+"""GPU parity of the online path (Som::trainSingle / trainBasicSom inner loop) against the
+oracle: every transformation x both decay functions, sigma > 1 (full search, window) and
+sigma <= 1 (local search, indicator neighbourhood)."""
+import numpy as np
+import pytest
+
+import gen
+import vsom_amd
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def beq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind == "f":
+        return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+    return (a == b).all()
+
+
+CASES = [
+    ("std_exp", 12, 10, 9, 0, 0, 60, 2.2),
+    ("std_inv", 12, 10, 9, 0, 1, 60, 2.2),
+    ("std_exp_big_window", 16, 16, 40, 0, 0, 40, 9.0),
+    ("median_exp", 9, 9, 17, 1, 0, 50, 1.6),
+    ("median_inv", 9, 9, 17, 1, 1, 50, 3.0),
+    ("clr_exp", 7, 7, 6, 2, 0, 40, 2.0),
+    ("clr_inv", 7, 7, 5, 2, 1, 40, 1.4),
+    ("local_sigma1_exp", 10, 10, 8, 0, 0, 60, 1.0),
+    ("local_sigma_lt1_inv", 10, 10, 8, 0, 1, 60, 0.7),
+    ("d794", 8, 8, 794, 0, 0, 12, 2.5),
+]
+
+
+@pytest.mark.parametrize("name,W,H,J,tr,fn,B,sigma", CASES, ids=[c[0] for c in CASES])
+def test_online_chunk(name, W, H, J, tr, fn, B, sigma):
+    D = po.length(tr, J)
+    X = gen.correlated(B, J, 5) if tr == 2 else (gen.mnist_like(B, 3, J) if J > 700 else gen.blobs(B, J, 4, 1, 2, sigma=0.3))
+    init = gen.random_map(W * H, D, seed=13)
+    eta = 0.05 if tr != 2 else 0.005
+    o = po.OracleSom(W, H, J, tr)
+    o.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    ctx.set_state(map=init)
+    for rep in range(2):          # second pass accumulates weightMap/SMap further (Q9)
+        lb = np.zeros(B, np.uint64)
+        mse_o = o.train_online_chunk(X, lb, eta, sigma, fn)
+        ctx.upload_chunk(X)
+        mse_g = ctx.train_online_chunk(eta, sigma, fn)
+        assert beq(ctx.get_last_bmu(), lb), (name, rep, "lastBMU")
+        st = ctx.get_state()
+        for k in ("map", "S", "sigma", "weight", "hits"):
+            assert beq(st[k], getattr(o, k)), (name, rep, k)
+        assert beq(np.float32(mse_g), np.float32(mse_o)), (name, rep, mse_g, mse_o)
+    ctx.close()
+
+
+@pytest.mark.parametrize("tr,fn,sigma", [(0, 0, 3.0), (1, 1, 2.0), (2, 0, 1.5), (0, 1, 1.0)])
+def test_train_single_api(tr, fn, sigma):
+    W, H, J = 11, 9, 6
+    D = po.length(tr, J)
+    X = gen.correlated(10, J, 5) if tr == 2 else gen.blobs(10, J, 3, 1, 2, sigma=0.3)
+    init = gen.random_map(W * H, D, seed=3)
+    o = po.OracleSom(W, H, J, tr)
+    o.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    ctx.set_state(map=init)
+    last_o = last_g = 5
+    for j in range(10):
+        bo, ro, do, last_o = o.train_single(X[j], 0.02, sigma, last_o, fn)
+        bg, rg, dg, last_g = ctx.train_single(X[j], 0.02, sigma, last_g, fn)
+        assert bo == bg and last_o == last_g
+        assert beq(ro, rg) and beq(do, dg)
+    st = ctx.get_state()
+    for k in ("map", "S", "sigma", "weight"):
+        assert beq(st[k], getattr(o, k)), k
+    assert (st["hits"] == 0).all()      # trainSingle itself does not count hits (addBmu is the driver's)
+    ctx.close()

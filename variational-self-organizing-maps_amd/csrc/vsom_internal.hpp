@@ -55,6 +55,7 @@ struct vsom_ctx {
     float2 *cw = nullptr; size_t cw_cap = 0;
     float *lut = nullptr; size_t lut_cap = 0; float *lut_host = nullptr;
     double lut_sigma = -1.0; uint32_t lut_w = 0, lut_h = 0;
+    double *lutd = nullptr; size_t lutd_cap = 0; double lutd_sigma = -1.0;   // online path (double)
 
     // online path scratch
     float *v_dev = nullptr;         // one sample, padded

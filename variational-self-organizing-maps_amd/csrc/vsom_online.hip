@@ -1,15 +1,455 @@
-// vsom_online.hip -- online path (Som::trainSingle, Som.cpp:885-947).  Placeholder until the
-// kernels land: the entry points fail loudly instead of falling back to a CPU path.
-#include "vsom_internal.hpp"
+// vsom_online.hip -- online path: Som::trainSingle (Som.cpp:885-947) and the per-chunk loop of
+// Som::trainBasicSom (Som.cpp:1159-1171) on gfx950.
+//
+// The path is strictly sequential in samples (sample j's BMU search reads the map sample j-1
+// wrote), so one sample = four small launches enqueued back to back on the context stream,
+// without host synchronisation:
+//   online_scan_kernel    sigma > 1: Som::findBmu, 8 lanes per node (one per Eigen accumulator
+//                         class), atomicMin on an order-preserving (distance, index) key
+//   online_resolve_kernel key + node-0-NaN rule -> BMU index
+//   online_local_kernel   sigma <= 1: Som::findLocalBmu from lastBMU (one wavefront)
+//   online_window_kernel  the +-2.5 sigma window (Som.cpp:899-944): one workgroup per window
+//                         node, elementwise over the model vector; weightMap / map / SMap /
+//                         sigmaMap updated with the reference's double->float narrowing (Q11)
+//   online_post_kernel    residual + distance of the BMU after the update (:946), addBmu
+//                         (:1189-1192), MSE running sum (:1167), lastBMU (:895)
+// The bandwidth roofline of one sample is 4*N*D (scan) + 20*k*D (k window nodes) bytes.
+#include "vsom_device.hpp"
+#include <cmath>
+#include <algorithm>
+
+// onl_state: [0] argmin key, [1] node-0-NaN flag, [2] BMU index ; onl_f: [0] dist, [1] mse sum
+struct OnlineArgs {
+    DistArgs d;          // xa/xb point at the sample's row(s)
+    u64 *state;
+    float *fstate;
+    int N, W, H;
+};
+
+template <bool CLR>
+__global__ __launch_bounds__(256) void online_scan_kernel(OnlineArgs a)
+{
+    __shared__ u64 skey[4];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int node = gid >> 3, k = threadIdx.x & 7;
+    const int nc = node < a.N ? node : a.N - 1;
+    float d = vsom_group_dist<CLR>(a.d.xa, a.d.xb, a.d.ma + (size_t)nc * a.d.ldm,
+                                   a.d.mb + (size_t)nc * a.d.ldm, a.d.L, k);
+    u64 key = (node < a.N) ? vsom_key(d, (uint32_t)node) : ~0ull;
+    if (node == 0 && k == 0)
+        a.state[1] = (d != d) ? 1ull : 0ull;
+    // wave min, then block min, then one atomic per block
+    for (int off = 32; off >= 8; off >>= 1) {
+        u64 o = __shfl_xor(key, off);
+        key = o < key ? o : key;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        skey[wave] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 m = skey[0];
+        for (int i = 1; i < 4; ++i)
+            m = skey[i] < m ? skey[i] : m;
+        atomicMin(&a.state[0], m);
+    }
+}
+
+__global__ void online_resolve_kernel(u64 *state)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        // a NaN distance at node 0 pins the BMU to 0 (Som.cpp:293-299)
+        state[2] = state[1] ? 0ull : (state[0] & 0xFFFFFFFFull);
+    }
+}
+
+// single-sample Som::findLocalBmu (same walk as bmu_local_kernel in vsom_bmu.hip)
+template <bool CLR>
+__global__ __launch_bounds__(64) void online_local_kernel(OnlineArgs a, const u64 *__restrict__ lastbmu)
+{
+    const int lane = threadIdx.x & 63, g = lane >> 3, k = lane & 7;
+    const u64 width = (u64)a.W, height = (u64)a.H;
+    const u64 m1 = ~0ull;
+    const u64 fsx = (g == 0 || g >= 6) ? m1 : ((g == 1 || g == 5) ? 0ull : 1ull);
+    const u64 fsy = (g <= 2) ? 1ull : ((g == 3 || g == 7) ? 0ull : m1);
+    const float *xa = a.d.xa, *xb = a.d.xb;
+    u64 lastBMU = *lastbmu;
+    float minDist = vsom_group_dist<CLR>(xa, xb, a.d.ma + (size_t)lastBMU * a.d.ldm,
+                                         a.d.mb + (size_t)lastBMU * a.d.ldm, a.d.L, k);
+    minDist = __shfl(minDist, 0);
+    u64 minIndex = lastBMU, lastMeasured = lastBMU;
+    for (;;) {
+        const u64 lmX = lastMeasured % width, lmY = lastMeasured / width;
+        const u64 lbX = lastBMU % width;
+        if (lastMeasured == lastBMU) {
+            u64 cx = lmX + fsx;
+            cx = cx < width - 1 ? cx : width - 1;
+            u64 cy = lmY + fsy;
+            cy = cy < height - 1 ? cy : height - 1;
+            u64 node = cy * width + cx;
+            float d = vsom_group_dist<CLR>(xa, xb, a.d.ma + (size_t)node * a.d.ldm,
+                                           a.d.mb + (size_t)node * a.d.ldm, a.d.L, k);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float di = __shfl(d, i * 8);
+                u64 ni = __shfl(node, i * 8);
+                if (di < minDist) {
+                    minDist = di;
+                    minIndex = ni;
+                }
+            }
+            if (minIndex == lastBMU)
+                break;
+            lastMeasured = minIndex;
+        } else {
+            if (lmX - lbX) {
+                u64 cx = lmX + lmX - lbX;
+                cx = cx < width - 1 ? cx : width - 1;
+                u64 off = (u64)(long long)((g < 3 ? g : 0) - 1);
+                u64 cy = lmY + off;
+                cy = cy < height - 1 ? cy : height - 1;
+                u64 node = cy * width + cx;
+                float d = vsom_group_dist<CLR>(xa, xb, a.d.ma + (size_t)node * a.d.ldm,
+                                               a.d.mb + (size_t)node * a.d.ldm, a.d.L, k);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    float di = __shfl(d, i * 8);
+                    u64 ni = __shfl(node, i * 8);
+                    if (di < minDist) {
+                        minDist = di;
+                        minIndex = ni;
+                    }
+                }
+            }
+            if (minIndex == lastMeasured)
+                break;
+            lastBMU = lastMeasured;
+            lastMeasured = minIndex;
+        }
+    }
+    if (lane == 0)
+        a.state[2] = minIndex;
+}
+
+__device__ __forceinline__ float onl_sign(float a)
+{
+    return a > 0.f ? 1.f : (a < 0.f ? -1.f : (a != a ? a : 0.f));
+}
+
+// one workgroup per node of the (maximal) window; nodes outside the actual window exit
+template <int KIND>
+__global__ __launch_bounds__(256) void online_window_kernel(
+    const float *__restrict__ xs, const float *__restrict__ xp, const float *__restrict__ yp,
+    const u64 *__restrict__ state, const double *__restrict__ lutd, int lutw, int W, int H, int D,
+    int P, int ppitch, int pitch, double eta, double sigma, int decay_fn, float *__restrict__ map,
+    float *__restrict__ Smap, float *__restrict__ sigmap, float *__restrict__ weight)
+{
+    const u64 bmu = state[2];
+    const int bx = (int)(bmu % (u64)W), by = (int)(bmu / (u64)W);   // bmu.getX()/getY() (:306)
+    // :899-903  truncating window
+    const double sxd = fmax((double)bx - 2.5 * sigma, 0.), syd = fmax((double)by - 2.5 * sigma, 0.);
+    const double exd = fmin((double)bx + 2.5 * sigma, (double)W), eyd = fmin((double)by + 2.5 * sigma, (double)H);
+    const u64 startX = (u64)sxd, startY = (u64)syd, endX = (u64)exd, endY = (u64)eyd;
+    const u64 i = startX + blockIdx.x, j = startY + blockIdx.y;
+    if (i >= endX || j >= endY)
+        return;
+    const size_t n = (size_t)(j * (u64)W + i);
+    int dx = (int)i - bx, dy = (int)j - by;
+    dx = dx < 0 ? -dx : dx;
+    dy = dy < 0 ? -dy : dy;
+    const double h = lutd[(size_t)dy * lutw + dx];   // calculateNeighbourhoodWeight(i,j,bx,by,sigma) :915
+    const float wold = weight[n];
+    float wnew, scM;
+    if (decay_fn == VSOM_EXPONENTIAL) {
+        wnew = wold + (float)(h * eta);              // :924
+        scM = (float)(h * eta);                      // double scalar narrowed before the fp32 product :925
+    } else {
+        wnew = wold + (float)h;                      // :930
+        double tw = wnew == 0 ? 1.0 : h / (double)wnew;   // :933
+        scM = (float)tw;
+    }
+    const double tw2 = wnew == 0 ? 0.000001 : (double)wnew;   // :939
+    const float twf = (float)tw2, hf = (float)h;
+    __syncthreads();   // every thread has read weight[n]
+    if (threadIdx.x == 0)
+        weight[n] = wnew;
+
+    float *M = map + n * pitch, *S = Smap + n * pitch, *sg = sigmap + n * pitch;
+    if (KIND == VSOM_CLR) {
+        for (int p = threadIdx.x; p < P; p += blockDim.x) {
+            const float x1 = xp[p], y1 = yp[p];
+            float A = M[p], Bv = M[ppitch + p];
+            float inner = A * x1;
+            inner = inner + Bv;
+            inner = inner - y1;
+            float m2 = -2.f * inner;
+            float dA = m2 * x1, dB = m2;                     // Stepper :912
+            float tA = scM * dA, tB = scM * dB;
+            A = A + tA;                                      // :925 / :935
+            Bv = Bv + tB;
+            float in2 = A * x1;
+            in2 = in2 + Bv;
+            in2 = in2 - y1;
+            float n2 = -2.f * in2;
+            float dA2 = n2 * x1, dB2 = n2;                   // Stepper(v, map_new) :941
+            float pa = dA * dA2, pb = dB * dB2;
+            float ua = hf * pa, ub = hf * pb;
+            float SA = S[p] + ua, SB = S[ppitch + p] + ub;   // :941
+            M[p] = A;
+            M[ppitch + p] = Bv;
+            S[p] = SA;
+            S[ppitch + p] = SB;
+            sg[p] = sqrtf(fabsf(SA / twf));                  // :942
+            sg[ppitch + p] = sqrtf(fabsf(SB / twf));
+        }
+    } else {
+        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+            const float x = xs[d];
+            float m = M[d];
+            float dl = x - m;                                // Stepper :912
+            if (KIND == VSOM_MEDIAN)
+                dl = onl_sign(dl);
+            float t = scM * dl;
+            m = m + t;                                       // :925 / :935
+            float dl2 = x - m;                               // Stepper(v, map_new) :941
+            if (KIND == VSOM_MEDIAN)
+                dl2 = onl_sign(dl2);
+            float pr = dl * dl2;
+            float u = hf * pr;
+            float s = S[d] + u;                              // :941
+            M[d] = m;
+            S[d] = s;
+            sg[d] = sqrtf(fabsf(s / twf));                   // :942
+        }
+    }
+}
+
+// residual / distance of the BMU after the update (:946), addBmu, MSE, lastBMU
+template <bool CLR>
+__global__ __launch_bounds__(64) void online_post_kernel(OnlineArgs a, u64 *__restrict__ hits,
+                                                         u64 *__restrict__ lastbmu_out,
+                                                         float *__restrict__ residual, float fB,
+                                                         int add_hit)
+{
+    const int lane = threadIdx.x & 63, k = lane & 7;
+    const u64 bmu = a.state[2];
+    const float *ma = a.d.ma + (size_t)bmu * a.d.ldm, *mb = a.d.mb + (size_t)bmu * a.d.ldm;
+    if (residual) {
+        for (int d = lane; d < a.d.L; d += 64)
+            residual[d] = vsom_resid<CLR>(a.d.xa[d], CLR ? a.d.xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
+    }
+    float dist = vsom_group_dist<CLR>(a.d.xa, a.d.xb, ma, mb, a.d.L, k);
+    if (lane == 0) {
+        a.fstate[0] = dist;
+        float q = dist / fB;                 // residual.squaredNorm() / epochSize  (:1167)
+        a.fstate[1] = a.fstate[1] + q;
+        if (add_hit)
+            hits[bmu] += 1ull;               // addBmu (:1165, :1189-1192)
+        *lastbmu_out = bmu;                  // lastBMU = by*W + bx (:895)
+        a.state[0] = ~0ull;                  // re-arm the argmin key for the next sample
+        a.state[1] = 0ull;
+    }
+}
+
+__global__ void online_init_kernel(u64 *state, float *fstate)
+{
+    state[0] = ~0ull;
+    state[1] = 0ull;
+    state[2] = 0ull;
+    fstate[0] = 0.f;
+    fstate[1] = 0.f;
+}
+
+// double-precision table of calculateNeighbourhoodWeight for the online path (the batch path
+// uses its float cast); cached per sigma
+static int ensure_lutd(vsom_ctx *c, double sigma, const double **out, int *lutw)
+{
+    const uint32_t lw = c->W, lh = c->H;
+    const size_t need = (size_t)lw * lh;
+    if (c->lutd && c->lutd_sigma == sigma) {
+        *out = c->lutd;
+        *lutw = (int)lw;
+        return VSOM_OK;
+    }
+    if (need > c->lutd_cap) {
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->lutd)
+            VSOM_HIP_CHECK(hipFree(c->lutd));
+        c->lutd = nullptr;
+        VSOM_HIP_CHECK(hipMalloc(&c->lutd, need * sizeof(double)));
+        c->lutd_cap = need;
+    }
+    std::vector<double> host(need);
+    for (uint32_t dy = 0; dy < lh; ++dy)
+        for (uint32_t dx = 0; dx < lw; ++dx)
+            host[(size_t)dy * lw + dx] = vsom_neighbourhood_weight(dx, dy, 0, 0, sigma);
+    // the previous table may still be in use by enqueued kernels
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    VSOM_HIP_CHECK(hipMemcpy(c->lutd, host.data(), need * sizeof(double), hipMemcpyHostToDevice));
+    c->lutd_sigma = sigma;
+    *out = c->lutd;
+    *lutw = (int)lw;
+    return VSOM_OK;
+}
+
+// enqueue one trainSingle on sample rows (xs / xp / yp), lastBMU in/out at `lastbmu_dev`
+static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const float *yp,
+                          double eta, double sigma, int decay_fn, u64 *lastbmu_dev,
+                          float *residual_dev, float fB, int add_hit, const double *lutd, int lutw)
+{
+    OnlineArgs a;
+    const bool clr = c->transform == VSOM_CLR;
+    a.d.xa = clr ? xp : xs;
+    a.d.xb = clr ? yp : xs;
+    a.d.ldx = 0;
+    a.d.ma = c->map;
+    a.d.mb = clr ? c->map + c->part_pitch : c->map;
+    a.d.ldm = (int)c->pitch;
+    a.d.L = (int)c->part_len;
+    a.state = c->onl_state;
+    a.fstate = c->onl_f;
+    a.N = (int)c->N;
+    a.W = (int)c->W;
+    a.H = (int)c->H;
+
+    if (sigma > 1) {   // SIGMA_SWITCH_TO_LOCAL (SOM.hpp:37, Som.cpp:891)
+        dim3 grid((unsigned)(((size_t)c->N * 8 + 255) / 256));
+        if (clr)
+            hipLaunchKernelGGL(online_scan_kernel<true>, grid, dim3(256), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(online_scan_kernel<false>, grid, dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(online_resolve_kernel, dim3(1), dim3(64), 0, c->stream, c->onl_state);
+    } else {
+        if (clr)
+            hipLaunchKernelGGL(online_local_kernel<true>, dim3(1), dim3(64), 0, c->stream, a, lastbmu_dev);
+        else
+            hipLaunchKernelGGL(online_local_kernel<false>, dim3(1), dim3(64), 0, c->stream, a, lastbmu_dev);
+    }
+    // maximal window extents: trunc(b+2.5s) - trunc(b-2.5s) <= floor(5s)+1, clipped to the map
+    double ext = std::floor(5.0 * sigma) + 2.0;
+    unsigned gx = (unsigned)std::min<double>((double)c->W, ext), gy = (unsigned)std::min<double>((double)c->H, ext);
+    dim3 wgrid(gx ? gx : 1, gy ? gy : 1);
+    const int L = (int)c->part_len;
+    int bs = L >= 256 ? 256 : ((L + 63) / 64) * 64;
+    if (bs < 64)
+        bs = 64;
+#define LAUNCH_WIN(KIND)                                                                          \
+    hipLaunchKernelGGL(online_window_kernel<KIND>, wgrid, dim3(bs), 0, c->stream, xs, xp, yp,      \
+                       c->onl_state, lutd, lutw, (int)c->W, (int)c->H, (int)c->D, (int)c->part_len, \
+                       (int)c->part_pitch, (int)c->pitch, eta, sigma, decay_fn, c->map, c->S,      \
+                       c->sigma, c->weight)
+    if (c->transform == VSOM_CLR)
+        LAUNCH_WIN(VSOM_CLR);
+    else if (c->transform == VSOM_MEDIAN)
+        LAUNCH_WIN(VSOM_MEDIAN);
+    else
+        LAUNCH_WIN(VSOM_STANDARD);
+#undef LAUNCH_WIN
+    if (clr)
+        hipLaunchKernelGGL(online_post_kernel<true>, dim3(1), dim3(64), 0, c->stream, a, c->hits,
+                           lastbmu_dev, residual_dev, fB, add_hit);
+    else
+        hipLaunchKernelGGL(online_post_kernel<false>, dim3(1), dim3(64), 0, c->stream, a, c->hits,
+                           lastbmu_dev, residual_dev, fB, add_hit);
+    return VSOM_OK;
+}
 
 extern "C" {
-int vsom_train_single(vsom_ctx *, const float *, double, double, uint64_t *, int, float *, float *,
-                      uint64_t *)
+
+int vsom_train_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn, float *mse_out)
 {
-    return vsom_fail(VSOM_ERR_UNSUPPORTED, "vsom_train_single: not implemented yet");
+    if (!c)
+        return vsom_fail(VSOM_ERR_INVALID, "null context");
+    VSOM_HIP_CHECK(hipSetDevice(c->device));
+    if (decay_fn != VSOM_EXPONENTIAL && decay_fn != VSOM_INVERSE_PROPORTIONAL)
+        return vsom_fail(VSOM_ERR_INVALID, "online training needs Exponential or InverseProportional");
+    if (c->B == 0)
+        return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
+    const double *lutd = nullptr;
+    int lutw = 0;
+    int rc = ensure_lutd(c, sigma, &lutd, &lutw);
+    if (rc)
+        return rc;
+    {
+        TimerScope ts(c, VSOM_T_ONLINE);
+        hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f);
+        const float fB = (float)c->B;
+        for (size_t j = 0; j < c->B; ++j) {
+            const float *xs = c->Xs + j * c->xpitch;
+            const float *xp = c->XP ? c->XP + j * c->part_pitch : nullptr;
+            const float *yp = c->YP ? c->YP + j * c->part_pitch : nullptr;
+            rc = enqueue_single(c, xs, xp, yp, eta, sigma, decay_fn, c->lastbmu + j, nullptr, fB, 1,
+                                lutd, lutw);
+            if (rc)
+                return rc;
+        }
+        VSOM_HIP_CHECK(hipGetLastError());
+    }
+    if (mse_out) {
+        VSOM_HIP_CHECK(hipMemcpyAsync(mse_out, c->onl_f + 1, 4, hipMemcpyDeviceToHost, c->stream));
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
+    return VSOM_OK;
 }
-int vsom_train_online_chunk(vsom_ctx *, double, double, int, float *)
+
+int vsom_train_single(vsom_ctx *c, const float *v_host, double eta, double sigma, uint64_t *last_bmu,
+                      int decay_fn, float *residual_out, float *dist_out, uint64_t *bmu_out)
 {
-    return vsom_fail(VSOM_ERR_UNSUPPORTED, "vsom_train_online_chunk: not implemented yet");
+    if (!c)
+        return vsom_fail(VSOM_ERR_INVALID, "null context");
+    VSOM_HIP_CHECK(hipSetDevice(c->device));
+    if (!v_host || !last_bmu)
+        return vsom_fail(VSOM_ERR_INVALID, "null argument");
+    if (decay_fn != VSOM_EXPONENTIAL && decay_fn != VSOM_INVERSE_PROPORTIONAL)
+        return vsom_fail(VSOM_ERR_INVALID, "online training needs Exponential or InverseProportional");
+    if (*last_bmu >= c->N)
+        return vsom_fail(VSOM_ERR_INVALID, "lastBMU out of range");
+    // single-sample staging buffers: [xs | xp | yp | residual] + lastBMU
+    const size_t xs_n = c->xpitch, pp = c->part_pitch;
+    if (!c->v_dev) {
+        VSOM_HIP_CHECK(hipMalloc(&c->v_dev, (xs_n + 3 * pp) * sizeof(float)));
+        VSOM_HIP_CHECK(hipMalloc(&c->res_dev, 64));
+    }
+    std::vector<float> host(xs_n + 2 * pp, 0.f);
+    for (uint32_t d = 0; d < c->J; ++d)
+        host[d] = v_host[d];
+    if (c->transform == VSOM_CLR) {
+        size_t p = 0;
+        for (uint32_t i = 0; i < c->J; ++i)
+            for (uint32_t j = i + 1; j < c->J; ++j) {   // Transformation.cpp:94-101
+                host[xs_n + p] = v_host[i];
+                host[xs_n + pp + p] = v_host[j];
+                ++p;
+            }
+    }
+    const double *lutd = nullptr;
+    int lutw = 0;
+    int rc = ensure_lutd(c, sigma, &lutd, &lutw);
+    if (rc)
+        return rc;
+    float *xs = c->v_dev, *xp = c->v_dev + xs_n, *yp = xp + pp, *res = yp + pp;
+    u64 *lb = reinterpret_cast<u64 *>(c->res_dev);
+    VSOM_HIP_CHECK(hipMemcpyAsync(xs, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    VSOM_HIP_CHECK(hipMemcpyAsync(lb, last_bmu, 8, hipMemcpyHostToDevice, c->stream));
+    {
+        TimerScope ts(c, VSOM_T_ONLINE);
+        hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f);
+        rc = enqueue_single(c, xs, xp, yp, eta, sigma, decay_fn, lb, res, 1.0f, 0, lutd, lutw);
+        if (rc)
+            return rc;
+        VSOM_HIP_CHECK(hipGetLastError());
+    }
+    uint64_t bmu = 0;
+    VSOM_HIP_CHECK(hipMemcpyAsync(&bmu, lb, 8, hipMemcpyDeviceToHost, c->stream));
+    if (residual_out)
+        VSOM_HIP_CHECK(hipMemcpyAsync(residual_out, res, (size_t)c->part_len * 4, hipMemcpyDeviceToHost, c->stream));
+    if (dist_out)
+        VSOM_HIP_CHECK(hipMemcpyAsync(dist_out, c->onl_f, 4, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *last_bmu = bmu;
+    if (bmu_out)
+        *bmu_out = bmu;
+    return VSOM_OK;
 }
-}
+
+}   // extern "C"
