@@ -1,0 +1,410 @@
+// tools/upd_bench.hip -- development micro-benchmark for variants of the phase-2 update kernel
+// (not part of the product; build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off
+//  tools/upd_bench.hip -o /tmp/upd_bench).  All variants must produce identical bits.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef const __attribute__((address_space(4))) float *cfp;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+// ---------------- V0: baseline (as shipped in round-1 v1) ----------------
+template <int RD>
+__global__ __launch_bounds__(256) void upd_v0(const float *__restrict__ Xs, int ldx, const float2 *__restrict__ cw, int ldn, int B,
+                                             int nloc, int D, int nslices, float *__restrict__ map, float *__restrict__ S_out, int pitch)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * 4 + wave;
+    if (slice >= nslices) return;
+    const int d0 = slice * RD;
+    const int nl = blockIdx.x * 64 + lane;
+    float M[RD], S[RD];
+#pragma unroll
+    for (int k = 0; k < RD; ++k) { M[k] = 0.f; S[k] = 0.f; }
+    const float2 *cwp = cw + nl;
+    cfp xr = (cfp)(Xs + d0);
+    for (int j = 0; j < B; ++j) {
+        const float2 v = cwp[(size_t)j * ldn];
+        const float c = v.x, w = v.y;
+#pragma unroll
+        for (int k = 0; k < RD; ++k) {
+            float x = xr[k];
+            float dl = x - M[k];
+            float t = c * dl;
+            M[k] = M[k] + t;
+            float u = w * dl;
+            u = u * dl;
+            S[k] = S[k] + u;
+        }
+        xr += ldx;
+    }
+#pragma unroll
+    for (int k = 0; k < RD; ++k)
+        if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
+}
+
+template <int RD>
+__device__ __forceinline__ void step(float (&M)[RD], float (&S)[RD], const float (&x)[RD], float c, float w)
+{
+#pragma unroll
+    for (int k = 0; k < RD; ++k) {
+        float dl = x[k] - M[k];
+        float t = c * dl;
+        M[k] = M[k] + t;
+        float u = w * dl;
+        u = u * dl;
+        S[k] = S[k] + u;
+    }
+}
+template <int RD>
+__device__ __forceinline__ void loadx(float (&x)[RD], cfp p)
+{
+#pragma unroll
+    for (int k = 0; k < RD; ++k) x[k] = p[k];
+}
+
+// ---------------- V1: deep cw prefetch from global (PF samples ahead), x 1-deep ----------------
+template <int RD, int PF>
+__global__ __launch_bounds__(512) void upd_v1(const float *__restrict__ Xs, int ldx, const float2 *__restrict__ cw, int ldn, int B,
+                                             int nloc, int D, int nslices, int wpb, float *__restrict__ map, float *__restrict__ S_out, int pitch)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * wpb + wave;
+    if (slice >= nslices) return;
+    const int d0 = slice * RD;
+    const int nl = blockIdx.x * 64 + lane;
+    float M[RD], S[RD];
+#pragma unroll
+    for (int k = 0; k < RD; ++k) { M[k] = 0.f; S[k] = 0.f; }
+    const float2 *cwp = cw + nl;
+    cfp xr = (cfp)(Xs + d0);
+    float2 buf[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) buf[u] = cwp[(size_t)u * ldn];
+    float xa[RD], xb[RD];
+    loadx<RD>(xa, xr);
+    for (int j = 0; j < B; j += PF) {   // B multiple of PF in this harness; buffers padded
+#pragma unroll
+        for (int u = 0; u < PF; u += 2) {
+            loadx<RD>(xb, xr + (size_t)(j + u + 1) * ldx);
+            float2 c0 = buf[u];
+            buf[u] = cwp[(size_t)(j + u + PF) * ldn];
+            step<RD>(M, S, xa, c0.x, c0.y);
+            loadx<RD>(xa, xr + (size_t)(j + u + 2) * ldx);
+            float2 c1 = buf[u + 1];
+            buf[u + 1] = cwp[(size_t)(j + u + 1 + PF) * ldn];
+            step<RD>(M, S, xb, c1.x, c1.y);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RD; ++k)
+        if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
+}
+
+// ---------------- V2: cw tile shared through LDS (double buffered), x via SMEM 1-deep ----------------
+template <int RD, int TJ, int NT>   // NT threads per block (multiple of 64)
+__global__ __launch_bounds__(NT) void upd_v2(const float *__restrict__ Xs, int ldx, const float2 *__restrict__ cw, int ldn, int B,
+                                            int nloc, int D, int nslices, float *__restrict__ map, float *__restrict__ S_out, int pitch)
+{
+    constexpr int WPB = NT / 64;
+    constexpr int F4 = TJ * 32;                       // float4 per tile (TJ rows x 512 B)
+    constexpr int PER = (F4 + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float2 tile[2][TJ * 64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * WPB + wave;
+    const bool active = slice < nslices;
+    const int d0 = (active ? slice : 0) * RD;
+    const int nb = blockIdx.x * 64;
+    float M[RD], S[RD];
+#pragma unroll
+    for (int k = 0; k < RD; ++k) { M[k] = 0.f; S[k] = 0.f; }
+    cfp xr = (cfp)(Xs + d0);
+    const float4 *cw4 = reinterpret_cast<const float4 *>(cw + nb);   // row stride ldn*8 B = ldn/2 float4
+    const int ld4 = ldn / 2;
+    float4 st[PER];
+    // prologue: tile 0 -> LDS buffer 0
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        int f = threadIdx.x + i * NT;
+        if (f < F4) st[i] = cw4[(size_t)(f >> 5) * ld4 + (f & 31)];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        int f = threadIdx.x + i * NT;
+        if (f < F4) reinterpret_cast<float4 *>(tile[0])[f] = st[i];
+    }
+    __syncthreads();
+    float xa[RD], xb[RD];
+    loadx<RD>(xa, xr);
+    const int ntiles = B / TJ;   // harness: B multiple of TJ
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        // stage tile t+1 into registers (rows beyond B are padded in the harness)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int f = threadIdx.x + i * NT;
+            if (f < F4) st[i] = cw4[(size_t)((t + 1) * TJ + (f >> 5)) * ld4 + (f & 31)];
+        }
+        if (active) {
+            const float2 *tl = tile[cur] + lane;
+            const int j0 = t * TJ;
+#pragma unroll 4
+            for (int u = 0; u < TJ; u += 2) {
+                loadx<RD>(xb, xr + (size_t)(j0 + u + 1) * ldx);
+                float2 c0 = tl[u * 64];
+                step<RD>(M, S, xa, c0.x, c0.y);
+                loadx<RD>(xa, xr + (size_t)(j0 + u + 2) * ldx);
+                float2 c1 = tl[(u + 1) * 64];
+                step<RD>(M, S, xb, c1.x, c1.y);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            int f = threadIdx.x + i * NT;
+            if (f < F4) reinterpret_cast<float4 *>(tile[cur ^ 1])[f] = st[i];
+        }
+        __syncthreads();
+    }
+    if (active) {
+        const int nl = nb + lane;
+#pragma unroll
+        for (int k = 0; k < RD; ++k)
+            if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
+    }
+}
+
+
+// ---------------- VC: compute only (x and cw loaded once) -- VALU ceiling probe ----------------
+template <int RD, bool SGPRX, bool PACKED_HINT>
+__global__ __launch_bounds__(256) void upd_vc(const float *__restrict__ Xs, int ldx, const float2 *__restrict__ cw, int ldn, int B,
+                                             int nloc, int D, int nslices, float *__restrict__ map, float *__restrict__ S_out, int pitch)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * 4 + wave;
+    if (slice >= nslices) return;
+    const int d0 = slice * RD;
+    const int nl = blockIdx.x * 64 + lane;
+    float M[RD], S[RD], x[RD];
+#pragma unroll
+    for (int k = 0; k < RD; ++k) { M[k] = 0.f; S[k] = 0.f; }
+    if (SGPRX) { cfp xr = (cfp)(Xs + d0); loadx<RD>(x, xr); }
+    else { for (int k = 0; k < RD; ++k) x[k] = Xs[d0 + k + lane * 0 + (lane & 1) * ldx]; }
+    float2 v = cw[nl];
+    for (int j = 0; j < B; ++j) {
+        step<RD>(M, S, x, v.x, v.y);
+        asm volatile("" : "+v"(v.x), "+v"(v.y));   // keep the loop from being collapsed
+    }
+#pragma unroll
+    for (int k = 0; k < RD; ++k)
+        if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
+}
+
+
+// ---------------- VA: cw streamed, x constant ; VB: x streamed (SMEM), cw constant ----------------
+template <int RD, bool STREAM_X, bool STREAM_CW>
+__global__ __launch_bounds__(256) void upd_vab(const float *__restrict__ Xs, int ldx, const float2 *__restrict__ cw, int ldn, int B,
+                                              int nloc, int D, int nslices, float *__restrict__ map, float *__restrict__ S_out, int pitch)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * 4 + wave;
+    if (slice >= nslices) return;
+    const int d0 = slice * RD;
+    const int nl = blockIdx.x * 64 + lane;
+    float M[RD], S[RD], x[RD];
+#pragma unroll
+    for (int k = 0; k < RD; ++k) { M[k] = 0.f; S[k] = 0.f; }
+    cfp xr = (cfp)(Xs + d0);
+    loadx<RD>(x, xr);
+    const float2 *cwp = cw + nl;
+    float2 v = cwp[0];
+    for (int j = 0; j < B; ++j) {
+        if (STREAM_CW) v = cwp[(size_t)j * ldn];
+        if (STREAM_X) loadx<RD>(x, xr + (size_t)j * ldx);
+        step<RD>(M, S, x, v.x, v.y);
+        asm volatile("" : "+v"(v.x), "+v"(v.y));
+    }
+#pragma unroll
+    for (int k = 0; k < RD; ++k)
+        if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
+}
+
+
+// ---------------- V3: explicit 2-group software pipeline pinned with sched_barrier ----------------
+template <int RD, int G>
+__global__ __launch_bounds__(256) void upd_v3(const float *__restrict__ Xs, int ldx, const float2 *__restrict__ cw, int ldn, int B,
+                                             int nloc, int D, int nslices, float *__restrict__ map, float *__restrict__ S_out, int pitch)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * 4 + wave;
+    if (slice >= nslices) return;
+    const int d0 = slice * RD;
+    const int nl = blockIdx.x * 64 + lane;
+    float M[RD], S[RD];
+#pragma unroll
+    for (int k = 0; k < RD; ++k) { M[k] = 0.f; S[k] = 0.f; }
+    const float2 *cwp = cw + nl;
+    cfp xr = (cfp)(Xs + d0);
+    float2 bufA[G], bufB[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) { bufA[u] = cwp[(size_t)u * ldn]; bufB[u] = cwp[(size_t)(G + u) * ldn]; }
+    float xa[RD], xb[RD];
+    loadx<RD>(xa, xr);
+    for (int j = 0; j < B; j += 2 * G) {
+#pragma unroll
+        for (int u = 0; u < G; u += 2) {
+            loadx<RD>(xb, xr + (size_t)(j + u + 1) * ldx);
+            __builtin_amdgcn_sched_barrier(0);
+            step<RD>(M, S, xa, bufA[u].x, bufA[u].y);
+            __builtin_amdgcn_sched_barrier(0);
+            loadx<RD>(xa, xr + (size_t)(j + u + 2) * ldx);
+            __builtin_amdgcn_sched_barrier(0);
+            step<RD>(M, S, xb, bufA[u + 1].x, bufA[u + 1].y);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) bufA[u] = cwp[(size_t)(j + 2 * G + u) * ldn];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < G; u += 2) {
+            loadx<RD>(xb, xr + (size_t)(j + G + u + 1) * ldx);
+            __builtin_amdgcn_sched_barrier(0);
+            step<RD>(M, S, xa, bufB[u].x, bufB[u].y);
+            __builtin_amdgcn_sched_barrier(0);
+            loadx<RD>(xa, xr + (size_t)(j + G + u + 2) * ldx);
+            __builtin_amdgcn_sched_barrier(0);
+            step<RD>(M, S, xb, bufB[u + 1].x, bufB[u + 1].y);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) bufB[u] = cwp[(size_t)(j + 3 * G + u) * ldn];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < RD; ++k)
+        if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
+}
+
+
+// ---------------- V4: cw loads in inline asm with hand-counted vmcnt (PF-deep ring), x SMEM 1-deep ----------------
+#define VS_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+template <int RD, int PF>
+__global__ __launch_bounds__(256) void upd_v4(const float *__restrict__ Xs, int ldx, const float2 *__restrict__ cw, int ldn, int B,
+                                             int nloc, int D, int nslices, float *__restrict__ map, float *__restrict__ S_out, int pitch)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * 4 + wave;
+    if (slice >= nslices) return;
+    const int d0 = slice * RD;
+    const int nl = blockIdx.x * 64 + lane;
+    float M[RD], S[RD];
+#pragma unroll
+    for (int k = 0; k < RD; ++k) { M[k] = 0.f; S[k] = 0.f; }
+    const float2 *cwp = cw + nl;
+    const size_t rowb = (size_t)ldn * sizeof(float2);
+    cfp xr = (cfp)(Xs + d0);
+    float2 buf[PF];
+    const char *ap = reinterpret_cast<const char *>(cwp);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        buf[u] = make_float2(0.f, 0.f);
+        asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(buf[u]) : "v"(ap) : "memory");
+        ap += rowb;
+    }
+    float xa[RD], xb[RD];
+    loadx<RD>(xa, xr);
+    for (int j = 0; j < B; j += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u += 2) {
+            VS_WAIT_LGKM0();
+            __builtin_amdgcn_sched_barrier(0);
+            loadx<RD>(xb, xr + (size_t)(j + u + 1) * ldx);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(buf[u]) : "n"(PF - 1) : "memory");
+            step<RD>(M, S, xa, buf[u].x, buf[u].y);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(buf[u]) : "v"(ap) : "memory");
+            ap += rowb;
+            VS_WAIT_LGKM0();
+            __builtin_amdgcn_sched_barrier(0);
+            loadx<RD>(xa, xr + (size_t)(j + u + 2) * ldx);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(buf[u + 1]) : "n"(PF - 1) : "memory");
+            step<RD>(M, S, xb, buf[u + 1].x, buf[u + 1].y);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(buf[u + 1]) : "v"(ap) : "memory");
+            ap += rowb;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < RD; ++k)
+        if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
+}
+
+int main(int argc, char **argv)
+{
+    const int N = 16384, D = 784, B = 4096, pitch = 800, ldx = 800, ldn = N;
+    const int reps = argc > 1 ? atoi(argv[1]) : 3;
+    std::vector<float> hx((size_t)(B + 72) * ldx), hcw((size_t)(B + 72) * ldn * 2);
+    srand(1);
+    for (auto &v : hx) v = (float)(rand() % 256);
+    for (size_t i = 0; i < hcw.size(); i += 2) { hcw[i] = (rand() % 1000) / 4000.f; hcw[i + 1] = (rand() % 1000) / 1000.f + 0.01f; }
+    float *dx, *dmap, *dS, *dmap2, *dS2; float2 *dcw;
+    CK(hipMalloc(&dx, hx.size() * 4)); CK(hipMalloc(&dcw, hcw.size() * 4));
+    CK(hipMalloc(&dmap, (size_t)N * pitch * 4)); CK(hipMalloc(&dS, (size_t)N * pitch * 4));
+    CK(hipMalloc(&dmap2, (size_t)N * pitch * 4)); CK(hipMalloc(&dS2, (size_t)N * pitch * 4));
+    CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dcw, hcw.data(), hcw.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ref((size_t)N * pitch), got((size_t)N * pitch), refS((size_t)N * pitch), gotS((size_t)N * pitch);
+
+    auto run = [&](const char *name, auto launch, bool is_ref) {
+        float *m = is_ref ? dmap : dmap2, *s = is_ref ? dS : dS2;
+        CK(hipMemset(m, 0, (size_t)N * pitch * 4)); CK(hipMemset(s, 0, (size_t)N * pitch * 4));
+        launch(m, s); CK(hipDeviceSynchronize());
+        float best = 1e9f;
+        for (int r = 0; r < reps; ++r) {
+            CK(hipEventRecord(e0)); launch(m, s); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        CK(hipGetLastError());
+        if (is_ref) { CK(hipMemcpy(ref.data(), m, ref.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(refS.data(), s, refS.size() * 4, hipMemcpyDeviceToHost)); printf("%-28s %8.3f ms (reference)\n", name, best); }
+        else {
+            CK(hipMemcpy(got.data(), m, got.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gotS.data(), s, gotS.size() * 4, hipMemcpyDeviceToHost));
+            bool same = memcmp(ref.data(), got.data(), got.size() * 4) == 0 && memcmp(refS.data(), gotS.data(), gotS.size() * 4) == 0;
+            printf("%-28s %8.3f ms  %s  (%.1f TFLOP/s alg)\n", name, best, same ? "bits-ok" : "MISMATCH", 6.0 * N * D * B / best / 1e9);
+        }
+    };
+    run("v0 RD16 wpb4", [&](float *m, float *s) { hipLaunchKernelGGL(upd_v0<16>, dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, true);
+    run("vc RD16 sgpr-x compute-only", [&](float *m, float *s) { hipLaunchKernelGGL((upd_vc<16, true, true>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("vc RD16 vgpr-x compute-only", [&](float *m, float *s) { hipLaunchKernelGGL((upd_vc<16, false, true>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("va RD16 cw streamed only", [&](float *m, float *s) { hipLaunchKernelGGL((upd_vab<16, false, true>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("vb RD16 x streamed only", [&](float *m, float *s) { hipLaunchKernelGGL((upd_vab<16, true, false>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("vab RD16 both (==v0)", [&](float *m, float *s) { hipLaunchKernelGGL((upd_vab<16, true, true>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("va cw stride0 (L1 hits)", [&](float *m, float *s) { hipLaunchKernelGGL((upd_vab<16, false, true>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, 0, B, N, D, 49, m, s, pitch); }, false);
+    run("v0 B=64 rows x64 (L2 hits)", [&](float *m, float *s) { for (int r = 0; r < 64; ++r) hipLaunchKernelGGL(upd_v0<16>, dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, 64, N, D, 49, m, s, pitch); }, false);
+    run("v3 RD16 G4 pinned pipeline", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v3<16, 4>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("v3 RD16 G8 pinned pipeline", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v3<16, 8>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("v3 RD14 G8 pinned pipeline", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v3<14, 8>), dim3(N / 64, 14), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 56, m, s, pitch); }, false);
+    run("v4 RD16 asm ring pf8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v4<16, 8>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("v4 RD16 asm ring pf16", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v4<16, 16>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("v4 RD14 asm ring pf8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v4<14, 8>), dim3(N / 64, 14), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 56, m, s, pitch); }, false);
+    run("v1 RD16 wpb7 pf4", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v1<16, 4>), dim3(N / 64, 7), dim3(448), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, 7, m, s, pitch); }, false);
+    run("v1 RD16 wpb7 pf8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v1<16, 8>), dim3(N / 64, 7), dim3(448), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, 7, m, s, pitch); }, false);
+    run("v1 RD16 wpb4 pf8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v1<16, 8>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, 4, m, s, pitch); }, false);
+    run("v1 RD14 wpb8 pf8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v1<14, 8>), dim3(N / 64, 7), dim3(512), 0, 0, dx, ldx, dcw, ldn, B, N, D, 56, 8, m, s, pitch); }, false);
+    run("v2 RD16 lds tj32 448", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v2<16, 32, 448>), dim3(N / 64, 7), dim3(448), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("v2 RD14 lds tj32 512", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v2<14, 32, 512>), dim3(N / 64, 7), dim3(512), 0, 0, dx, ldx, dcw, ldn, B, N, D, 56, m, s, pitch); }, false);
+    run("v2 RD16 lds tj64 448", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v2<16, 64, 448>), dim3(N / 64, 7), dim3(448), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
+    run("v2 RD28 lds tj32 448", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v2<28, 32, 448>), dim3(N / 64, 4), dim3(448), 0, 0, dx, ldx, dcw, ldn, B, N, D, 28, m, s, pitch); }, false);
+    return 0;
+}
