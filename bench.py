@@ -163,6 +163,7 @@ def main():
         dt = float(t.item())
 
     mse = float(ctx.get_mse())
+    sl_stats = ctx.shortlist_stats()
     if rank == 0:
         nloc = W * H // world if (W * H) % world == 0 else None
         n_nodes_rank = (vdist.shard_bounds(W * H, world, 0)[1])
@@ -204,6 +205,7 @@ def main():
                          "algorithmic_flop_per_launch": flops_launch},
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in timing.items()},
             "mse_last": mse,
+            "bmu_shortlist_last": sl_stats,
         }
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args, chunks_host[0][:Bper], init_map)

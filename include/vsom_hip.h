@@ -99,6 +99,10 @@ void vsom_destroy(vsom_ctx *ctx);
 int vsom_set_stream(vsom_ctx *ctx, void *hip_stream);
 int vsom_synchronize(vsom_ctx *ctx);
 int vsom_set_bmu_mode(vsom_ctx *ctx, int mode);
+/* diagnostics of the last MFMA-shortlist search (synchronises): out[0] = samples that had to be
+ * redone by the exact-order kernel, out[1] = shortlisted candidates in total, out[2] = samples
+ * searched, out[3] = number of shortlist searches so far */
+int vsom_get_shortlist_stats(vsom_ctx *ctx, uint32_t *out /*[4]*/);
 uint32_t vsom_depth(const vsom_ctx *ctx);   /* D */
 uint32_t vsom_nodes(const vsom_ctx *ctx);   /* N */
 

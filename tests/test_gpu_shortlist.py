@@ -1,0 +1,166 @@
+"""GPU: the MFMA shortlist BMU search must return exactly what the exact-order search returns
+(indices bit-exact, distances bit-identical) -- against the oracle at sizes it finishes in
+seconds, and against the exact-order GPU kernel at BASELINE's full size."""
+import numpy as np
+import pytest
+
+import gen
+import vsom_amd
+from vsom_amd import capi
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def beq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind == "f":
+        return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+    return (a == b).all()
+
+
+def _run(ctx, mode):
+    ctx.set_bmu_mode(mode)
+    return ctx.bmu_batch()
+
+
+def _oracle_bmu(o, X, threads=16):
+    B = X.shape[0]
+    lb = np.zeros(B, np.uint64)
+    sq = np.zeros(B, np.float32)
+    o.batch_phase1_range(X, 0, B, lb, sq, True, nthreads=threads)
+    return lb, sq
+
+
+CASES = [
+    ("mnist_48x48", 48, 48, 784, 384, "mnist"),
+    ("d794", 40, 40, 794, 200, "mnist"),
+    ("blobs_64x64x32", 64, 64, 32, 700, "blobs"),
+    ("tiny_dim5", 40, 40, 5, 300, "blobs"),
+    ("ragged_33x31x77", 33, 31, 77, 150, "blobs"),
+]
+
+
+@pytest.mark.parametrize("name,W,H,J,B,kind", CASES, ids=[c[0] for c in CASES])
+def test_shortlist_equals_oracle(name, W, H, J, B, kind):
+    X = gen.mnist_like(B, 3, J) if kind == "mnist" else gen.blobs(B, J, 6, 1, 2, sigma=0.5)
+    if kind == "mnist":
+        init = (gen.random_map(W * H, J, 42) * np.float32(120) + np.float32(110)).astype(np.float32)
+    else:
+        init = gen.random_map(W * H, J, 42)
+    o = po.OracleSom(W, H, J)
+    o.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_state(map=init)
+    ctx.upload_chunk(X)
+    lb_o, sq_o = _oracle_bmu(o, X)
+    for mode in (capi.BMU_SHORTLIST, capi.BMU_EXACT):
+        idx, dist = _run(ctx, mode)
+        assert beq(idx, lb_o), (name, mode)
+        assert beq(dist, sq_o), (name, mode)
+    # a trained-looking map: run one real epoch, then search again on the smooth map
+    lb = np.zeros(B, np.uint64)
+    o.batch_epoch(X, lb, max(W, H) / 4.0, True, nthreads=16)
+    ctx.set_bmu_mode(capi.BMU_SHORTLIST)
+    ctx.batch_epoch(max(W, H) / 4.0, True)
+    assert beq(ctx.get_last_bmu(), lb), name
+    st = ctx.get_state()
+    assert beq(st["map"], o.map) and beq(st["sigma"], o.sigma), name
+    lb_o, sq_o = _oracle_bmu(o, X)
+    ctx.upload_chunk(X)
+    idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+    assert beq(idx, lb_o) and beq(dist, sq_o), name + " trained"
+    ctx.close()
+
+
+def test_ties_duplicates_and_zero_map():
+    """Equal nodes: the lowest index must win; an all-zero map/chunk makes every node a
+    candidate, which must fall back to the exact kernel (still node 0)."""
+    W = H = 40
+    J, B = 24, 130
+    X = gen.blobs(B, J, 4, 1, 2)
+    base = gen.random_map(W * H, J, 5)
+    dup = base.copy()
+    dup[1000:1100] = base[200:300]       # exact duplicates at higher indices
+    dup[37] = base[1500]                 # and one at a lower index than its twin
+    o = po.OracleSom(W, H, J)
+    o.set_state(map=dup)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_state(map=dup)
+    ctx.upload_chunk(X)
+    lb_o, sq_o = _oracle_bmu(o, X, 8)
+    idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+    assert beq(idx, lb_o) and beq(dist, sq_o)
+    # zero map
+    z = np.zeros_like(dup)
+    o.set_state(map=z)
+    ctx.set_state(map=z)
+    lb_o, sq_o = _oracle_bmu(o, X, 8)
+    idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+    assert (lb_o == 0).all()
+    assert beq(idx, lb_o) and beq(dist, sq_o)
+    # zero samples on a zero map
+    ctx.upload_chunk(np.zeros((B, J), np.float32))
+    idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+    assert (idx == 0).all() and (dist == 0).all()
+    ctx.close()
+
+
+def test_nan_rows_and_nan_node0():
+    W = H = 36
+    J, B = 16, 96
+    X = gen.blobs(B, J, 4, 1, 2)
+    m = gen.random_map(W * H, J, 6)
+    m[5:400:7] = np.nan                  # poisoned rows (Q7) never win
+    o = po.OracleSom(W, H, J)
+    o.set_state(map=m)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_state(map=m)
+    ctx.upload_chunk(X)
+    lb_o, sq_o = _oracle_bmu(o, X, 8)
+    idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+    assert beq(idx, lb_o) and beq(dist, sq_o)
+    m[0, 3] = np.nan                     # node 0 NaN pins every BMU to 0 (Q3)
+    o.set_state(map=m)
+    ctx.set_state(map=m)
+    lb_o, sq_o = _oracle_bmu(o, X, 8)
+    idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+    assert (lb_o == 0).all() and beq(idx, lb_o) and beq(dist, sq_o)
+    # +inf in the map: the bound is not applicable -> device-side fallback to the exact kernel
+    m = gen.random_map(W * H, J, 6)
+    m[77, 2] = np.inf
+    o.set_state(map=m)
+    ctx.set_state(map=m)
+    lb_o, sq_o = _oracle_bmu(o, X, 8)
+    idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+    assert beq(idx, lb_o) and beq(dist, sq_o)
+    ctx.close()
+
+
+def test_full_size_shortlist_equals_exact_kernel():
+    """BASELINE size (128x128 map, 784-dim, B=4096): shortlist == exact-order kernel for every
+    sample; a random subset is also checked against the oracle."""
+    W = H = 128
+    J, B = 784, 4096
+    X = gen.mnist_like(B, 3, J)
+    init = (gen.random_map(W * H, J, 42) * np.float32(100) + np.float32(100)).astype(np.float32)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_state(map=init)
+    ctx.upload_chunk(X)
+    i_s, d_s = _run(ctx, capi.BMU_SHORTLIST)
+    i_e, d_e = _run(ctx, capi.BMU_EXACT)
+    assert beq(i_s, i_e) and beq(d_s, d_e)
+    # after one epoch the map is smooth (neighbouring nodes nearly equal): the hard case
+    ctx.set_bmu_mode(capi.BMU_EXACT)
+    ctx.batch_epoch(32.0, True)
+    ctx.upload_chunk(X)
+    i_s, d_s = _run(ctx, capi.BMU_SHORTLIST)
+    i_e, d_e = _run(ctx, capi.BMU_EXACT)
+    assert beq(i_s, i_e) and beq(d_s, d_e)
+    st = ctx.get_state(sigma=False, S=False, weight=False, hits=False)
+    o = po.OracleSom(W, H, J)
+    o.set_state(map=st["map"])
+    rs = np.random.RandomState(0)
+    for s in rs.randint(0, B, size=24):
+        assert o.find_bmu(X[s]) == int(i_s[s])
+    ctx.close()

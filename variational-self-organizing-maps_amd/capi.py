@@ -23,7 +23,7 @@ TIMER_NAMES = ["stage", "bmu", "finish", "cw", "update", "online"]
 # every symbol include/vsom_hip.h declares (tests/test_capi_symbols.py checks the header too)
 SYMBOLS = [
     "vsom_last_error", "vsom_device_count", "vsom_create", "vsom_destroy", "vsom_set_stream",
-    "vsom_synchronize", "vsom_set_bmu_mode", "vsom_depth", "vsom_nodes", "vsom_set_state",
+    "vsom_synchronize", "vsom_set_bmu_mode", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
     "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_get_last_bmu",
     "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_bmu_local_batch",
     "vsom_distances", "vsom_batch_phase1_async", "vsom_batch_finish_async",
@@ -70,6 +70,7 @@ def lib():
     L.vsom_set_stream.argtypes = [vp, vp]
     L.vsom_synchronize.argtypes = [vp]
     L.vsom_set_bmu_mode.argtypes = [vp, C.c_int]
+    L.vsom_get_shortlist_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
     for name in ("vsom_depth", "vsom_nodes", "vsom_residual_len", "vsom_pitch", "vsom_chunk_pitch"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = C.c_uint32
@@ -158,6 +159,12 @@ class Context:
 
     def set_bmu_mode(self, mode):
         check(lib().vsom_set_bmu_mode(self._h, int(mode)))
+
+    def shortlist_stats(self):
+        out = (C.c_uint32 * 4)()
+        check(lib().vsom_get_shortlist_stats(self._h, out))
+        return {"redo_samples": int(out[0]), "candidates": int(out[1]), "samples": int(out[2]),
+                "searches": int(out[3])}
 
     def device_ptr(self, which):
         return int(lib().vsom_device_ptr(self._h, int(which)) or 0)

@@ -8,7 +8,7 @@ out="${1:-$here/../libvsom_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function"
 objs=()
-for f in vsom_capi vsom_bmu vsom_update vsom_online; do
+for f in vsom_capi vsom_bmu vsom_shortlist vsom_update vsom_online; do
   o="$here/$f.o"
   if [ ! -f "$o" ] || [ "$here/$f.hip" -nt "$o" ] || [ "$here/vsom_internal.hpp" -nt "$o" ] || [ "$here/vsom_device.hpp" -nt "$o" ] || [ "$here/../../include/vsom_hip.h" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$here/$f.hip" -o "$o" &

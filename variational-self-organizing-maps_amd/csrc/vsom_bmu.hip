@@ -106,8 +106,18 @@ static DistArgs make_dist_args(const vsom_ctx *c)
 template <bool CLR>
 __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, int s1, int N,
                                                           u64 *__restrict__ partial, int pstride,
-                                                          unsigned char *__restrict__ nan0)
+                                                          unsigned char *__restrict__ nan0,
+                                                          const int *__restrict__ slist,
+                                                          const unsigned *__restrict__ scount)
 {
+    // optional indirection: process only the samples listed by the shortlist path
+    // (vsom_shortlist.hip); s0/s1 then index the list and workgroups beyond its length exit
+    if (scount) {
+        const int cnt = (int)*scount;
+        s1 = s0 + cnt < s1 ? s0 + cnt : s1;
+        if (s0 + (int)blockIdx.y * TILE >= s1)
+            return;
+    }
     __shared__ __attribute__((aligned(16))) float sx[TILE * LDT];
     __shared__ __attribute__((aligned(16))) float sm[TILE * LDT];
     __shared__ __attribute__((aligned(16))) float sy[CLR ? TILE * LDT : 4];
@@ -139,9 +149,10 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
             int s = sbase + row, n = nbase + row;
             float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vm = vx, vy = vx, vb = vx;
             if (s < s1) {
-                vx = *reinterpret_cast<const float4 *>(a.xa + (size_t)s * a.ldx + dk + c4);
+                const size_t srow = slist ? (size_t)slist[s - s0] : (size_t)s;
+                vx = *reinterpret_cast<const float4 *>(a.xa + srow * a.ldx + dk + c4);
                 if (CLR)
-                    vy = *reinterpret_cast<const float4 *>(a.xb + (size_t)s * a.ldx + dk + c4);
+                    vy = *reinterpret_cast<const float4 *>(a.xb + srow * a.ldx + dk + c4);
             }
             if (n < N) {
                 vm = *reinterpret_cast<const float4 *>(a.ma + (size_t)n * a.ldm + dk + c4);
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
         for (int i = 0; i < 4; ++i) {
             int s = sbase + ty + 16 * i;
             if (s < s1)
-                nan0[s] = (dist[i][0] != dist[i][0]) ? 1 : 0;
+                nan0[slist ? slist[s - s0] : s] = (dist[i][0] != dist[i][0]) ? 1 : 0;
         }
     }
 
@@ -259,18 +270,25 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
                 u64 k = keys[tid * 16 + t];
                 kmin = k < kmin ? k : kmin;
             }
-            partial[(size_t)blockIdx.x * pstride + s] = kmin;
+            partial[(size_t)blockIdx.x * pstride + (slist ? slist[s - s0] : s)] = kmin;
         }
     }
 }
 
 __global__ void bmu_reduce_kernel(const u64 *__restrict__ partial, int pstride, int ntiles,
                                   const unsigned char *__restrict__ nan0, int s0, int s1,
-                                  u64 *__restrict__ lastbmu, float *__restrict__ sqres)
+                                  u64 *__restrict__ lastbmu, float *__restrict__ sqres,
+                                  const int *__restrict__ slist, const unsigned *__restrict__ scount)
 {
     int s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (scount) {
+        const int cnt = (int)*scount;
+        s1 = s0 + cnt < s1 ? s0 + cnt : s1;
+    }
     if (s >= s1)
         return;
+    if (slist)
+        s = slist[s - s0];
     u64 kmin = ~0ull;
     for (int t = 0; t < ntiles; ++t) {
         u64 k = partial[(size_t)t * pstride + s];
@@ -285,7 +303,7 @@ __global__ void bmu_reduce_kernel(const u64 *__restrict__ partial, int pstride, 
     }
 }
 
-int launch_bmu_full_exact(vsom_ctx *c, size_t s0, size_t s1)
+int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount)
 {
     if (s1 <= s0)
         return VSOM_OK;
@@ -303,21 +321,47 @@ int launch_bmu_full_exact(vsom_ctx *c, size_t s0, size_t s1)
     dim3 grid((unsigned)ntn, (unsigned)nts);
     if (c->transform == VSOM_CLR)
         hipLaunchKernelGGL(bmu_tile_kernel<true>, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
-                           (int)c->N, c->partial, (int)c->Bcap, c->nan0);
+                           (int)c->N, c->partial, (int)c->Bcap, c->nan0, slist, scount);
     else
         hipLaunchKernelGGL(bmu_tile_kernel<false>, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
-                           (int)c->N, c->partial, (int)c->Bcap, c->nan0);
+                           (int)c->N, c->partial, (int)c->Bcap, c->nan0, slist, scount);
     hipLaunchKernelGGL(bmu_reduce_kernel, dim3((unsigned)((s1 - s0 + 255) / 256)), dim3(256), 0,
                        c->stream, c->partial, (int)c->Bcap, ntn, c->nan0, (int)s0, (int)s1, c->lastbmu,
-                       c->sqres);
+                       c->sqres, slist, scount);
     VSOM_HIP_CHECK(hipGetLastError());
     return VSOM_OK;
 }
 
+int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1);
+
 int launch_bmu_full(vsom_ctx *c, size_t s0, size_t s1)
 {
     TimerScope ts(c, VSOM_T_BMU);
-    return launch_bmu_full_exact(c, s0, s1);
+    // the MFMA shortlist covers the plain squared-distance comparer (Standard / Median);
+    // it pays once the map is large enough to fill the matrix pipes
+    const bool can = c->transform != VSOM_CLR;
+    bool want = c->bmu_mode == VSOM_BMU_SHORTLIST;
+    if (c->bmu_mode == VSOM_BMU_AUTO && c->N >= 1024 && (s1 - s0) >= 64) {
+        want = true;
+        // feedback of the previous shortlist call (pinned host words written by the device, read
+        // without synchronising: possibly one call stale): when more than a quarter of the samples
+        // had to be redone exactly the shortlist does not pay on this map -- skip it for a while
+        if (c->sl_fb) {
+            volatile unsigned *fb = c->sl_fb;
+            unsigned redo = fb[0], rows = fb[2];
+            if (c->sl_skip > 0) {
+                --c->sl_skip;
+                want = false;
+            } else if (rows > 0 && redo * 4u > rows) {
+                c->sl_skip = 8;
+                fb[0] = 0;   // re-probe after the pause
+                want = false;
+            }
+        }
+    }
+    if (can && want)
+        return launch_bmu_full_shortlist(c, s0, s1);
+    return launch_bmu_full_exact_list(c, s0, s1, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

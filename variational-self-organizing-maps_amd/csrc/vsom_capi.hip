@@ -65,12 +65,14 @@ static int free_all(vsom_ctx *c)
 {
     void *ptrs[] = {c->map, c->sigma, c->S, c->weight, c->hits, c->Xs, c->XP, c->YP, c->Xraw,
                     c->lastbmu, c->sqres, c->mse, c->bxy, c->pair_i, c->pair_j, c->partial, c->nan0,
-                    c->cw, c->lut, c->lutd, c->v_dev, c->res_dev, c->onl_state, c->onl_f};
+                    c->cw, c->lut, c->lutd, c->sl_G, c->sl_nrm, c->sl_scal, c->sl_list, c->v_dev, c->res_dev, c->onl_state, c->onl_f};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
     if (c->lut_host)
         (void)hipHostFree(c->lut_host);
+    if (c->sl_fb)
+        (void)hipHostFree(c->sl_fb);
     for (auto &e : c->ev_live) {
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
@@ -212,6 +214,17 @@ int vsom_set_bmu_mode(vsom_ctx *c, int mode)
     if (!c || mode < VSOM_BMU_AUTO || mode > VSOM_BMU_SHORTLIST)
         return vsom_fail(VSOM_ERR_INVALID, "bad bmu mode");
     c->bmu_mode = mode;
+    return VSOM_OK;
+}
+
+int vsom_get_shortlist_stats(vsom_ctx *c, uint32_t *out)
+{
+    CHECK_CTX(c);
+    if (!out)
+        return vsom_fail(VSOM_ERR_INVALID, "null output");
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 4; ++i)
+        out[i] = c->sl_fb ? ((volatile unsigned *)c->sl_fb)[i] : 0u;
     return VSOM_OK;
 }
 

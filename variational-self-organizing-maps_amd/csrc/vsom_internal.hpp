@@ -51,6 +51,12 @@ struct vsom_ctx {
     u64 *partial = nullptr; size_t partial_cap = 0;
     unsigned char *nan0 = nullptr;
 
+    // MFMA shortlist scratch
+    float *sl_G = nullptr; size_t sl_cap = 0; float *sl_nrm = nullptr; unsigned *sl_scal = nullptr;
+    int *sl_list = nullptr; size_t sl_list_cap = 0;
+    unsigned *sl_fb = nullptr;      // pinned host feedback: {redo samples, candidates, rows, seq}
+    int sl_skip = 0;
+
     // neighbourhood
     float2 *cw = nullptr; size_t cw_cap = 0;
     float *lut = nullptr; size_t lut_cap = 0; float *lut_host = nullptr;

@@ -1,0 +1,338 @@
+// vsom_shortlist.hip -- Som::findBmu (Som.cpp:291-309) through an MFMA shortlist (gfx950).
+//
+// Standard / Median comparer only (distance = sum_d (M_d - x_d)^2).  The result is REQUIRED to
+// be identical to the exact-order search of vsom_bmu.hip (and is checked against it and against
+// the oracle in tests): the matrix pipe only prunes, every returned index/distance comes from an
+// exact-order evaluation.
+//
+//   norm_kernel     nrm_i = sum_d M_id^2 (fp32), max over nodes, +inf flag
+//   gemm_kernel     G[s][i] = nrm_i - 2 * <x_s, M_i> with v_mfma_f32_32x32x2_f32 (an fp32 fmaf
+//                   chain, MI355X guide "FP32-input MFMA"); 128x128 output tile per workgroup,
+//                   64x64 per wavefront, K streamed through LDS in chunks of 32
+//   select_kernel   one wavefront per sample: m = min_i G[s][i]; every node with
+//                   G[s][i] <= m + T_s is re-evaluated in the reference's fp32 order
+//                   (vsom_group_dist) and the argmin is taken with the reference's rules.
+//
+// Threshold (u = 2^-24, K = D).  With d = true squared distance, e = exact-order fp32 value,
+// G + nx = approximate value (nx = |x|^2 is constant per sample and dropped):
+//   |G_i + nx - d_i| <= Ea_i = 2*g1*(nM_i + nx),  g1 = (GK + K/GK + 3)u: the dot product is
+//                       accumulated per K-chunk of GK=32 by the MFMA fmaf chain (gamma_GK) and the
+//                       chunk sums are added in fp32 (gamma_{K/GK}); norm + final subtraction: 3u
+//   |e_i - d_i|      <= g2 * d_i,                  g2 = (K/8+10)u (products + reduction tree depth)
+// If i* is the reference argmin (e_i* <= e_j for all j) then for jm = argmin G (m = G_jm):
+//   G_i* <= m + Ea_jm + Ea_i* + 2.1*g2*d_jm,   d_jm <= m + nx + Ea_jm
+//        <= m + 4*g1*(nMmax + nx) + 2.1*g2*(m + nx + 2*g1*(nMmax + nx)) =: m + T_s
+// T_s is inflated by 1.05 to cover the fp32 rounding of nrm, nx, m + nx and of T_s itself.  Nodes whose row contains NaN have G = NaN and an exact distance of NaN: excluded,
+// as in the reference (a NaN never wins; node 0 is checked explicitly, Som.cpp:293-299).
+// Samples for which the bound is not applicable (non-finite nx or nrm) or whose shortlist exceeds
+// SL_CMAX are appended to a device-side redo list; the exact-order tile kernel then handles
+// exactly those samples (its workgroups beyond the list length exit at once).  The redo fraction
+// is fed back to the host through pinned memory so that AUTO mode can stop using the shortlist on
+// maps where it does not prune (very smooth maps early in training).
+#include "vsom_device.hpp"
+#include <cstring>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SL_CMAX 2048
+
+__global__ __launch_bounds__(256) void sl_norm_kernel(const float *__restrict__ map, int ldm, int D, int N,
+                                                      float *__restrict__ nrm, unsigned *__restrict__ scal)
+{
+    // one wavefront per node; scal[0] = max finite nrm (as uint bits), scal[1] = non-finite flag
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (wave >= N)
+        return;
+    const float *row = map + (size_t)wave * ldm;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        float v = row[d];
+        float p = v * v;
+        s = s + p;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        s = s + __shfl_xor(s, off);
+    if (lane == 0) {
+        nrm[wave] = s;
+        if (s == s) {   // NaN rows are legal (excluded from every search)
+            if (s > 3.0e38f)
+                atomicOr(&scal[1], 1u);
+            else
+                atomicMax(&scal[0], __float_as_uint(s));
+        }
+    }
+}
+
+#define GT 128     // block tile (samples x nodes)
+#define GK 32      // K chunk
+#define GLD 36     // LDS row stride (floats)
+
+__global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict__ X, int ldx, int s0, int s1,
+                                                         const float *__restrict__ M, int ldm, int N, int Kp,
+                                                         const float *__restrict__ nrm,
+                                                         float *__restrict__ G, int ldg)
+{
+    __shared__ __attribute__((aligned(16))) float As[GT * GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[GT * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int sbase = s0 + blockIdx.y * GT, nbase = blockIdx.x * GT;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    f32x16 tot[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tot[i][j][r] = 0.f;
+
+    float4 pa[4], pb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int f = tid + 256 * i;
+            int row = f >> 3, c4 = (f & 7) * 4;
+            int s = sbase + row, n = nbase + row;
+            pa[i] = s < s1 ? *reinterpret_cast<const float4 *>(X + (size_t)s * ldx + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[i] = n < N ? *reinterpret_cast<const float4 *>(M + (size_t)n * ldm + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < Kp; k0 += GK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int f = tid + 256 * i;
+            int row = f >> 3, c4 = (f & 7) * 4;
+            *reinterpret_cast<float4 *>(&As[row * GLD + c4]) = pa[i];
+            *reinterpret_cast<float4 *>(&Bs[row * GLD + c4]) = pb[i];
+        }
+        __syncthreads();
+        if (k0 + GK < Kp)
+            gload(k0 + GK);
+        // one fmaf chain of length GK per chunk (short chains keep the error bound tight)
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < GK; kb += 8) {
+            float4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const float4 *>(&As[(wm * 64 + i * 32 + lr) * GLD + kb + 4 * lh]);
+                b[i] = *reinterpret_cast<const float4 *>(&Bs[(wn * 64 + i * 32 + lr) * GLD + kb + 4 * lh]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tot[i][j][r] = tot[i][j][r] + acc[i][j][r];
+    }
+    // epilogue: G = nrm - 2*dot   (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = nbase + wn * 64 + j * 32 + lr;
+        const float nm = col < N ? nrm[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = sbase + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < s1 && col < N) {
+                    float t = 2.f * tot[i][j][r];
+                    G[(size_t)(row - s0) * ldg + col] = nm - t;
+                }
+            }
+        }
+    }
+}
+
+// one wavefront per sample.  stats: [0] samples sent to the exact redo list, [1] total candidates
+__global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int s1, int N, int D,
+                                                        const float *__restrict__ G, int ldg,
+                                                        const unsigned *__restrict__ scal, float c_g1, float c_g2,
+                                                        u64 *__restrict__ lastbmu, float *__restrict__ sqres,
+                                                        unsigned *__restrict__ redo_count, int *__restrict__ redo_list,
+                                                        unsigned *__restrict__ stats)
+{
+    __shared__ unsigned cand[4][SL_CMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = s0 + blockIdx.x * 4 + wave;
+    if (s >= s1)
+        return;   // wave-uniform
+    const float *xr = a.xa + (size_t)s * a.ldx;
+    const float *g = G + (size_t)(s - s0) * ldg;
+    // |x|^2
+    float nx = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        float v = xr[d];
+        float p = v * v;
+        nx = nx + p;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        nx = nx + __shfl_xor(nx, off);
+    const float nmax = __uint_as_float(scal[0]);
+    bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f);
+    // pass 1: minimum of the approximations (a NaN never replaces the incumbent)
+    float m = __uint_as_float(0x7F800000u);
+    for (int i = lane; i < N; i += 64) {
+        float v = g[i];
+        m = v < m ? v : m;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        float o = __shfl_xor(m, off);
+        m = o < m ? o : m;
+    }
+    unsigned cnt = 0;
+    if (!bad) {
+        // T_s = 4*g1*(nMmax+nx) + 2.1*g2*(m + nx + 2*g1*(nMmax+nx)), inflated by 1.05 (header)
+        const float ea = c_g1 * (nmax + nx);                 // c_g1 = 2*g1
+        float dj = m + nx;
+        dj = dj + ea;
+        dj = dj > 0.f ? dj : 0.f;
+        const float T = 1.05f * (2.f * ea + c_g2 * dj);      // c_g2 = 2.1*g2
+        const float thr = m + T;
+        if (!(thr < 3.0e38f))
+            bad = true;                                      // nothing finite to compare with
+        // pass 2: collect candidates (order irrelevant: the key min decides)
+        for (int i0 = 0; i0 < N && !bad; i0 += 64) {
+            int i = i0 + lane;
+            bool c = i < N && g[i] <= thr;
+            u64 mask = __ballot(c);
+            unsigned before = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+            if (c && cnt + before < SL_CMAX)
+                cand[wave][cnt + before] = (unsigned)i;
+            cnt += (unsigned)__popcll(mask);
+        }
+        if (cnt > SL_CMAX)
+            bad = true;
+    }
+    if (bad) {
+        if (lane == 0) {
+            unsigned slot = atomicAdd(redo_count, 1u);
+            redo_list[slot] = s;
+            atomicAdd(&stats[0], 1u);
+        }
+        return;
+    }
+    // exact-order evaluation: 8 lanes per candidate, node 0 always included
+    const int grp = lane >> 3, k = lane & 7;
+    float d0 = vsom_group_dist<false>(xr, xr, a.ma, a.ma, a.L, k);
+    d0 = __shfl(d0, 0);
+    u64 best = vsom_key(d0, 0u);
+    const bool nan0 = d0 != d0;
+    for (unsigned c0 = 0; c0 < cnt; c0 += 8) {
+        unsigned ci = c0 + grp;
+        unsigned node = cand[wave][ci < cnt ? ci : cnt - 1];
+        float d = vsom_group_dist<false>(xr, xr, a.ma + (size_t)node * a.ldm, a.ma, a.L, k);
+        u64 key = ci < cnt ? vsom_key(d, node) : ~0ull;
+        best = key < best ? key : best;
+    }
+    for (int off = 32; off >= 8; off >>= 1) {
+        u64 o = __shfl_xor(best, off);
+        best = o < best ? o : best;
+    }
+    if (lane == 0) {
+        atomicAdd(&stats[1], cnt);
+        if (nan0) {
+            lastbmu[s] = 0;
+            sqres[s] = __uint_as_float(0x7FC00000u);
+        } else {
+            lastbmu[s] = best & 0xFFFFFFFFull;
+            sqres[s] = __uint_as_float((uint32_t)(best >> 32));
+        }
+    }
+}
+
+__global__ void sl_reset_kernel(unsigned *scal)
+{
+    if (threadIdx.x < 8)
+        scal[threadIdx.x] = 0u;
+}
+
+// copies {redo samples, candidates} of this call into the host-visible feedback words
+__global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsigned nrows)
+{
+    host_fb[0] = scal[4];
+    host_fb[1] = scal[5];
+    host_fb[2] = nrows;
+    __threadfence_system();
+    host_fb[3] = host_fb[3] + 1u;
+}
+
+// host side ------------------------------------------------------------------------------------
+int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount);
+
+int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
+{
+    if (s1 <= s0)
+        return VSOM_OK;
+    const size_t nrows = s1 - s0;
+    const size_t ldg = ((size_t)c->N + 127) / 128 * 128;
+    const size_t need = nrows * ldg;
+    if (need > c->sl_cap) {
+        if (c->sl_G)
+            VSOM_HIP_CHECK(hipFree(c->sl_G));
+        c->sl_G = nullptr;
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_G, need * sizeof(float)));
+        c->sl_cap = need;
+    }
+    if (nrows > c->sl_list_cap) {
+        if (c->sl_list)
+            VSOM_HIP_CHECK(hipFree(c->sl_list));
+        c->sl_list = nullptr;
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_list, nrows * sizeof(int)));
+        c->sl_list_cap = nrows;
+    }
+    if (!c->sl_nrm) {
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_nrm, (size_t)c->N * sizeof(float)));
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 64));
+        VSOM_HIP_CHECK(hipHostMalloc(&c->sl_fb, 64));
+        std::memset(c->sl_fb, 0, 64);
+    }
+    // scal: [0] max nrm bits, [1] non-finite flag, [2] redo count, [4] redo samples, [5] candidates
+    unsigned *scal = c->sl_scal;
+    hipLaunchKernelGGL(sl_reset_kernel, dim3(1), dim3(64), 0, c->stream, scal);
+    hipLaunchKernelGGL(sl_norm_kernel, dim3((unsigned)(((size_t)c->N * 64 + 255) / 256)), dim3(256), 0, c->stream,
+                       c->map, (int)c->pitch, (int)c->D, (int)c->N, c->sl_nrm, scal);
+    dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
+    hipLaunchKernelGGL(sl_gemm_kernel, grid, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, (int)s0, (int)s1,
+                       c->map, (int)c->pitch, (int)c->N, (int)c->xpitch, c->sl_nrm, c->sl_G, (int)ldg);
+    DistArgs a;
+    a.xa = c->Xs;
+    a.xb = c->Xs;
+    a.ldx = (int)c->xpitch;
+    a.ma = c->map;
+    a.mb = c->map;
+    a.ldm = (int)c->pitch;
+    a.L = (int)c->part_len;
+    const double u = 5.9604644775390625e-08;   // 2^-24
+    const double K = (double)c->xpitch;
+    const double g1 = ((double)GK + K / GK + 3.0) * u, g2 = ((double)c->D / 8.0 + 10.0) * u;
+    hipLaunchKernelGGL(sl_select_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, a, (int)s0,
+                       (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, scal, (float)(2.0 * g1), (float)(2.1 * g2),
+                       c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4);
+    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows);
+    VSOM_HIP_CHECK(hipGetLastError());
+    // exact-order redo of the listed samples (device-side count; blocks beyond it exit at once)
+    return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2);
+}
