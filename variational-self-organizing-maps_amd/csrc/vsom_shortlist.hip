@@ -36,24 +36,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define SL_CMAX 2048
 
-__global__ __launch_bounds__(256) void sl_norm_kernel(const float *__restrict__ map, int ldm, int D, int N,
+__global__ __launch_bounds__(256) void sl_norm_kernel(const float *__restrict__ map, int ldm, int Dp, int N,
                                                       float *__restrict__ nrm, unsigned *__restrict__ scal)
 {
-    // one wavefront per node; scal[0] = max finite nrm (as uint bits), scal[1] = non-finite flag
-    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
-    if (wave >= N)
-        return;
-    const float *row = map + (size_t)wave * ldm;
-    float s = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        float v = row[d];
-        float p = v * v;
-        s = s + p;
+    // 16 lanes per node, float4 per lane (rows are zero padded to Dp, a multiple of 32);
+    // scal[0] = max finite nrm (as uint bits), scal[1] = non-finite flag
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int node = gid >> 4, sub = gid & 15;
+    const int nc = node < N ? node : N - 1;
+    const float4 *row = reinterpret_cast<const float4 *>(map + (size_t)nc * ldm);
+    const int n4 = Dp >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll 4
+    for (int q = sub; q < n4; q += 16) {
+        float4 v = row[q];
+        s0 = s0 + v.x * v.x;
+        s1 = s1 + v.y * v.y;
+        s2 = s2 + v.z * v.z;
+        s3 = s3 + v.w * v.w;
     }
-    for (int off = 32; off > 0; off >>= 1)
+    float s = (s0 + s1) + (s2 + s3);
+    for (int off = 8; off > 0; off >>= 1)
         s = s + __shfl_xor(s, off);
-    if (lane == 0) {
-        nrm[wave] = s;
+    if (sub == 0 && node < N) {
+        nrm[node] = s;
         if (s == s) {   // NaN rows are legal (excluded from every search)
             if (s > 3.0e38f)
                 atomicOr(&scal[1], 1u);
@@ -70,7 +76,8 @@ __global__ __launch_bounds__(256) void sl_norm_kernel(const float *__restrict__ 
 __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict__ X, int ldx, int s0, int s1,
                                                          const float *__restrict__ M, int ldm, int N, int Kp,
                                                          const float *__restrict__ nrm,
-                                                         float *__restrict__ G, int ldg)
+                                                         float *__restrict__ G, int ldg,
+                                                         float *__restrict__ tmin, int ntm)
 {
     __shared__ __attribute__((aligned(16))) float As[GT * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[GT * GLD];
@@ -148,20 +155,33 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict
                     tot[i][j][r] = tot[i][j][r] + acc[i][j][r];
     }
     // epilogue: G = nrm - 2*dot   (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    // plus the minimum of every sample row over this wavefront's 64 nodes (NaN never replaces)
+    const float inf = __uint_as_float(0x7F800000u);
+    const int col0 = nbase + wn * 64 + lr, col1 = col0 + 32;
+    const float nm0 = col0 < N ? nrm[col0] : 0.f, nm1 = col1 < N ? nrm[col1] : 0.f;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = nbase + wn * 64 + j * 32 + lr;
-        const float nm = col < N ? nrm[col] : 0.f;
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = sbase + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < s1 && col < N) {
-                    float t = 2.f * tot[i][j][r];
-                    G[(size_t)(row - s0) * ldg + col] = nm - t;
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int row = sbase + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float g0 = nm0 - 2.f * tot[i][0][r];
+            float g1 = nm1 - 2.f * tot[i][1][r];
+            if (row < s1) {
+                if (col0 < N)
+                    G[(size_t)(row - s0) * ldg + col0] = g0;
+                if (col1 < N)
+                    G[(size_t)(row - s0) * ldg + col1] = g1;
             }
+            float mn = col0 < N ? g0 : inf;
+            mn = (col1 < N && g1 < mn) ? g1 : mn;
+            mn = mn == mn ? mn : inf;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {   // the 32 lanes that share this row
+                float o = __shfl_xor(mn, off);
+                mn = o < mn ? o : mn;
+            }
+            if (lr == 0 && row < s1)
+                tmin[(size_t)(row - s0) * ntm + blockIdx.x * 2 + wn] = mn;
         }
     }
 }
@@ -169,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict
 // one wavefront per sample.  stats: [0] samples sent to the exact redo list, [1] total candidates
 __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int s1, int N, int D,
                                                         const float *__restrict__ G, int ldg,
+                                                        const float *__restrict__ tmin, int ntm,
                                                         const unsigned *__restrict__ scal, float c_g1, float c_g2,
                                                         u64 *__restrict__ lastbmu, float *__restrict__ sqres,
                                                         unsigned *__restrict__ redo_count, int *__restrict__ redo_list,
@@ -194,9 +215,12 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f);
     // pass 1: minimum of the approximations (a NaN never replaces the incumbent)
     float m = __uint_as_float(0x7F800000u);
-    for (int i = lane; i < N; i += 64) {
-        float v = g[i];
-        m = v < m ? v : m;
+    {
+        const float *tm = tmin + (size_t)(s - s0) * ntm;
+        for (int i = lane; i < ntm; i += 64) {
+            float v = tm[i];
+            m = v < m ? v : m;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         float o = __shfl_xor(m, off);
@@ -214,14 +238,24 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         if (!(thr < 3.0e38f))
             bad = true;                                      // nothing finite to compare with
         // pass 2: collect candidates (order irrelevant: the key min decides)
-        for (int i0 = 0; i0 < N && !bad; i0 += 64) {
-            int i = i0 + lane;
-            bool c = i < N && g[i] <= thr;
-            u64 mask = __ballot(c);
-            unsigned before = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-            if (c && cnt + before < SL_CMAX)
-                cand[wave][cnt + before] = (unsigned)i;
-            cnt += (unsigned)__popcll(mask);
+        const float4 *g4 = reinterpret_cast<const float4 *>(g);   // rows are ldg (x128) floats long
+        const u64 below = (1ull << lane) - 1ull;
+        for (int i0 = 0; i0 < N && !bad; i0 += 256) {
+            const int i = i0 + lane * 4;
+            float4 v = i < N ? g4[i >> 2] : make_float4(thr, thr, thr, thr);
+            const bool c0 = i < N && v.x <= thr, c1 = i + 1 < N && v.y <= thr;
+            const bool c2 = i + 2 < N && v.z <= thr, c3 = i + 3 < N && v.w <= thr;
+            if (__ballot(c0 | c1 | c2 | c3) == 0ull)
+                continue;
+            const bool cs[4] = {c0, c1, c2, c3};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u64 mask = __ballot(cs[e]);
+                unsigned before = (unsigned)__popcll(mask & below);
+                if (cs[e] && cnt + before < SL_CMAX)
+                    cand[wave][cnt + before] = (unsigned)(i + e);
+                cnt += (unsigned)__popcll(mask);
+            }
         }
         if (cnt > SL_CMAX)
             bad = true;
@@ -296,6 +330,14 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
         VSOM_HIP_CHECK(hipMalloc(&c->sl_G, need * sizeof(float)));
         c->sl_cap = need;
     }
+    const size_t ntm = (((size_t)c->N + GT - 1) / GT) * 2;
+    if (nrows * ntm > c->sl_tmin_cap) {
+        if (c->sl_tmin)
+            VSOM_HIP_CHECK(hipFree(c->sl_tmin));
+        c->sl_tmin = nullptr;
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_tmin, nrows * ntm * sizeof(float)));
+        c->sl_tmin_cap = nrows * ntm;
+    }
     if (nrows > c->sl_list_cap) {
         if (c->sl_list)
             VSOM_HIP_CHECK(hipFree(c->sl_list));
@@ -312,11 +354,11 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     // scal: [0] max nrm bits, [1] non-finite flag, [2] redo count, [4] redo samples, [5] candidates
     unsigned *scal = c->sl_scal;
     hipLaunchKernelGGL(sl_reset_kernel, dim3(1), dim3(64), 0, c->stream, scal);
-    hipLaunchKernelGGL(sl_norm_kernel, dim3((unsigned)(((size_t)c->N * 64 + 255) / 256)), dim3(256), 0, c->stream,
-                       c->map, (int)c->pitch, (int)c->D, (int)c->N, c->sl_nrm, scal);
+    hipLaunchKernelGGL(sl_norm_kernel, dim3((unsigned)(((size_t)c->N * 16 + 255) / 256)), dim3(256), 0, c->stream,
+                       c->map, (int)c->pitch, (int)c->part_pitch, (int)c->N, c->sl_nrm, scal);
     dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
     hipLaunchKernelGGL(sl_gemm_kernel, grid, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, (int)s0, (int)s1,
-                       c->map, (int)c->pitch, (int)c->N, (int)c->xpitch, c->sl_nrm, c->sl_G, (int)ldg);
+                       c->map, (int)c->pitch, (int)c->N, (int)c->xpitch, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm);
     DistArgs a;
     a.xa = c->Xs;
     a.xb = c->Xs;
@@ -329,7 +371,7 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     const double K = (double)c->xpitch;
     const double g1 = ((double)GK + K / GK + 3.0) * u, g2 = ((double)c->D / 8.0 + 10.0) * u;
     hipLaunchKernelGGL(sl_select_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, a, (int)s0,
-                       (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, scal, (float)(2.0 * g1), (float)(2.1 * g2),
+                       (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(2.0 * g1), (float)(2.1 * g2),
                        c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4);
     hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows);
     VSOM_HIP_CHECK(hipGetLastError());

@@ -32,33 +32,79 @@ __global__ void bxy_kernel(const u64 *__restrict__ lastbmu, int B, int W, int H,
     bxy[j] = make_int2(x, y);
 }
 
-// one thread per node of [n0,n1)
-__global__ __launch_bounds__(64) void cw_kernel(const int2 *__restrict__ bxy, int B, int n0, int n1,
-                                                int W, int H, const float *__restrict__ lut,
-                                                int lutw, float2 *__restrict__ cw, int ldn,
-                                                float *__restrict__ weight)
+// Neighbourhood chain.  Only the fp32 prefix sum W_j = W_{j-1} + w_j is inherently serial; the
+// table lookup of w and the division c = w/W are not.  A quad of 4 lanes serves one node: lane q
+// of the quad looks up / divides / stores the samples j = 4r+q, while all four lanes run the
+// same serial chain redundantly (w of the other lanes arrives through DPP quad broadcasts), so
+// no lane ever waits for a cross-lane hand-off.  16 nodes per wavefront, N/16 wavefronts.
+#define CWR 4   // rounds (of 4 samples) in flight per loop iteration
+template <bool LUT_LDS>
+__global__ __launch_bounds__(256) void cw_kernel(const int2 *__restrict__ bxy, int B, int n0, int n1,
+                                                 int W, int H, const float *__restrict__ lut,
+                                                 int lutw, int luth, float2 *__restrict__ cw, int ldn,
+                                                 float *__restrict__ weight)
 {
-    const int nl = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ float slut[];
+    if (LUT_LDS) {
+        for (int i = threadIdx.x; i < lutw * luth; i += blockDim.x)
+            slut[i] = lut[i];
+        __syncthreads();
+    }
+    const float *tab = LUT_LDS ? slut : lut;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = gid & 3;
+    const int nl = gid >> 2;
     const int node = n0 + nl;
     const bool valid = node < n1;
     int cx = 0, cy = 0;
     if (valid)
         vsom_somindex((u64)node, (u64)W, (u64)H, cx, cy);   // SomIndex(*this, index) (Som.cpp:816)
-    float sumW = 0.f;                                        // :840
+    float run = 0.f;                                         // sumOfWeights :840
     float2 *out = cw + (valid ? nl : 0);
-    for (int j = 0; j < B; ++j) {
+    const int Bq = B & ~3;
+    int j = 0;
+    for (; j + 4 * CWR <= Bq; j += 4 * CWR) {
+        float w[CWR], Wm[CWR];
+#pragma unroll
+        for (int r = 0; r < CWR; ++r) {
+            int2 b = bxy[j + 4 * r + q];
+            int dx = cx - b.x, dy = cy - b.y;
+            dx = dx < 0 ? -dx : dx;
+            dy = dy < 0 ? -dy : dy;
+            w[r] = tab[dy * lutw + dx];      // (float)calculateNeighbourhoodWeight(...)  :851
+        }
+#pragma unroll
+        for (int r = 0; r < CWR; ++r) {
+            // samples 4r..4r+3 in order; every lane of the quad runs the same additions
+            float w0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w[r]), 0x00, 0xF, 0xF, true));
+            float w1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w[r]), 0x55, 0xF, 0xF, true));
+            float w2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w[r]), 0xAA, 0xF, 0xF, true));
+            float w3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w[r]), 0xFF, 0xF, 0xF, true));
+            float W0 = run + w0;             // :857
+            float W1 = W0 + w1;
+            float W2 = W1 + w2;
+            float W3 = W2 + w3;
+            run = W3;
+            Wm[r] = q == 0 ? W0 : (q == 1 ? W1 : (q == 2 ? W2 : W3));
+        }
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < CWR; ++r)
+                out[(size_t)(j + 4 * r + q) * ldn] = make_float2(w[r] / Wm[r], w[r]);   // c = w/W :864 (0/0 -> NaN, Q7)
+        }
+    }
+    for (; j < B; ++j) {   // tail, every lane of the quad redundantly; lane 0 stores
         int2 b = bxy[j];
         int dx = cx - b.x, dy = cy - b.y;
         dx = dx < 0 ? -dx : dx;
         dy = dy < 0 ? -dy : dy;
-        float w = lut[dy * lutw + dx];   // (float)calculateNeighbourhoodWeight(...)  :851
-        sumW = sumW + w;                 // :857
-        float c = w / sumW;              // currentWeight / sumOfWeights  :864 (0/0 -> NaN, Q7)
-        if (valid)
-            out[(size_t)j * ldn] = make_float2(c, w);
+        float w = tab[dy * lutw + dx];
+        run = run + w;
+        if (valid && q == 0)
+            out[(size_t)j * ldn] = make_float2(w / run, w);
     }
-    if (valid)
-        weight[node] = sumW;   // :875
+    if (valid && q == 0)
+        weight[node] = run;   // :875
 }
 
 // Eigen scalar_sign_op<float>: NaN -> NaN, else (a>0)-(a<0) as float (Transformation.cpp:50)
@@ -264,9 +310,15 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         TimerScope ts(c, VSOM_T_CW);
         hipLaunchKernelGGL(bxy_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, c->stream,
                            c->lastbmu, (int)c->B, (int)c->W, (int)c->H, c->bxy);
-        hipLaunchKernelGGL(cw_kernel, dim3((unsigned)((nloc + 63) / 64)), dim3(64), 0, c->stream,
-                           c->bxy, (int)c->B, (int)n0, (int)n1, (int)c->W, (int)c->H, c->lut,
-                           (int)c->lut_w, c->cw, (int)ldn, c->weight);
+        const size_t lut_bytes = (size_t)c->lut_w * c->lut_h * sizeof(float);
+        if (lut_bytes <= 64 * 1024)
+            hipLaunchKernelGGL(cw_kernel<true>, dim3((unsigned)((nloc * 4 + 255) / 256)), dim3(256), lut_bytes,
+                               c->stream, c->bxy, (int)c->B, (int)n0, (int)n1, (int)c->W, (int)c->H, c->lut,
+                               (int)c->lut_w, (int)c->lut_h, c->cw, (int)ldn, c->weight);
+        else
+            hipLaunchKernelGGL(cw_kernel<false>, dim3((unsigned)((nloc * 4 + 255) / 256)), dim3(256), 0,
+                               c->stream, c->bxy, (int)c->B, (int)n0, (int)n1, (int)c->W, (int)c->H, c->lut,
+                               (int)c->lut_w, (int)c->lut_h, c->cw, (int)ldn, c->weight);
         VSOM_HIP_CHECK(hipGetLastError());
     }
     {
