@@ -198,7 +198,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
                          "traffic": traffic,
-                         "kernel": "update_kernel<16,false> (phase-2 mean/sigma^2 chains)",
+                         "kernel": "vsom_update_std_rd14_gfx950 (phase-2 mean/sigma^2 chains, hand-scheduled)",
                          "note": ("fp32 VALU-bound kernel priced against the fp32 dense peak shared by the vector and "
                                   "matrix pipes; strict non-FMA arithmetic caps it at 0.5"),
                          "avg_launch_ms": round(upd_avg_s * 1e3, 4),

@@ -82,7 +82,8 @@ typedef enum vsom_timer {
     VSOM_T_CW = 3,         /* neighbourhood weight chain (w, w/W) kernel        */
     VSOM_T_UPDATE = 4,     /* mean / sigma^2 chain kernel                       */
     VSOM_T_ONLINE = 5,     /* online (trainSingle) kernels                      */
-    VSOM_T_COUNT = 6
+    VSOM_T_SIGMA = 6,      /* sigmaMap = sqrt(S/W) pass after the assembly chain kernel */
+    VSOM_T_COUNT = 7
 } vsom_timer;
 
 const char *vsom_last_error(void);

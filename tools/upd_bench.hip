@@ -350,8 +350,160 @@ __global__ __launch_bounds__(256) void upd_v4(const float *__restrict__ Xs, int 
         if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
 }
 
+
+// ---------------- V5: x and cw tiles through LDS by global_load_lds (DMA), 2 buffers ----------------
+template <int RD, int TJ, int WPB>
+__global__ __launch_bounds__(WPB * 64) void upd_v5(const float *__restrict__ Xs, int ldx, const float2 *__restrict__ cw, int ldn, int B,
+                                                   int nloc, int D, int nslices, float *__restrict__ map, float *__restrict__ S_out, int pitch)
+{
+    constexpr int NT = WPB * 64;
+    constexpr int XROW = WPB * RD * 4;                 // bytes of one x tile row
+    constexpr int CWB = TJ * 512, XB = TJ * XROW;      // bytes per tile
+    constexpr int XPIECES = XB / 16;
+    static_assert(XROW % 16 == 0, "x tile row must be a multiple of 16 B");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][CWB + XB]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * WPB + wave;
+    const bool active = slice < nslices;
+    const int dblk = blockIdx.y * WPB * RD;
+    const int nb = blockIdx.x * 64;
+    float M[RD], S[RD];
+#pragma unroll
+    for (int k = 0; k < RD; ++k) { M[k] = 0.f; S[k] = 0.f; }
+
+    auto issue = [&](int t, int buf) {
+        unsigned char *base = lds + buf * (CWB + XB);
+        // cw: TJ rows x 512 B; one wave-instruction = 2 rows
+        for (int i = wave; i < TJ / 2; i += WPB) {
+            const int row = t * TJ + 2 * i + (lane >> 5);
+            const char *src = reinterpret_cast<const char *>(cw + (size_t)row * ldn + nb) + (lane & 31) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                             (__attribute__((address_space(3))) void *)(base + i * 1024), 16, 0, 0);
+        }
+        // x: TJ rows x XROW B, dense
+        for (int i = wave; i * 64 < XPIECES; i += WPB) {
+            int f = i * 64 + lane;
+            f = f < XPIECES ? f : XPIECES - 1;
+            const int row = t * TJ + f / (XROW / 16), piece = f % (XROW / 16);
+            const char *src = reinterpret_cast<const char *>(Xs + (size_t)row * ldx + dblk) + piece * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                             (__attribute__((address_space(3))) void *)(base + CWB + i * 1024), 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    __syncthreads();
+    const int ntiles = B / TJ;
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        issue(t + 1, cur ^ 1);   // rows beyond B are padded in the harness
+        if (active) {
+            const unsigned char *base = lds + cur * (CWB + XB);
+            const float2 *ct = reinterpret_cast<const float2 *>(base) + lane;
+            const float *xt = reinterpret_cast<const float *>(base + CWB) + wave * RD;
+#pragma unroll 4
+            for (int u = 0; u < TJ; ++u) {
+                float2 cv = ct[u * 64];
+                float x[RD];
+#pragma unroll
+                for (int k = 0; k < RD; k += 2) {
+                    float2 xv = *reinterpret_cast<const float2 *>(xt + u * (XROW / 4) + k);
+                    x[k] = xv.x; x[k + 1] = xv.y;
+                }
+                step<RD>(M, S, x, cv.x, cv.y);
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        const int d0 = slice * RD;
+        const int nl = nb + lane;
+#pragma unroll
+        for (int k = 0; k < RD; ++k)
+            if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
+    }
+}
+
+
+// ---------------- V6: like V5 but two distinct __shared__ arrays (alias info) + explicit LDS read pipelining ----------------
+template <int RD, int TJ, int WPB>
+__global__ __launch_bounds__(WPB * 64) void upd_v6(const float *__restrict__ Xs, int ldx, const float2 *__restrict__ cw, int ldn, int B,
+                                                   int nloc, int D, int nslices, float *__restrict__ map, float *__restrict__ S_out, int pitch)
+{
+    constexpr int XROW = WPB * RD * 4;
+    constexpr int CWB = TJ * 512, XB = TJ * XROW;
+    constexpr int XPIECES = XB / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char ldsA[CWB + XB];
+    __shared__ __attribute__((aligned(16))) unsigned char ldsB[CWB + XB];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int slice = blockIdx.y * WPB + wave;
+    const bool active = slice < nslices;
+    const int dblk = blockIdx.y * WPB * RD;
+    const int nb = blockIdx.x * 64;
+    float M[RD], S[RD];
+#pragma unroll
+    for (int k = 0; k < RD; ++k) { M[k] = 0.f; S[k] = 0.f; }
+
+    auto issue = [&](int t, unsigned char *base) {
+        for (int i = wave; i < TJ / 2; i += WPB) {
+            const int row = t * TJ + 2 * i + (lane >> 5);
+            const char *src = reinterpret_cast<const char *>(cw + (size_t)row * ldn + nb) + (lane & 31) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                             (__attribute__((address_space(3))) void *)(base + i * 1024), 16, 0, 0);
+        }
+        for (int i = wave; i * 64 < XPIECES; i += WPB) {
+            int f = i * 64 + lane;
+            f = f < XPIECES ? f : XPIECES - 1;
+            const int row = t * TJ + f / (XROW / 16), piece = f % (XROW / 16);
+            const char *src = reinterpret_cast<const char *>(Xs + (size_t)row * ldx + dblk) + piece * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src),
+                                             (__attribute__((address_space(3))) void *)(base + CWB + i * 1024), 16, 0, 0);
+        }
+    };
+    auto compute = [&](const unsigned char *base) {
+        const float2 *ct = reinterpret_cast<const float2 *>(base) + lane;
+        const float *xt = reinterpret_cast<const float *>(base + CWB) + wave * RD;
+        float2 cv = ct[0];
+        float x[RD];
+#pragma unroll
+        for (int k = 0; k < RD; k += 2) { float2 xv = *reinterpret_cast<const float2 *>(xt + k); x[k] = xv.x; x[k + 1] = xv.y; }
+#pragma unroll 2
+        for (int u = 0; u < TJ; ++u) {
+            const int un = u + 1 < TJ ? u + 1 : u;
+            float2 cn = ct[un * 64];
+            float xn[RD];
+#pragma unroll
+            for (int k = 0; k < RD; k += 2) { float2 xv = *reinterpret_cast<const float2 *>(xt + un * (XROW / 4) + k); xn[k] = xv.x; xn[k + 1] = xv.y; }
+            step<RD>(M, S, x, cv.x, cv.y);
+            cv = cn;
+#pragma unroll
+            for (int k = 0; k < RD; ++k) x[k] = xn[k];
+        }
+    };
+    issue(0, ldsA);
+    __syncthreads();
+    const int ntiles = B / TJ;   // even in the harness
+    for (int t = 0; t < ntiles; t += 2) {
+        issue(t + 1, ldsB);
+        if (active) compute(ldsA);
+        __syncthreads();
+        issue(t + 2, ldsA);
+        if (active) compute(ldsB);
+        __syncthreads();
+    }
+    if (active) {
+        const int d0 = slice * RD;
+        const int nl = nb + lane;
+#pragma unroll
+        for (int k = 0; k < RD; ++k)
+            if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
+    }
+}
+
 int main(int argc, char **argv)
 {
+    setvbuf(stdout, NULL, _IONBF, 0);
     const int N = 16384, D = 784, B = 4096, pitch = 800, ldx = 800, ldn = N;
     const int reps = argc > 1 ? atoi(argv[1]) : 3;
     std::vector<float> hx((size_t)(B + 72) * ldx), hcw((size_t)(B + 72) * ldn * 2);
@@ -364,6 +516,20 @@ int main(int argc, char **argv)
     CK(hipMalloc(&dmap2, (size_t)N * pitch * 4)); CK(hipMalloc(&dS2, (size_t)N * pitch * 4));
     CK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dcw, hcw.data(), hcw.size() * 4, hipMemcpyHostToDevice));
+    // pair-interleaved copy for the assembly kernel: float4 {c_j,w_j,c_j+1,w_j+1} at [(j>>1)][node]
+    float2 *dcw2;
+    {
+        std::vector<float> h2(hcw.size());
+        const size_t rows = hcw.size() / 2 / ldn;
+        for (size_t j = 0; j + 1 < rows; ++j)
+            for (size_t i = 0; i < (size_t)ldn; ++i) {
+                size_t dst = (((j >> 1) * ldn + i) * 2 + (j & 1)) * 2;
+                h2[dst] = hcw[(j * ldn + i) * 2];
+                h2[dst + 1] = hcw[(j * ldn + i) * 2 + 1];
+            }
+        CK(hipMalloc(&dcw2, h2.size() * 4));
+        CK(hipMemcpy(dcw2, h2.data(), h2.size() * 4, hipMemcpyHostToDevice));
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ref((size_t)N * pitch), got((size_t)N * pitch), refS((size_t)N * pitch), gotS((size_t)N * pitch);
 
@@ -395,9 +561,29 @@ int main(int argc, char **argv)
     run("v3 RD16 G4 pinned pipeline", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v3<16, 4>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
     run("v3 RD16 G8 pinned pipeline", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v3<16, 8>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
     run("v3 RD14 G8 pinned pipeline", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v3<14, 8>), dim3(N / 64, 14), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 56, m, s, pitch); }, false);
-    run("v4 RD16 asm ring pf8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v4<16, 8>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
-    run("v4 RD16 asm ring pf16", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v4<16, 16>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, m, s, pitch); }, false);
-    run("v4 RD14 asm ring pf8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v4<14, 8>), dim3(N / 64, 14), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 56, m, s, pitch); }, false);
+    run("v5 RD14 glds tj32 wpb8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v5<14, 32, 8>), dim3(N / 64, 7), dim3(512), 2 * 32 * (512 + 8 * 14 * 4), 0, dx, ldx, dcw, ldn, B, N, D, 56, m, s, pitch); }, false);
+    run("v5 RD14 glds tj16 wpb8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v5<14, 16, 8>), dim3(N / 64, 7), dim3(512), 2 * 16 * (512 + 8 * 14 * 4), 0, dx, ldx, dcw, ldn, B, N, D, 56, m, s, pitch); }, false);
+    run("v5 RD28 glds tj32 wpb4", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v5<28, 32, 4>), dim3(N / 64, 7), dim3(256), 2 * 32 * (512 + 4 * 28 * 4), 0, dx, ldx, dcw, ldn, B, N, D, 28, m, s, pitch); }, false);
+    run("v6 RD14 glds2 tj32 wpb8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v6<14, 32, 8>), dim3(N / 64, 7), dim3(512), 0, 0, dx, ldx, dcw, ldn, B, N, D, 56, m, s, pitch); }, false);
+    run("v6 RD28 glds2 tj32 wpb4", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v6<28, 32, 4>), dim3(N / 64, 7), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 28, m, s, pitch); }, false);
+    {
+        hipModule_t mod;
+        if (hipModuleLoad(&mod, "/tmp/vu.hsaco") == hipSuccess) {
+            struct Args { const void *xs; const void *cw; void *map; void *sb; unsigned ldxb, ldnb, B, nloc, nsl, pitchb, n0, pad; };
+            struct V { const char *name; int rd; } vs[] = {{"vsom_update_std_rd16_gfx950", 16}, {"vsom_update_std_rd14_gfx950", 14}};
+            for (auto &v : vs) {
+                hipFunction_t fn;
+                if (hipModuleGetFunction(&fn, mod, v.name) != hipSuccess) { printf("missing %s\n", v.name); continue; }
+                const unsigned nsl = D / v.rd;
+                run(v.name + 12, [&](float *m, float *s) {
+                    Args a{dx, dcw2, m, s, (unsigned)ldx * 4u, (unsigned)ldn * 16u, (unsigned)B, (unsigned)N, nsl, (unsigned)pitch * 4u, 0u, 0u};
+                    size_t sz = sizeof(a);
+                    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+                    CK(hipModuleLaunchKernel(fn, N / 64, (nsl + 3) / 4, 1, 256, 1, 1, 0, 0, nullptr, extra));
+                }, false);
+            }
+        } else printf("asm module not loaded\n");
+    }
     run("v1 RD16 wpb7 pf4", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v1<16, 4>), dim3(N / 64, 7), dim3(448), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, 7, m, s, pitch); }, false);
     run("v1 RD16 wpb7 pf8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v1<16, 8>), dim3(N / 64, 7), dim3(448), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, 7, m, s, pitch); }, false);
     run("v1 RD16 wpb4 pf8", [&](float *m, float *s) { hipLaunchKernelGGL((upd_v1<16, 8>), dim3(N / 64, 13), dim3(256), 0, 0, dx, ldx, dcw, ldn, B, N, D, 49, 4, m, s, pitch); }, false);

@@ -17,8 +17,8 @@ STANDARD, MEDIAN, CLR = 0, 1, 2
 EXPONENTIAL, INVERSE_PROPORTIONAL, BATCHMAP = 0, 1, 2
 BMU_AUTO, BMU_EXACT, BMU_SHORTLIST = 0, 1, 2
 BUF_MAP, BUF_SIGMA, BUF_S, BUF_WEIGHT, BUF_HITS, BUF_LASTBMU, BUF_SQRES, BUF_CHUNK = range(8)
-T_STAGE, T_BMU, T_FINISH, T_CW, T_UPDATE, T_ONLINE, T_COUNT = range(7)
-TIMER_NAMES = ["stage", "bmu", "finish", "cw", "update", "online"]
+T_STAGE, T_BMU, T_FINISH, T_CW, T_UPDATE, T_ONLINE, T_SIGMA, T_COUNT = range(8)
+TIMER_NAMES = ["stage", "bmu", "finish", "cw", "update", "online", "sigma"]
 
 # every symbol include/vsom_hip.h declares (tests/test_capi_symbols.py checks the header too)
 SYMBOLS = [

@@ -2,6 +2,7 @@
 #include "vsom_internal.hpp"
 
 #include <cstring>
+#include <cstdlib>
 #include <cmath>
 #include <new>
 
@@ -81,6 +82,8 @@ static int free_all(vsom_ctx *c)
         (void)hipEventDestroy(e.a);
         (void)hipEventDestroy(e.b);
     }
+    if (c->upd_module)
+        (void)hipModuleUnload((hipModule_t)c->upd_module);
     if (c->own_stream)
         (void)hipStreamDestroy(c->own_stream);
     return 0;
@@ -129,6 +132,8 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
     c->part_pitch = roundup(c->part_len, VSOM_TK);
     c->pitch = c->nparts * c->part_pitch;
     c->xpitch = roundup(c->J, VSOM_TK);
+    if (const char *e = std::getenv("VSOM_NO_ASM"))
+        c->use_asm = !(e[0] == '1');   // debugging aid: HIP update kernel instead of the hand-scheduled one
 
     int rc = VSOM_OK;
     do {
@@ -305,7 +310,9 @@ static int ensure_chunk_capacity(vsom_ctx *c, size_t B)
     c->partial_cap = 0;
     c->Bcap = 0;
     size_t cap = (B + 63) / 64 * 64;
-    VSOM_HIP_CHECK(hipMalloc(&c->Xs, cap * c->xpitch * 4));
+    // the assembly update kernel prefetches up to 2 sample rows past the chunk
+    VSOM_HIP_CHECK(hipMalloc(&c->Xs, (cap + 8) * c->xpitch * 4));
+    VSOM_HIP_CHECK(hipMemset(c->Xs, 0, (cap + 8) * c->xpitch * 4));
     if (c->transform == VSOM_CLR) {
         VSOM_HIP_CHECK(hipMalloc(&c->XP, cap * c->part_pitch * 4));
         VSOM_HIP_CHECK(hipMalloc(&c->YP, cap * c->part_pitch * 4));

@@ -64,6 +64,10 @@ struct vsom_ctx {
     double lut_sigma = -1.0; uint32_t lut_w = 0, lut_h = 0;
     double *lutd = nullptr; size_t lutd_cap = 0; double lutd_sigma = -1.0;   // online path (double)
 
+    // hand-scheduled update kernel (code object loaded with hipModuleLoadData)
+    void *upd_module = nullptr, *upd_fn16 = nullptr, *upd_fn14 = nullptr;
+    bool use_asm = true;
+
     // online path scratch
     float *v_dev = nullptr;         // one sample, padded
     float *res_dev = nullptr;       // residual

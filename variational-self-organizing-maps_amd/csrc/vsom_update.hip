@@ -18,6 +18,15 @@
 //                  result is bit-identical to the reference's SSE2 build.
 #include "vsom_device.hpp"
 #include <cmath>
+#include <mutex>
+
+// (c,w) layout: pair-interleaved, float2 at ((j>>1)*ldn + node)*2 + (j&1), i.e. one float4
+// {c_j, w_j, c_j+1, w_j+1} per node and sample pair -- the assembly kernel (gen_update_asm.py)
+// fetches it with one global_load_dwordx4 per two samples.
+__device__ __forceinline__ size_t cw2_index(int j, int ldn, int nl)
+{
+    return (((size_t)(j >> 1) * ldn + nl) << 1) + (j & 1);
+}
 
 typedef const __attribute__((address_space(4))) float *vsom_cfp;   // forces s_load_* (scalar cache)
 
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(256) void cw_kernel(const int2 *__restrict__ bxy, i
     if (valid)
         vsom_somindex((u64)node, (u64)W, (u64)H, cx, cy);   // SomIndex(*this, index) (Som.cpp:816)
     float run = 0.f;                                         // sumOfWeights :840
-    float2 *out = cw + (valid ? nl : 0);
+    const int nlo = valid ? nl : 0;
     const int Bq = B & ~3;
     int j = 0;
     for (; j + 4 * CWR <= Bq; j += 4 * CWR) {
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(256) void cw_kernel(const int2 *__restrict__ bxy, i
         if (valid) {
 #pragma unroll
             for (int r = 0; r < CWR; ++r)
-                out[(size_t)(j + 4 * r + q) * ldn] = make_float2(w[r] / Wm[r], w[r]);   // c = w/W :864 (0/0 -> NaN, Q7)
+                cw[cw2_index(j + 4 * r + q, ldn, nlo)] = make_float2(w[r] / Wm[r], w[r]);   // c = w/W :864 (0/0 -> NaN, Q7)
         }
     }
     for (; j < B; ++j) {   // tail, every lane of the quad redundantly; lane 0 stores
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(256) void cw_kernel(const int2 *__restrict__ bxy, i
         float w = tab[dy * lutw + dx];
         run = run + w;
         if (valid && q == 0)
-            out[(size_t)j * ldn] = make_float2(w / run, w);
+            cw[cw2_index(j, ldn, nlo)] = make_float2(w / run, w);
     }
     if (valid && q == 0)
         weight[node] = run;   // :875
@@ -117,7 +126,7 @@ __device__ __forceinline__ float vsom_sign(float a)
 template <int RD, bool MEDIAN>
 __global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ Xs, int ldx,
                                                      const float2 *__restrict__ cw, int ldn, int B,
-                                                     int n0, int nloc, int D, int nslices,
+                                                     int n0, int nloc, int D, int nslices, int dbase,
                                                      float *__restrict__ map,
                                                      float *__restrict__ sigma, int pitch,
                                                      const float *__restrict__ weight)
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ X
     const int slice = blockIdx.y * 4 + wave;
     if (slice >= nslices)
         return;
-    const int d0 = slice * RD;
+    const int d0 = dbase + slice * RD;   // dbase: first dim not covered by the assembly kernel
     const int nl = blockIdx.x * 64 + lane;
     const bool valid = nl < nloc;
     const int nlc = valid ? nl : nloc - 1;
@@ -138,10 +147,9 @@ __global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ X
         M[k] = 0.f;   // currentModel.setZero()       :843
         S[k] = 0.f;   // currentModelSigma.setZero()  :844
     }
-    const float2 *cwp = cw + nlc;
     vsom_cfp xr = (vsom_cfp)(Xs + d0);
     for (int j = 0; j < B; ++j) {
-        const float2 v = cwp[(size_t)j * ldn];
+        const float2 v = cw[cw2_index(j, ldn, nlc)];
         const float c = v.x, w = v.y;
 #pragma unroll
         for (int k = 0; k < RD; ++k) {
@@ -198,11 +206,10 @@ __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict
         SA[k] = 0.f;
         SB[k] = 0.f;
     }
-    const float2 *cwp = cw + nlc;
     vsom_cfp xr = (vsom_cfp)(XP + p0);
     vsom_cfp yr = (vsom_cfp)(YP + p0);
     for (int j = 0; j < B; ++j) {
-        const float2 v = cwp[(size_t)j * ldn];
+        const float2 v = cw[cw2_index(j, ldn, nlc)];
         const float c = v.x, w = v.y;
 #pragma unroll
         for (int k = 0; k < RP; ++k) {
@@ -239,6 +246,50 @@ __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict
             }
         }
     }
+}
+
+// sigmaMap[i] = sqrt(S / W)  (Som.cpp:873) for the columns the assembly kernel left as raw S
+__global__ void sigma_finalize_kernel(float *__restrict__ sigma, int pitch, int ncols, int n0, int nloc,
+                                      const float *__restrict__ weight)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)nloc * ncols;
+    if (i >= total)
+        return;
+    const int nl = (int)(i / ncols), d = (int)(i % ncols);
+    const size_t node = (size_t)n0 + nl;
+    const float Wf = weight[node];
+    float *p = sigma + node * pitch + d;
+    *p = sqrtf(*p / Wf);
+}
+
+// hand-scheduled gfx950 code object (gen_update_asm.py -> vsom_update_gfx950.s -> .hsaco),
+// embedded at build time
+static const unsigned char vsom_update_hsaco[] = {
+#include "vsom_update_hsaco.inc"
+};
+
+struct UpdAsmArgs {
+    const void *xs;
+    const void *cw2;
+    void *map;
+    void *sbuf;
+    unsigned ldx_bytes, ldn_bytes, B, nloc, nslices, pitch_bytes, n0, pad;
+};
+
+int vsom_load_asm_module(vsom_ctx *c)
+{
+    if (c->upd_module)
+        return VSOM_OK;
+    hipModule_t mod;
+    VSOM_HIP_CHECK(hipModuleLoadData(&mod, vsom_update_hsaco));
+    hipFunction_t f16, f14;
+    VSOM_HIP_CHECK(hipModuleGetFunction(&f16, mod, "vsom_update_std_rd16_gfx950"));
+    VSOM_HIP_CHECK(hipModuleGetFunction(&f14, mod, "vsom_update_std_rd14_gfx950"));
+    c->upd_module = mod;
+    c->upd_fn16 = f16;
+    c->upd_fn14 = f14;
+    return VSOM_OK;
 }
 
 // Host: tabulate (float)calculateNeighbourhoodWeight over (|dx|,|dy|) (Som.cpp:949-975).
@@ -298,12 +349,16 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         return rc;
     const size_t nloc = n1 - n0;
     const size_t ldn = (nloc + 63) / 64 * 64;
-    const size_t need = c->B * ldn;
+    // pair rows: ceil(B/2) + the prefetch ring of the assembly kernel (4) + slack
+    const size_t prow = (c->B + 1) / 2 + 8;
+    const size_t need = prow * ldn * 2;   // float2 elements
     if (need > c->cw_cap) {
         if (c->cw)
             VSOM_HIP_CHECK(hipFree(c->cw));
         c->cw = nullptr;
         VSOM_HIP_CHECK(hipMalloc(&c->cw, need * sizeof(float2)));
+        // rows beyond B are prefetched (never used): keep them initialised
+        VSOM_HIP_CHECK(hipMemsetAsync(c->cw, 0, need * sizeof(float2), c->stream));
         c->cw_cap = need;
     }
     {
@@ -321,6 +376,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                                (int)c->lut_w, (int)c->lut_h, c->cw, (int)ldn, c->weight);
         VSOM_HIP_CHECK(hipGetLastError());
     }
+    int sig_cols = 0;   // columns left as raw S by the assembly kernel
     {
         TimerScope ts(c, VSOM_T_UPDATE);
         const unsigned gx = (unsigned)((nloc + 63) / 64);
@@ -334,17 +390,58 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                                (int)c->pitch, c->weight);
         } else {
             constexpr int RD = 16;
-            const int nsl = (int)((c->D + RD - 1) / RD);
-            dim3 grid(gx, (unsigned)((nsl + 3) / 4));
-            if (c->transform == VSOM_MEDIAN)
-                hipLaunchKernelGGL((update_kernel<RD, true>), grid, dim3(256), 0, c->stream, c->Xs,
-                                   (int)c->xpitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
-                                   (int)c->D, nsl, c->map, c->sigma, (int)c->pitch, c->weight);
-            else
-                hipLaunchKernelGGL((update_kernel<RD, false>), grid, dim3(256), 0, c->stream, c->Xs,
-                                   (int)c->xpitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
-                                   (int)c->D, nsl, c->map, c->sigma, (int)c->pitch, c->weight);
+            int dbase = 0;
+            if (c->transform == VSOM_STANDARD && c->use_asm) {
+                // hand-scheduled kernel for the full slices; RD = 14 when it tiles D exactly
+                // (14 slices per SIMD on 128x128x784: no tail wave), else 16
+                if ((rc = vsom_load_asm_module(c)))
+                    return rc;
+                const int rd = (c->D % 14 == 0) ? 14 : 16;
+                const unsigned nfull = c->D / rd;
+                if (nfull > 0) {
+                    UpdAsmArgs a;
+                    a.xs = c->Xs;
+                    a.cw2 = c->cw;
+                    a.map = c->map;
+                    a.sbuf = c->sigma;
+                    a.ldx_bytes = c->xpitch * 4u;
+                    a.ldn_bytes = (unsigned)(ldn * 16u);
+                    a.B = (unsigned)c->B;
+                    a.nloc = (unsigned)nloc;
+                    a.nslices = nfull;
+                    a.pitch_bytes = c->pitch * 4u;
+                    a.n0 = (unsigned)n0;
+                    a.pad = 0;
+                    size_t sz = sizeof(a);
+                    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
+                                     HIP_LAUNCH_PARAM_END};
+                    VSOM_HIP_CHECK(hipModuleLaunchKernel(rd == 14 ? (hipFunction_t)c->upd_fn14 : (hipFunction_t)c->upd_fn16,
+                                                         gx, (nfull + 3) / 4, 1, 256, 1, 1, 0, c->stream, nullptr, extra));
+                    dbase = (int)(nfull * rd);
+                    sig_cols = dbase;
+                }
+            }
+            const int rest = (int)c->D - dbase;
+            if (rest > 0) {
+                const int nsl = (rest + RD - 1) / RD;
+                dim3 grid(gx, (unsigned)((nsl + 3) / 4));
+                if (c->transform == VSOM_MEDIAN)
+                    hipLaunchKernelGGL((update_kernel<RD, true>), grid, dim3(256), 0, c->stream, c->Xs,
+                                       (int)c->xpitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
+                                       (int)c->D, nsl, dbase, c->map, c->sigma, (int)c->pitch, c->weight);
+                else
+                    hipLaunchKernelGGL((update_kernel<RD, false>), grid, dim3(256), 0, c->stream, c->Xs,
+                                       (int)c->xpitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
+                                       (int)c->D, nsl, dbase, c->map, c->sigma, (int)c->pitch, c->weight);
+            }
         }
+        VSOM_HIP_CHECK(hipGetLastError());
+    }
+    if (sig_cols > 0) {
+        TimerScope ts(c, VSOM_T_SIGMA);
+        const size_t tot = nloc * (size_t)sig_cols;
+        hipLaunchKernelGGL(sigma_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                           c->sigma, (int)c->pitch, sig_cols, (int)n0, (int)nloc, c->weight);
         VSOM_HIP_CHECK(hipGetLastError());
     }
     return VSOM_OK;
