@@ -1,0 +1,120 @@
+"""GPU: the C++ host mirror (variational-self-organizing-maps_amd/host, libsom_hip.so) driven the
+way the reference's perf harness drives libsom; its results are compared bit for bit with the
+oracle running the same schedules."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "variational-self-organizing-maps_amd", "host")
+
+
+def make_rows(n, d, seed):
+    out = np.empty(n * d, np.float32)
+    s = seed
+    for i in range(n * d):
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        out[i] = np.float32(np.float32((s >> 8) & 0xFFFF) / np.float32(65536.0) * np.float32(2.0) - np.float32(1.0))
+    return out.reshape(n, d)
+
+
+def read_dump(path):
+    raw = open(path, "rb").read()
+    N, D, nm = np.frombuffer(raw[:24], np.uint64)
+    N, D, nm = int(N), int(D), int(nm)
+    off = 24
+    out = {}
+    for k in ("map", "sigma", "S"):
+        out[k] = np.frombuffer(raw, np.float32, N * D, off).reshape(N, D)
+        off += N * D * 4
+    out["weight"] = np.frombuffer(raw, np.float32, N, off)
+    off += N * 4
+    out["hits"] = np.frombuffer(raw, np.uint64, N, off)
+    off += N * 8
+    out["mse"] = np.frombuffer(raw, np.float32, nm, off)
+    return out
+
+
+def beq(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind == "f":
+        return ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all()
+    return (a == b).all()
+
+
+@pytest.fixture(scope="module")
+def dumps():
+    exe = os.path.join(HOST, "host_api_test")
+    if not os.path.exists(exe):
+        subprocess.check_call(["bash", os.path.join(HOST, "build.sh")], stdout=subprocess.DEVNULL)
+    d = tempfile.mkdtemp(prefix="vsom_host_")
+    res = subprocess.run([exe, d], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    return d, res.stdout, res.stderr
+
+
+def check_state(dump, o, with_S=False):
+    assert beq(dump["map"], o.map) and beq(dump["sigma"], o.sigma)
+    assert beq(dump["weight"], o.weight) and beq(dump["hits"], o.hits)
+    if with_S:
+        assert beq(dump["S"], o.S)
+
+
+def test_batch_training_through_cpp_api(dumps):
+    d, out, _ = dumps
+    rows = make_rows(50, 9, 12345)
+    o = po.OracleSom(10, 10, 9, po.STANDARD)
+    o.random_initialize(42, 1.0)
+    done, mse = o.train_batch(rows, [0, 20, 40, 50], 5, 10.0, 0.3, nthreads=2)
+    dump = read_dump(os.path.join(d, "batch_std.bin"))
+    check_state(dump, o)
+    assert done == 5 and beq(dump["mse"], mse)
+
+
+def test_online_training_through_cpp_api(dumps):
+    d, _, _ = dumps
+    rows = make_rows(50, 9, 12345)
+    o = po.OracleSom(10, 10, 9, po.MEDIAN)
+    o.random_initialize(7, 1.0)
+    mse = o.train_online(rows, [0, 20, 40, 50], 3, 0.05, 0.1, 3.0, 0.5, po.EXPONENTIAL)
+    dump = read_dump(os.path.join(d, "online_median.bin"))
+    check_state(dump, o, with_S=True)
+    assert beq(dump["mse"], mse)
+
+    crows = make_rows(30, 5, 777)
+    o = po.OracleSom(6, 6, 5, po.CLR)
+    o.random_initialize(3, 1.0)
+    mse = o.train_online(crows, [0, 30], 2, 0.01, 0.0, 2.0, 0.2, po.INVERSE_PROPORTIONAL)
+    dump = read_dump(os.path.join(d, "online_clr.bin"))
+    check_state(dump, o, with_S=True)
+    assert beq(dump["mse"], mse)
+
+
+def test_search_single_copy_and_checkpoint(dumps):
+    d, _, _ = dumps
+    rows = make_rows(50, 9, 12345)
+    v = rows[0]
+    o = po.OracleSom(10, 10, 9)
+    o.random_initialize(11, 1.0)
+    b = o.find_bmu(v)
+    loc = o.find_local_bmu(v, 37)
+    dist = o.dist(b, v)
+    bmu, res, derr, last = o.train_single(v, 0.1, 2.0, 5, po.EXPONENTIAL)
+    tok = open(os.path.join(d, "search.txt")).read().split()
+    assert int(tok[0]) == b and int(tok[1]) == loc and float.fromhex(tok[2]) == dist
+    assert int(tok[3]) == bmu and int(tok[4]) == last
+    assert np.float32(float.fromhex(tok[5])) == derr and np.float32(float.fromhex(tok[6])) == res[0]
+    for name in ("single.bin", "single_copy.bin", "single_loaded.bin"):
+        check_state(read_dump(os.path.join(d, name)), o, with_S=True)
+
+
+def test_custom_transformation_is_rejected_not_emulated(dumps):
+    _, out, err = dumps
+    assert "custom_transformation_rejected=1 kind=-1" in out
+    assert "no CPU fallback" in err

@@ -1,0 +1,877 @@
+// vsom_host.cpp -- host-side implementation of vsom_api.hpp (libsom_hip.so).
+//
+// Every hot-path member of `Som` forwards to the C ABI of libvsom_hip.so (include/vsom_hip.h);
+// the drivers (train / trainBatchSom / trainBasicSom) restate the reference's control flow
+// (src/Som.cpp:716-754, 1113-1187) around those calls.  No training arithmetic runs here.
+#include "vsom_api.hpp"
+#include "../../../include/vsom_hip.h"
+
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+
+// ---------------------------------------------------------------------------------------------
+// Transformation (reference src/Transformation.cpp:3-167).  Host evaluation of the built-in hooks
+// is provided for callers that invoke transform.Comparer/Stepper directly; training uses the
+// device kernels selected by kind().
+// ---------------------------------------------------------------------------------------------
+namespace vsom {
+
+T StandardComparer::operator()(const T &value, const T &model, const T &, const T &) const
+{
+    T r(model.size());
+    for (Eigen::Index i = 0; i < model.size(); ++i)
+        r[i] = model[i] - value[i];   // model - value  (Transformation.cpp:8)
+    return r;
+}
+
+T StandardStepper::operator()(const T &value, const T &model, const T &) const
+{
+    T r(model.size());
+    for (Eigen::Index i = 0; i < model.size(); ++i)
+        r[i] = value[i] - model[i];   // value - model  (Transformation.cpp:12)
+    return r;
+}
+
+T MedianStepper::operator()(const T &value, const T &model, const T &) const
+{
+    T r(model.size());
+    for (Eigen::Index i = 0; i < model.size(); ++i) {
+        float a = value[i] - model[i];   // sign(value - model)  (Transformation.cpp:50)
+        r[i] = (a != a) ? a : (float)((a > 0.f) - (a < 0.f));
+    }
+    return r;
+}
+
+static void clr_inner(const T &value, const T &model, T &inner, T &xprime)
+{
+    const Eigen::Index P = model.size() / 2;   // A = head, B = tail (Transformation.cpp:87-88)
+    inner = T(P);
+    xprime = T(P);
+    Eigen::Index p = 0;
+    for (Eigen::Index i = 0; i < value.size(); ++i)
+        for (Eigen::Index j = i + 1; j < value.size(); ++j) {   // pairs i<j (Transformation.cpp:95-101)
+            if (p < P) {
+                float t = model[p] * value[i];
+                t = t + model[P + p];
+                t = t - value[j];
+                inner[p] = t;
+                xprime[p] = value[i];
+            }
+            ++p;
+        }
+}
+
+T ClrComparer::operator()(const T &value, const T &model, const T &, const T &) const
+{
+    T inner, xp;
+    clr_inner(value, model, inner, xp);
+    return inner;   // A.*x' + B - y'  (Transformation.cpp:104)
+}
+
+T ClrStepper::operator()(const T &value, const T &model, const T &) const
+{
+    T inner, xp;
+    clr_inner(value, model, inner, xp);
+    const Eigen::Index P = inner.size();
+    T delta(model.size());
+    for (Eigen::Index p = 0; p < P; ++p) {
+        float m2 = -2.f * inner[p];
+        delta[p] = m2 * xp[p];    // aDelta (Transformation.cpp:135)
+        delta[P + p] = m2;        // bDelta (Transformation.cpp:136)
+    }
+    return delta;
+}
+
+}   // namespace vsom
+
+static std::function<std::vector<std::string>(const Eigen::VectorXf &)> make_displayer(std::vector<std::string> names, bool clr)
+{
+    return [names, clr](const Eigen::VectorXf &model) {
+        std::vector<std::string> disp;
+        if (!clr) {
+            for (size_t i = 0; i < names.size() && (Eigen::Index)i < model.size(); ++i) {
+                std::stringstream ss;
+                ss << names[i] << " = " << model[(Eigen::Index)i];
+                disp.emplace_back(ss.str());
+            }
+            return disp;
+        }
+        const Eigen::Index tail = model.size() / 2;
+        Eigen::Index idx = 0;
+        for (size_t i = 0; i < names.size() && idx < tail; ++i)
+            for (size_t j = i + 1; j < names.size() && idx < tail; ++j, ++idx) {
+                std::stringstream ss;
+                ss << names[i] << " = " << model[idx] << '*' << names[j] << " + " << model[tail + idx];
+                disp.emplace_back(ss.str());
+            }
+        return disp;
+    };
+}
+
+Transformation Transformation::Standard(const std::vector<std::string> &columnNames)
+{
+    Transformation t;
+    t.names = columnNames;
+    t.Displayer = make_displayer(columnNames, false);
+    t.Name = "Standard transformation";
+    return t;
+}
+
+Transformation Transformation::StandardMedianEstimator(const std::vector<std::string> &columnNames)
+{
+    Transformation t;
+    t.Stepper = vsom::MedianStepper{};
+    t.names = columnNames;
+    t.Displayer = make_displayer(columnNames, false);
+    t.Name = "Standard median estimator transformation";
+    return t;
+}
+
+Transformation Transformation::CombinatorialLinearRegression(const std::vector<std::string> &columnNames)
+{
+    Transformation t;
+    t.Comparer = vsom::ClrComparer{};
+    t.Stepper = vsom::ClrStepper{};
+    t.Length = vsom::ClrLength{};
+    t.names = columnNames;
+    t.Displayer = make_displayer(columnNames, true);
+    t.Name = "Linear regression";
+    return t;
+}
+
+int Transformation::kind() const noexcept
+{
+    const bool sc = Comparer.target<vsom::StandardComparer>() != nullptr;
+    const bool ss = Stepper.target<vsom::StandardStepper>() != nullptr;
+    const bool ms = Stepper.target<vsom::MedianStepper>() != nullptr;
+    const bool il = Length.target<vsom::IdentityLength>() != nullptr;
+    if (sc && ss && il)
+        return vsom::Standard;
+    if (sc && ms && il)
+        return vsom::Median;
+    if (Comparer.target<vsom::ClrComparer>() && Stepper.target<vsom::ClrStepper>() && Length.target<vsom::ClrLength>())
+        return vsom::Clr;
+    return vsom::Custom;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SomIndex (reference src/SomIndex.cpp:10-44)
+// ---------------------------------------------------------------------------------------------
+SomIndex::SomIndex(size_t inX, size_t inY) noexcept : x{inX}, y{inY} {}
+SomIndex::SomIndex(const Som &map, size_t index) noexcept
+    : x{index % map.getWidth()}, y{(index - index % map.getWidth()) / map.getHeight()} {}   // divides by HEIGHT (Q10)
+size_t SomIndex::getSomIndex(const Som &map) { return map.getWidth() * y + x; }
+size_t SomIndex::getX() const noexcept { return x; }
+size_t SomIndex::getY() const noexcept { return y; }
+void SomIndex::setX(size_t ix) noexcept { x = ix; }
+void SomIndex::setY(size_t iy) noexcept { y = iy; }
+
+// ---------------------------------------------------------------------------------------------
+// ArrayDataLoader / DataSet (reference src/DataSet.cpp:8-176)
+// ---------------------------------------------------------------------------------------------
+ArrayDataLoader::ArrayDataLoader(const float *rows, size_t nrows, size_t depth, std::optional<size_t> maxLoadCount)
+    : IDataLoader(maxLoadCount), m_rows(rows, rows + nrows * depth), m_nrows(nrows), m_depth(depth),
+      m_weights(depth, 1.0f), m_binary(depth, 0), m_continuous(depth, 1)
+{
+    for (size_t i = 0; i < depth; ++i)
+        m_names.push_back("c" + std::to_string(i));
+}
+
+size_t ArrayDataLoader::load()
+{
+    const size_t chunk = m_maxLoadCount.value_or(m_nrows);
+    const size_t end = std::min(m_currentIndex + chunk, m_nrows);
+    data.clear();
+    data.reserve(end - m_currentIndex);
+    for (size_t r = m_currentIndex; r < end; ++r) {
+        RowData row;
+        row.values = Eigen::VectorXf((Eigen::Index)m_depth);
+        for (size_t d = 0; d < m_depth; ++d)
+            row.values[(Eigen::Index)d] = m_rows[r * m_depth + d];
+        row.valid.assign(m_depth, 1);
+        data.push_back(std::move(row));
+    }
+    const size_t n = end - m_currentIndex;
+    m_currentIndex = end >= m_nrows ? 0 : end;   // wrap: the stream is back at its start
+    return n;
+}
+
+std::vector<RowData> ArrayDataLoader::getPreview(size_t count)
+{
+    std::vector<RowData> out;
+    for (size_t r = 0; r < std::min(count, m_nrows); ++r) {
+        RowData row;
+        row.values = Eigen::VectorXf((Eigen::Index)m_depth);
+        for (size_t d = 0; d < m_depth; ++d)
+            row.values[(Eigen::Index)d] = m_rows[r * m_depth + d];
+        row.valid.assign(m_depth, 1);
+        out.push_back(std::move(row));
+    }
+    return out;
+}
+
+void ArrayDataLoader::setColumnSpec(const std::vector<ColumnSpec> columnSpec) noexcept
+{
+    for (size_t i = 0; i < columnSpec.size() && i < m_depth; ++i) {
+        m_names[i] = columnSpec[i].name;
+        m_weights[i] = columnSpec[i].weight;
+        m_binary[i] = columnSpec[i].isBinary ? 1 : 0;
+        m_continuous[i] = columnSpec[i].isBinary ? 0 : 1;
+    }
+}
+
+const std::vector<ColumnSpec> ArrayDataLoader::getColumnSpec() noexcept
+{
+    std::vector<ColumnSpec> out;
+    for (size_t i = 0; i < m_depth; ++i)
+        out.emplace_back(m_names[i], m_weights[i], m_binary[i]);
+    return out;
+}
+
+const std::vector<DataSet::DataRow> DataSet::getAll() const { return allData; }
+std::vector<DataSet::DataRow> DataSet::getAll() { return allData; }
+
+std::vector<Eigen::VectorXf> DataSet::getPreviewData(size_t count) const
+{
+    std::vector<Eigen::VectorXf> out;
+    for (auto &item : _loader.getPreview(count))
+        out.emplace_back(item.values);
+    return out;
+}
+
+Eigen::VectorXf DataSet::getData(size_t i) const
+{
+    if (_loader.data.size() > i)
+        return data[i];
+    return Eigen::VectorXf::Zero((Eigen::Index)_loader.getDepth());
+}
+
+const Eigen::VectorXi DataSet::getValidity(size_t i) const
+{
+    Eigen::VectorXi v = Eigen::VectorXi::Zero((Eigen::Index)_loader.getDepth());
+    if (n > i)
+        for (size_t d = 0; d < valid[i].size(); ++d)
+            v[(Eigen::Index)d] = valid[i][d];
+    return v;
+}
+
+static Eigen::ArrayXi to_arrayxi(const std::vector<int> &src)
+{
+    Eigen::ArrayXi a((Eigen::Index)src.size());
+    for (size_t i = 0; i < src.size(); ++i)
+        a[(Eigen::Index)i] = src[i];
+    return a;
+}
+
+const Eigen::ArrayXi DataSet::getBinary() const { return to_arrayxi(_loader.getBinary()); }
+const Eigen::ArrayXi DataSet::getContinuous() const { return to_arrayxi(_loader.getContinuous()); }
+
+const Eigen::VectorXf DataSet::getWeights() const
+{
+    const auto w = _loader.getWeights();
+    Eigen::VectorXf v((Eigen::Index)w.size());
+    for (size_t i = 0; i < w.size(); ++i)
+        v[(Eigen::Index)i] = w[i];
+    return v;
+}
+
+float DataSet::getWeight(size_t i) { return _loader.getWeight(i); }
+const std::vector<std::string> DataSet::getNames() const noexcept { return _loader.getNames(); }
+std::string DataSet::getName(size_t i) const { return _loader.getName(i); }
+const std::vector<size_t> &DataSet::getLastBMU() const noexcept { return lastBMU; }
+size_t &DataSet::getLastBMU(size_t i)
+{
+    assert(n > i);
+    return lastBMU[i];
+}
+size_t DataSet::size() const { return n; }
+
+void DataSet::addVector(Eigen::VectorXf v)
+{
+    if ((size_t)v.rows() == _loader.getDepth()) {
+        data.push_back(v);
+        n += 1;
+    } else {
+        std::cout << "Added vector size does not correspond to data set depth!\n";
+    }
+}
+
+void DataSet::resetStreamLoadPosition() noexcept { loadedNumberOfChunks = 0; }
+bool DataSet::hasReadWholeDataStream() const noexcept { return loadedNumberOfChunks > 0 && _loader.isAtStartOfDataStream(); }
+
+// DataSet.cpp:118-160: reload, rebuild the row views, lastBMU := 0 (:136-137)
+void DataSet::loadNextDataFromStream()
+{
+    if (_loader.isAtStartOfDataStream())
+        loadedNumberOfChunks = 0;
+    const size_t numberOfRows = _loader.load();
+    n = numberOfRows;
+    depth = _loader.getDepth();
+    valid.clear();
+    valid.reserve(numberOfRows);
+    data.clear();
+    data.reserve(numberOfRows);
+    lastBMU.assign(numberOfRows, 0);
+    allData.clear();
+    allData.reserve(numberOfRows);
+    index.resize(numberOfRows);
+    for (size_t k = 0; k < index.size(); ++k)
+        index[k] = k;
+    shuffle();
+    m_flat.resize(numberOfRows * depth);
+    size_t cur = 0;
+    for (auto &row : _loader.data) {
+        data.push_back(row.values);
+        valid.push_back(row.valid);
+        for (size_t d = 0; d < depth; ++d)
+            m_flat[cur * depth + d] = row.values[(Eigen::Index)d];
+        allData.push_back(DataRow{&data.back(), &valid.back(), &lastBMU[cur]});
+        ++cur;
+    }
+    ++loadedNumberOfChunks;
+    if (_verbose)
+        std::cout << "Loaded " << loadedNumberOfChunks << " number of chunks\n";
+}
+
+void DataSet::display() const
+{
+    std::cout << "Number of samples: " << _loader.data.size() << "\nVector length: " << _loader.getDepth() << "\n";
+}
+size_t DataSet::vectorLength() const { return _loader.getDepth(); }
+// the reference shuffles an index vector that nothing reads (DataSet.cpp:143-146,173-176): order = load order
+void DataSet::shuffle() {}
+
+// ---------------------------------------------------------------------------------------------
+// Som
+// ---------------------------------------------------------------------------------------------
+static int g_default_device = 0;
+void Som::setDefaultDevice(int device) { g_default_device = device; }
+
+static void check(int rc, const char *what)
+{
+    if (rc != 0)
+        throw std::runtime_error(std::string(what) + ": " + vsom_last_error());
+}
+
+void Som::createContext()
+{
+    const int kind = transform.kind();
+    if (kind == vsom::Custom) {
+        ctx = nullptr;   // state-less shell: accessors work on zeros, training throws
+        return;
+    }
+    check(vsom_create(&ctx, g_default_device, (uint32_t)width, (uint32_t)height, (uint32_t)inLen, kind), "vsom_create");
+}
+
+void Som::requireDevicePath(const char *what) const
+{
+    if (!ctx)
+        throw std::runtime_error(std::string(what) +
+                                 ": this Transformation is not one of Standard / StandardMedianEstimator / "
+                                 "CombinatorialLinearRegression; custom std::function hooks cannot run on the "
+                                 "GPU and this build has no CPU fallback");
+}
+
+void Som::Construct(size_t inWidth, size_t inHeight, size_t inDepth, std::vector<std::string> names)
+{
+    width = inWidth;
+    height = inHeight;
+    depth = inDepth;
+    uMatrix.assign(inWidth * inHeight, 0.0);
+    transform.names = names;
+    createContext();   // Som.cpp:11-48: all state zero (vsom_create zero-fills)
+    hostStale = true;
+}
+
+static size_t in_len_from_depth(const Transformation &t, size_t depth)
+{
+    if (t.kind() != vsom::Clr)
+        return depth;
+    // depth = J(J-1) (Transformation.cpp:162-165); the depth constructor is used this way by
+    // tests/performance/perf_tests.cpp:338-339
+    size_t J = (size_t)std::llround((1.0 + std::sqrt(1.0 + 4.0 * (double)depth)) / 2.0);
+    if (J * (J - 1) != depth)
+        throw std::invalid_argument("depth is not J*(J-1) for any J (CombinatorialLinearRegression)");
+    return J;
+}
+
+Som::Som(size_t w, size_t h, DataSet dataset, Transformation transformation) : transform{transformation}, _isTraining{false}
+{
+    inLen = dataset.vectorLength();
+    // the reference passes the *input* length as depth here (SOM.hpp:81); the model length follows
+    // from the transformation
+    Construct(w, h, transform.Length(inLen), dataset.getNames());
+}
+
+Som::Som(size_t w, size_t h, size_t d, Transformation transformation) : transform{transformation}, _isTraining{false}
+{
+    inLen = in_len_from_depth(transform, d);
+    Construct(w, h, d, std::vector<std::string>{});
+}
+
+Som::Som(const char *filename) : _isTraining{false}
+{
+    width = height = depth = 0;
+    load(filename);
+}
+
+Som::Som(const Som &som)
+    : transform{som.transform}, metrics{}, uMatrix{som.uMatrix}, _isTraining{false}, height{som.height},
+      width{som.width}, depth{som.depth}, inLen{som.inLen}
+{
+    createContext();
+    if (ctx && som.ctx) {
+        const size_t N = width * height;
+        std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
+        std::vector<uint64_t> hh(N);
+        som.getState(m.data(), s.data(), S.data(), w.data(), hh.data());
+        setState(m.data(), s.data(), S.data(), w.data(), hh.data());
+    }
+    _isTraining.store(som._isTraining.load());
+}
+
+Som &Som::operator=(const Som &other)
+{
+    if (this == &other)
+        return *this;
+    if (ctx)
+        vsom_destroy(ctx);
+    ctx = nullptr;
+    transform = other.transform;
+    uMatrix = other.uMatrix;
+    height = other.height;
+    width = other.width;
+    depth = other.depth;
+    inLen = other.inLen;
+    createContext();
+    if (ctx && other.ctx) {
+        const size_t N = width * height;
+        std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
+        std::vector<uint64_t> hh(N);
+        other.getState(m.data(), s.data(), S.data(), w.data(), hh.data());
+        setState(m.data(), s.data(), S.data(), w.data(), hh.data());
+    }
+    _isTraining.store(other._isTraining.load());
+    hostStale = true;
+    return *this;
+}
+
+Som::~Som()
+{
+    if (ctx)
+        vsom_destroy(ctx);
+}
+
+void Som::setState(const float *map, const float *sigma, const float *S, const float *weight, const uint64_t *hits)
+{
+    requireDevicePath("setState");
+    check(vsom_set_state(ctx, map, sigma, S, weight, hits), "vsom_set_state");
+    hostStale = true;
+}
+
+void Som::getState(float *map, float *sigma, float *S, float *weight, uint64_t *hits) const
+{
+    requireDevicePath("getState");
+    check(vsom_get_state(ctx, map, sigma, S, weight, hits), "vsom_get_state");
+}
+
+void Som::refreshHost() const
+{
+    if (!hostStale)
+        return;
+    const size_t N = width * height;
+    hMap.assign(N * depth, 0.f);
+    hSigma.assign(N * depth, 0.f);
+    hWeight.assign(N, 0.f);
+    hHits.assign(N, 0);
+    if (ctx)
+        check(vsom_get_state(ctx, hMap.data(), hSigma.data(), nullptr, hWeight.data(), hHits.data()), "vsom_get_state");
+    hostStale = false;
+}
+
+// ---- accessors ---------------------------------------------------------------------------------
+UMatrix Som::getUMatrix() const noexcept { return UMatrix{uMatrix, width, height}; }
+size_t Som::getHeight() const noexcept { return height; }
+size_t Som::getWidth() const noexcept { return width; }
+size_t Som::getDepth() const noexcept { return depth; }
+size_t Som::getIndex(SomIndex i) const noexcept { return i.getY() * width + i.getX(); }
+
+static Eigen::VectorXf row_of(const std::vector<float> &a, size_t row, size_t depth)
+{
+    Eigen::VectorXf v((Eigen::Index)depth);
+    for (size_t d = 0; d < depth; ++d)
+        v[(Eigen::Index)d] = a[row * depth + d];
+    return v;
+}
+
+Eigen::VectorXf Som::getWeigthMap() const noexcept
+{
+    refreshHost();
+    Eigen::VectorXf v((Eigen::Index)hWeight.size());
+    for (size_t i = 0; i < hWeight.size(); ++i)
+        v[(Eigen::Index)i] = hWeight[i];
+    return v;
+}
+
+std::vector<size_t> Som::getBmuHits() const noexcept
+{
+    refreshHost();
+    return std::vector<size_t>(hHits.begin(), hHits.end());
+}
+
+Eigen::VectorXf Som::getNeuron(SomIndex i) const noexcept { return getNeuron(getIndex(i)); }
+Eigen::VectorXf Som::getNeuron(size_t i) const noexcept
+{
+    refreshHost();
+    return row_of(hMap, i, depth);
+}
+Eigen::VectorXf Som::getSigmaNeuron(SomIndex i) const noexcept { return getSigmaNeuron(getIndex(i)); }
+Eigen::VectorXf Som::getSigmaNeuron(size_t i) const noexcept
+{
+    refreshHost();
+    return row_of(hSigma, i, depth);
+}
+std::vector<std::string> Som::getNeuronStrings(SomIndex index) const noexcept { return transform.Displayer(getNeuron(index)); }
+std::vector<std::string> Som::getSigmaNeuronStrings(SomIndex index) const noexcept { return transform.Displayer(getSigmaNeuron(index)); }
+
+static float extreme(const std::vector<float> &a, size_t depth, size_t col, bool want_max)
+{
+    assert(col < depth);
+    float best = a[col];
+    for (size_t r = 0; r * depth < a.size(); ++r) {
+        float v = a[r * depth + col];
+        if (want_max ? best < v : v < best)
+            best = v;
+    }
+    return best;
+}
+
+float Som::getMaxValueOfFeature(size_t c) const { refreshHost(); return extreme(hMap, depth, c, true); }
+float Som::getMinValueOfFeature(size_t c) const { refreshHost(); return extreme(hMap, depth, c, false); }
+float Som::getMaxSigmaOfFeature(size_t c) const { refreshHost(); return extreme(hSigma, depth, c, true); }
+float Som::getMinSigmaOfFeature(size_t c) const { refreshHost(); return extreme(hSigma, depth, c, false); }
+Som::Metrics Som::getMetrics() const noexcept { return metrics; }
+bool Som::isTraining() const noexcept { return _isTraining; }
+bool Som::isCompatibleWithData(DataSet &data) const noexcept { return transform.Length(data.vectorLength()) == depth; }
+
+void Som::display() const
+{
+    refreshHost();
+    std::cout << "Map size: " << width * height << "\nMap width: " << width << "\nMap height: " << height
+              << "\nM size: " << depth << "\n\n";
+    for (size_t i = 0; i < height; ++i) {
+        for (size_t j = 0; j < width; ++j)
+            std::cout << hHits[i * width + j] << "\t";
+        std::cout << "\n";
+    }
+}
+
+void Som::displayUMatrix() const
+{
+    std::cout << "\nU-matrix:\n[";
+    for (size_t i = 0; i < height; i++) {
+        for (size_t j = 0; j < width; j++)
+            std::cout << uMatrix[i * width + j] << " ";
+        std::cout << "; ";
+    }
+    std::cout << "]\n";
+}
+
+// Som.cpp:977-997: glibc srand/rand, node-major, dim-minor; everything else zero
+void Som::randomInitialize(int seed, float sigma)
+{
+    requireDevicePath("randomInitialize");
+    std::srand((unsigned)seed);
+    metrics = Metrics{depth};
+    const size_t N = width * height;
+    std::vector<float> m(N * depth), z(N * depth, 0.f), w(N, 0.f);
+    std::vector<uint64_t> hh(N, 0);
+    for (size_t i = 0; i < N; ++i)
+        for (size_t d = 0; d < depth; ++d)
+            m[i * depth + d] = (static_cast<float>(std::rand() % static_cast<int>((2000 * sigma))) - (1000.f * sigma)) / 1000.f;
+    std::fill(uMatrix.begin(), uMatrix.end(), 0.0);
+    setState(m.data(), z.data(), z.data(), w.data(), hh.data());
+}
+
+void Som::addBmu(SomIndex pos)   // Som.cpp:1189-1192
+{
+    requireDevicePath("addBmu");
+    const size_t N = width * height;
+    std::vector<uint64_t> hh(N);
+    check(vsom_get_state(ctx, nullptr, nullptr, nullptr, nullptr, hh.data()), "vsom_get_state");
+    hh[getIndex(pos)] += 1;
+    check(vsom_set_state(ctx, nullptr, nullptr, nullptr, nullptr, hh.data()), "vsom_set_state");
+    hostStale = true;
+}
+
+double Som::calculateNeighbourhoodWeight(const size_t &currentX, const size_t &currentY, const size_t &bmuX,
+                                         const size_t &bmuY, const double &currentSigma)
+{
+    return vsom_neighbourhood_weight(currentX, currentY, bmuX, bmuY, currentSigma);
+}
+
+// ---- search ------------------------------------------------------------------------------------
+void Som::stageOne(const Eigen::VectorXf &v) const
+{
+    requireDevicePath("search");
+    if ((size_t)v.size() != inLen)
+        throw std::invalid_argument("sample length does not match the map");
+    check(vsom_upload_chunk(ctx, v.data(), 1), "vsom_upload_chunk");
+}
+
+SomIndex Som::findBmu(const Eigen::VectorXf &v) const
+{
+    Eigen::VectorXf ones = Eigen::VectorXf::Ones(v.size());
+    return findBmu(v, ones, ones);
+}
+
+SomIndex Som::findBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &, const Eigen::VectorXf &) const
+{
+    stageOne(v);
+    uint64_t idx = 0;
+    check(vsom_bmu_batch(ctx, &idx, nullptr), "vsom_bmu_batch");
+    return SomIndex((size_t)idx % width, (size_t)idx / width);   // Som.cpp:306
+}
+
+SomIndex Som::findLocalBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &, const size_t &lastBMUref,
+                           const Eigen::VectorXf &) const
+{
+    stageOne(v);
+    uint64_t idx = lastBMUref;
+    check(vsom_set_last_bmu(ctx, &idx), "vsom_set_last_bmu");
+    check(vsom_bmu_local_batch(ctx, &idx, nullptr), "vsom_bmu_local_batch");
+    return SomIndex((size_t)idx % width, (size_t)idx / width);
+}
+
+double Som::euclidianWeightedDist(const SomIndex &pos, const Eigen::VectorXf &v, const Eigen::VectorXf &valid,
+                                  const Eigen::VectorXf &weights) const
+{
+    return euclidianWeightedDist(pos.getY() * width + pos.getX(), v, valid, weights);
+}
+
+double Som::euclidianWeightedDist(const size_t &pos, const Eigen::VectorXf &v, const Eigen::VectorXf &,
+                                  const Eigen::VectorXf &) const
+{
+    stageOne(v);
+    uint64_t node = pos, row = 0;
+    float d = 0.f;
+    check(vsom_distances(ctx, &node, &row, 1, &d), "vsom_distances");
+    return (double)d;
+}
+
+// ---- batch training ----------------------------------------------------------------------------
+float Som::trainBatchSomEpoch(DataSet &dataset, double currentSigma, bool isFirst)
+{
+    requireDevicePath("trainBatchSomEpoch");
+    const size_t B = dataset.size();
+    if (B == 0)
+        return 0.f;
+    check(vsom_upload_chunk(ctx, dataset.contiguous().data(), B), "vsom_upload_chunk");
+    std::vector<uint64_t> lb(B);
+    if (!isFirst) {
+        for (size_t s = 0; s < B; ++s)
+            lb[s] = dataset.getLastBMU(s);
+        check(vsom_set_last_bmu(ctx, lb.data()), "vsom_set_last_bmu");
+    }
+    float mse = 0.f;
+    check(vsom_batch_epoch(ctx, currentSigma, isFirst ? 1 : 0, &mse), "vsom_batch_epoch");
+    check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
+    for (size_t s = 0; s < B; ++s)
+        dataset.getLastBMU(s) = (size_t)lb[s];   // *data.lastBMU = index (Som.cpp:777,800)
+    hostStale = true;
+    return mse;
+}
+
+void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, double sigmaDecay, bool)
+{
+    requireDevicePath("trainBatchSom");
+    metrics = Som::Metrics(numberOfEpochs);   // Som.cpp:719
+    for (size_t i = 0; i < numberOfEpochs; ++i) {
+        std::cout << "Training VSOM epoch " << i << "/" << numberOfEpochs << '\n';
+        auto sigma = sigma0 * std::exp(-sigmaDecay * static_cast<double>(i));   // :727
+        if (sigma < 1.0)
+            return;   // :729-730
+        auto meanSquareError = float{0.0f};
+        auto countDataChunks = size_t{0};
+        while (!data.hasReadWholeDataStream()) {   // :735
+            data.loadNextDataFromStream();
+            meanSquareError += trainBatchSomEpoch(data, sigma, i == 0);
+            ++countDataChunks;
+        }
+        meanSquareError /= static_cast<float>(countDataChunks);   // :743
+        {
+            const std::lock_guard<std::mutex> lock(metricsMutex);
+            metrics.MeanSquaredError[i] = meanSquareError;
+        }
+        data.resetStreamLoadPosition();
+    }
+}
+
+// ---- online training ---------------------------------------------------------------------------
+static int decay_code(Som::WeigthDecayFunction f)
+{
+    return f == Som::WeigthDecayFunction::Exponential ? VSOM_EXPONENTIAL
+           : f == Som::WeigthDecayFunction::InverseProportional ? VSOM_INVERSE_PROPORTIONAL : VSOM_BATCHMAP;
+}
+
+Som::TrainingReturnValue Som::trainSingle(const Eigen::VectorXf &v, const Eigen::VectorXf &, const Eigen::VectorXf &,
+                                          const double eta, const double sigma, size_t &lastBMU,
+                                          const WeigthDecayFunction weightDecayFunction)
+{
+    requireDevicePath("trainSingle");
+    if ((size_t)v.size() != inLen)
+        throw std::invalid_argument("sample length does not match the map");
+    Eigen::VectorXf residual((Eigen::Index)vsom_residual_len(ctx));
+    uint64_t lb = lastBMU, bmu = 0;
+    float dist = 0.f;
+    check(vsom_train_single(ctx, v.data(), eta, sigma, &lb, decay_code(weightDecayFunction), residual.data(), &dist, &bmu),
+          "vsom_train_single");
+    lastBMU = (size_t)lb;
+    hostStale = true;
+    return TrainingReturnValue{SomIndex((size_t)bmu % width, (size_t)bmu / width), residual, dist};
+}
+
+void Som::trainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, double etaDecay, double sigma0,
+                        double sigmaDecay, WeigthDecayFunction weightDecayFunction, bool)
+{
+    requireDevicePath("trainBasicSom");
+    metrics = Som::Metrics(numberOfEpochs);   // Som.cpp:1139
+    for (size_t i = 0; i < numberOfEpochs; ++i) {
+        auto eta = eta0 * std::exp(-etaDecay * static_cast<double>(i));         // :1145
+        auto sigma = sigma0 * std::exp(-sigmaDecay * static_cast<double>(i));   // :1146
+        if (sigma < 1.0)
+            sigma = 1.0;   // :1148-1149
+        std::cout << "Epoch: " << i + 1 << "/" << numberOfEpochs << "\teta: " << eta << "\tsigma: " << sigma << "\n";
+        float meanSquareError{0.0};
+        size_t countDataChunks{0};
+        while (!data.hasReadWholeDataStream()) {
+            data.loadNextDataFromStream();
+            const size_t B = data.size();
+            if (B > 0) {
+                // the chunk's B sequential trainSingle + addBmu + MSE run on the device (:1161-1171)
+                check(vsom_upload_chunk(ctx, data.contiguous().data(), B), "vsom_upload_chunk");
+                float mse = 0.f;
+                check(vsom_train_online_chunk(ctx, eta, sigma, decay_code(weightDecayFunction), &mse),
+                      "vsom_train_online_chunk");
+                std::vector<uint64_t> lb(B);
+                check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
+                for (size_t s = 0; s < B; ++s)
+                    data.getLastBMU(s) = (size_t)lb[s];
+                meanSquareError += mse;
+            }
+            ++countDataChunks;
+        }
+        meanSquareError /= static_cast<float>(countDataChunks);   // :1175
+        {
+            const std::lock_guard<std::mutex> lock(metricsMutex);
+            metrics.MeanSquaredError[i] = meanSquareError;
+        }
+        data.resetStreamLoadPosition();
+        hostStale = true;
+    }
+    std::cout << "\rTraining SOM:100%\n";
+}
+
+// Som.cpp:1113-1132: dispatch; exceptions are printed, not propagated
+void Som::train(DataSet &data, size_t numberOfEpochs, double eta0, double etaDecay, double sigma0, double sigmaDecay,
+                WeigthDecayFunction weightDecayFunction, bool updateUMatrixAfterEpoch)
+{
+    _isTraining = true;
+    try {
+        switch (weightDecayFunction) {
+        case WeigthDecayFunction::BatchMap:
+            trainBatchSom(data, numberOfEpochs, sigma0, sigmaDecay, updateUMatrixAfterEpoch);
+            break;
+        default:
+            trainBasicSom(data, numberOfEpochs, eta0, etaDecay, sigma0, sigmaDecay, weightDecayFunction, updateUMatrixAfterEpoch);
+        }
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << '\n';
+    }
+    _isTraining = false;
+}
+
+// ---- members outside the hot path ----------------------------------------------------------------
+#define VSOM_NOT_IN_SCOPE(name) throw std::logic_error(name ": outside the MI355X hot-path build (SURVEY.md 8f)")
+double Som::evaluate(const DataSet &) const { VSOM_NOT_IN_SCOPE("Som::evaluate"); }
+int Som::measureSimilarity(const DataSet *, int, size_t) const { VSOM_NOT_IN_SCOPE("Som::measureSimilarity"); }
+int Som::autoEncoder(const DataSet *, size_t) const { VSOM_NOT_IN_SCOPE("Som::autoEncoder"); }
+size_t Som::variationalAutoEncoder(const DataSet *, size_t) const { VSOM_NOT_IN_SCOPE("Som::variationalAutoEncoder"); }
+SomIndex Som::findRestrictedBmu(const Eigen::VectorXf &, const Eigen::VectorXf &, const size_t, const Eigen::VectorXf &) const
+{
+    VSOM_NOT_IN_SCOPE("Som::findRestrictedBmu");
+}
+std::vector<double> Som::findRestrictedBmd(const Eigen::VectorXf &, const Eigen::VectorXf &, size_t, const Eigen::VectorXf &) const
+{
+    VSOM_NOT_IN_SCOPE("Som::findRestrictedBmd");
+}
+double Som::euclidianWeightedDistRaw(const size_t &, const Eigen::VectorXf &, const Eigen::VectorXf &, const Eigen::VectorXf &) const
+{
+    VSOM_NOT_IN_SCOPE("Som::euclidianWeightedDistRaw");
+}
+void Som::updateUMatrix(const Eigen::VectorXf &) { VSOM_NOT_IN_SCOPE("Som::updateUMatrix"); }
+
+// ---- checkpoint: lossless little-endian binary of this build (the reference's Octave text format,
+//      Som.cpp:1209-1597, is a "next" row) --------------------------------------------------------------
+void Som::save(const char *fileName) const
+{
+    requireDevicePath("save");
+    const size_t N = width * height;
+    std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
+    std::vector<uint64_t> hh(N);
+    getState(m.data(), s.data(), S.data(), w.data(), hh.data());
+    std::ofstream f(fileName, std::ios::binary);
+    if (!f) {
+        std::cout << "Could not open file " << fileName << " for writing. Quitting...\n";
+        std::exit(EXIT_FAILURE);   // Som.cpp:1213-1217
+    }
+    const uint64_t hdr[6] = {0x314d4f5356ull /* "VSOM1" */, width, height, depth, inLen, (uint64_t)transform.kind()};
+    f.write((const char *)hdr, sizeof(hdr));
+    f.write((const char *)m.data(), m.size() * 4);
+    f.write((const char *)s.data(), s.size() * 4);
+    f.write((const char *)S.data(), S.size() * 4);
+    f.write((const char *)w.data(), w.size() * 4);
+    f.write((const char *)hh.data(), hh.size() * 8);
+}
+
+void Som::load(const char *fileName)
+{
+    std::ifstream f(fileName, std::ios::binary);
+    if (!f) {
+        std::cout << "Could not open file " << fileName << " for reading. Quitting...\n";
+        std::exit(EXIT_FAILURE);
+    }
+    uint64_t hdr[6];
+    f.read((char *)hdr, sizeof(hdr));
+    if (!f || hdr[0] != 0x314d4f5356ull)
+        throw std::runtime_error("not a VSOM1 checkpoint");
+    if (ctx)
+        vsom_destroy(ctx);
+    ctx = nullptr;
+    width = hdr[1];
+    height = hdr[2];
+    depth = hdr[3];
+    inLen = hdr[4];
+    transform = hdr[5] == vsom::Median ? Transformation::StandardMedianEstimator({})
+                : hdr[5] == vsom::Clr  ? Transformation::CombinatorialLinearRegression({})
+                                       : Transformation::Standard({});
+    uMatrix.assign(width * height, 0.0);
+    createContext();
+    const size_t N = width * height;
+    std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
+    std::vector<uint64_t> hh(N);
+    f.read((char *)m.data(), m.size() * 4);
+    f.read((char *)s.data(), s.size() * 4);
+    f.read((char *)S.data(), S.size() * 4);
+    f.read((char *)w.data(), w.size() * 4);
+    f.read((char *)hh.data(), hh.size() * 8);
+    if (!f)
+        throw std::runtime_error("truncated VSOM1 checkpoint");
+    setState(m.data(), s.data(), S.data(), w.data(), hh.data());
+}

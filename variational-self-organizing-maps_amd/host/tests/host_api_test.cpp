@@ -1,0 +1,125 @@
+// host_api_test.cpp -- exercises the C++ mirror (vsom_api.hpp) the way the reference's perf harness
+// drives libsom (tests/performance/perf_tests.cpp:74-140): construct, randomInitialize, train with
+// each WeigthDecayFunction, findBmu / findLocalBmu / euclidianWeightedDist / trainSingle.
+// Writes the resulting state to binary dumps that tests/test_gpu_host_cpp.py compares with the oracle.
+//   usage: host_api_test <outdir>
+#include "SOM.hpp"
+#include "DataSet.hpp"
+#include "Transformation.hpp"
+
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+static void dump(const std::string &path, const Som &som, const std::vector<float> &mse)
+{
+    const size_t N = som.getWidth() * som.getHeight(), D = som.getDepth();
+    std::vector<float> m(N * D), s(N * D), S(N * D), w(N);
+    std::vector<uint64_t> h(N);
+    som.getState(m.data(), s.data(), S.data(), w.data(), h.data());
+    std::ofstream f(path, std::ios::binary);
+    uint64_t hdr[3] = {N, D, mse.size()};
+    f.write((const char *)hdr, sizeof(hdr));
+    f.write((const char *)m.data(), m.size() * 4);
+    f.write((const char *)s.data(), s.size() * 4);
+    f.write((const char *)S.data(), S.size() * 4);
+    f.write((const char *)w.data(), w.size() * 4);
+    f.write((const char *)h.data(), h.size() * 8);
+    f.write((const char *)mse.data(), mse.size() * 4);
+}
+
+// deterministic samples (same formula in the python test)
+static std::vector<float> make_rows(size_t n, size_t d, unsigned seed)
+{
+    std::vector<float> r(n * d);
+    unsigned s = seed;
+    for (auto &v : r) {
+        s = s * 1664525u + 1013904223u;
+        v = (float)((s >> 8) & 0xFFFF) / 65536.0f * 2.0f - 1.0f;
+    }
+    return r;
+}
+
+int main(int argc, char **argv)
+{
+    const std::string out = argc > 1 ? argv[1] : ".";
+    const size_t W = 10, H = 10, J = 9, NROWS = 50, CHUNK = 20;
+    auto rows = make_rows(NROWS, J, 12345u);
+
+    // ---- batch map, standard transformation, two-and-a-half chunks per epoch ----
+    {
+        ArrayDataLoader loader(rows.data(), NROWS, J, CHUNK);
+        DataSet ds(loader);
+        Som som{W, H, ds, Transformation::Standard(loader.getNames())};
+        som.randomInitialize(42, 1);
+        som.train(ds, 5, 0.001, 0.01, 10.0, 0.3, Som::WeigthDecayFunction::BatchMap);
+        auto met = som.getMetrics();
+        dump(out + "/batch_std.bin", som, met.MeanSquaredError);
+        std::cout << "batch_std hits0=" << som.getBmuHits()[0] << " neuron0[0]=" << som.getNeuron(size_t{0})[0] << "\n";
+    }
+    // ---- online, exponential decay, median estimator ----
+    {
+        ArrayDataLoader loader(rows.data(), NROWS, J, CHUNK);
+        DataSet ds(loader);
+        Som som{W, H, J, Transformation::StandardMedianEstimator({})};
+        som.randomInitialize(7, 1);
+        som.train(ds, 3, 0.05, 0.1, 3.0, 0.5, Som::WeigthDecayFunction::Exponential);
+        dump(out + "/online_median.bin", som, som.getMetrics().MeanSquaredError);
+    }
+    // ---- online, inverse proportional, CLR through the depth constructor (perf_tests.cpp:338-339) ----
+    {
+        const size_t Jc = 5;
+        auto crows = make_rows(30, Jc, 777u);
+        ArrayDataLoader loader(crows.data(), 30, Jc);
+        DataSet ds(loader);
+        auto t = Transformation::CombinatorialLinearRegression({});
+        Som som{6, 6, t.Length(Jc), t};
+        som.randomInitialize(3, 1);
+        som.train(ds, 2, 0.01, 0.0, 2.0, 0.2, Som::WeigthDecayFunction::InverseProportional);
+        dump(out + "/online_clr.bin", som, som.getMetrics().MeanSquaredError);
+    }
+    // ---- searches and trainSingle ----
+    {
+        Som som{W, H, J};
+        som.randomInitialize(11, 1);
+        Eigen::VectorXf v(J), ones = Eigen::VectorXf::Ones(J);
+        for (size_t d = 0; d < J; ++d)
+            v[d] = rows[d];
+        SomIndex b = som.findBmu(v);
+        SomIndex l = som.findLocalBmu(v, ones, 37, ones);
+        double dist = som.euclidianWeightedDist(b, v, ones, ones);
+        size_t last = 5;
+        auto [pos, residual, derr] = som.trainSingle(v, ones, ones, 0.1, 2.0, last, Som::WeigthDecayFunction::Exponential);
+        std::ofstream f(out + "/search.txt");
+        f << som.getIndex(b) << " " << som.getIndex(l) << " " << std::hexfloat << dist << " " << som.getIndex(pos) << " "
+          << last << " " << std::hexfloat << (double)derr << " " << (double)residual[0] << "\n";
+        dump(out + "/single.bin", som, {});
+        // a copy carries the state (copy constructor, SOM.hpp:90-105)
+        Som copy{som};
+        dump(out + "/single_copy.bin", copy, {});
+        som.save((out + "/ckpt.vsom").c_str());
+        Som loaded{(out + "/ckpt.vsom").c_str()};
+        dump(out + "/single_loaded.bin", loaded, {});
+    }
+    // ---- a custom std::function transformation cannot run on the device: train() reports, no fallback ----
+    {
+        Transformation custom{.Comparer = [](const Eigen::VectorXf &, const Eigen::VectorXf &m, const Eigen::VectorXf &,
+                                             const Eigen::VectorXf &) { return m; }};
+        ArrayDataLoader loader(rows.data(), NROWS, J, CHUNK);
+        DataSet ds(loader);
+        Som som{W, H, ds, custom};
+        som.train(ds, 1, 0.1, 0.1, 3.0, 0.1, Som::WeigthDecayFunction::BatchMap);   // prints the error
+        bool threw = false;
+        try {
+            ds.loadNextDataFromStream();
+            som.trainBatchSomEpoch(ds, 3.0, true);
+        } catch (const std::exception &e) {
+            threw = true;
+        }
+        std::cout << "custom_transformation_rejected=" << (threw ? 1 : 0) << " kind=" << custom.kind() << "\n";
+    }
+    std::cout << "host_api_test done\n";
+    return 0;
+}
