@@ -415,8 +415,10 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     size_t sz = sizeof(a);
                     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
                                      HIP_LAUNCH_PARAM_END};
+                    // XCD-aware grid: x = 8 * slice quads, y = node groups / 8 (see gen_update_asm.py)
                     VSOM_HIP_CHECK(hipModuleLaunchKernel(rd == 14 ? (hipFunction_t)c->upd_fn14 : (hipFunction_t)c->upd_fn16,
-                                                         gx, (nfull + 3) / 4, 1, 256, 1, 1, 0, c->stream, nullptr, extra));
+                                                         8 * ((nfull + 3) / 4), (gx + 7) / 8, 1, 256, 1, 1, 0, c->stream,
+                                                         nullptr, extra));
                     dbase = (int)(nfull * rd);
                     sig_cols = dbase;
                 }
