@@ -65,9 +65,9 @@ __global__ void online_resolve_kernel(u64 *state)
 
 // single-sample Som::findLocalBmu (same walk as bmu_local_kernel in vsom_bmu.hip)
 template <bool CLR>
-__global__ __launch_bounds__(64) void online_local_kernel(OnlineArgs a, const u64 *__restrict__ lastbmu)
+__device__ __forceinline__ u64 online_local_search(const OnlineArgs &a, const u64 *lastbmu, int lane)
 {
-    const int lane = threadIdx.x & 63, g = lane >> 3, k = lane & 7;
+    const int g = lane >> 3, k = lane & 7;
     const u64 width = (u64)a.W, height = (u64)a.H;
     const u64 m1 = ~0ull;
     const u64 fsx = (g == 0 || g >= 6) ? m1 : ((g == 1 || g == 5) ? 0ull : 1ull);
@@ -127,6 +127,14 @@ __global__ __launch_bounds__(64) void online_local_kernel(OnlineArgs a, const u6
             lastMeasured = minIndex;
         }
     }
+    return minIndex;   // identical in every lane
+}
+
+template <bool CLR>
+__global__ __launch_bounds__(64) void online_local_kernel(OnlineArgs a, const u64 *__restrict__ lastbmu)
+{
+    const int lane = threadIdx.x & 63;
+    const u64 minIndex = online_local_search<CLR>(a, lastbmu, lane);
     if (lane == 0)
         a.state[2] = minIndex;
 }
@@ -136,28 +144,15 @@ __device__ __forceinline__ float onl_sign(float a)
     return a > 0.f ? 1.f : (a < 0.f ? -1.f : (a != a ? a : 0.f));
 }
 
-// one workgroup per node of the (maximal) window; nodes outside the actual window exit
-template <int KIND>
-__global__ __launch_bounds__(256) void online_window_kernel(
-    const float *__restrict__ xs, const float *__restrict__ xp, const float *__restrict__ yp,
-    const u64 *__restrict__ state, const double *__restrict__ lutd, int lutw, int W, int H, int D,
-    int P, int ppitch, int pitch, double eta, double sigma, int decay_fn, float *__restrict__ map,
-    float *__restrict__ Smap, float *__restrict__ sigmap, float *__restrict__ weight)
+// update of ONE window node (Som.cpp:911-943) by the `nthr` threads tid = 0..nthr-1 of a group
+// (a workgroup with BLOCK_SYNC, or a single wavefront running in lockstep without)
+template <int KIND, bool BLOCK_SYNC>
+__device__ __forceinline__ void online_node_update(size_t n, double h, int tid, int nthr,
+                                                   const float *__restrict__ xs, const float *__restrict__ xp,
+                                                   const float *__restrict__ yp, int D, int P, int ppitch, int pitch,
+                                                   double eta, int decay_fn, float *map, float *Smap, float *sigmap,
+                                                   float *weight)
 {
-    const u64 bmu = state[2];
-    const int bx = (int)(bmu % (u64)W), by = (int)(bmu / (u64)W);   // bmu.getX()/getY() (:306)
-    // :899-903  truncating window
-    const double sxd = fmax((double)bx - 2.5 * sigma, 0.), syd = fmax((double)by - 2.5 * sigma, 0.);
-    const double exd = fmin((double)bx + 2.5 * sigma, (double)W), eyd = fmin((double)by + 2.5 * sigma, (double)H);
-    const u64 startX = (u64)sxd, startY = (u64)syd, endX = (u64)exd, endY = (u64)eyd;
-    const u64 i = startX + blockIdx.x, j = startY + blockIdx.y;
-    if (i >= endX || j >= endY)
-        return;
-    const size_t n = (size_t)(j * (u64)W + i);
-    int dx = (int)i - bx, dy = (int)j - by;
-    dx = dx < 0 ? -dx : dx;
-    dy = dy < 0 ? -dy : dy;
-    const double h = lutd[(size_t)dy * lutw + dx];   // calculateNeighbourhoodWeight(i,j,bx,by,sigma) :915
     const float wold = weight[n];
     float wnew, scM;
     if (decay_fn == VSOM_EXPONENTIAL) {
@@ -170,13 +165,14 @@ __global__ __launch_bounds__(256) void online_window_kernel(
     }
     const double tw2 = wnew == 0 ? 0.000001 : (double)wnew;   // :939
     const float twf = (float)tw2, hf = (float)h;
-    __syncthreads();   // every thread has read weight[n]
-    if (threadIdx.x == 0)
+    if (BLOCK_SYNC)
+        __syncthreads();   // every thread has read weight[n]
+    if (tid == 0)
         weight[n] = wnew;
 
     float *M = map + n * pitch, *S = Smap + n * pitch, *sg = sigmap + n * pitch;
     if (KIND == VSOM_CLR) {
-        for (int p = threadIdx.x; p < P; p += blockDim.x) {
+        for (int p = tid; p < P; p += nthr) {
             const float x1 = xp[p], y1 = yp[p];
             float A = M[p], Bv = M[ppitch + p];
             float inner = A * x1;
@@ -203,7 +199,7 @@ __global__ __launch_bounds__(256) void online_window_kernel(
             sg[ppitch + p] = sqrtf(fabsf(SB / twf));
         }
     } else {
-        for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        for (int d = tid; d < D; d += nthr) {
             const float x = xs[d];
             float m = M[d];
             float dl = x - m;                                // Stepper :912
@@ -224,15 +220,49 @@ __global__ __launch_bounds__(256) void online_window_kernel(
     }
 }
 
+// window bounds of Som.cpp:899-903 (truncating, asymmetric, Q6)
+__device__ __forceinline__ void online_window(u64 bmu, int W, int H, double sigma, int &bx, int &by,
+                                              u64 &startX, u64 &startY, u64 &endX, u64 &endY)
+{
+    bx = (int)(bmu % (u64)W);
+    by = (int)(bmu / (u64)W);   // bmu.getX()/getY() (:306)
+    const double sxd = fmax((double)bx - 2.5 * sigma, 0.), syd = fmax((double)by - 2.5 * sigma, 0.);
+    const double exd = fmin((double)bx + 2.5 * sigma, (double)W), eyd = fmin((double)by + 2.5 * sigma, (double)H);
+    startX = (u64)sxd;
+    startY = (u64)syd;
+    endX = (u64)exd;
+    endY = (u64)eyd;
+}
+
+// one workgroup per node of the (maximal) window; nodes outside the actual window exit
+template <int KIND>
+__global__ __launch_bounds__(256) void online_window_kernel(
+    const float *__restrict__ xs, const float *__restrict__ xp, const float *__restrict__ yp,
+    const u64 *__restrict__ state, const double *__restrict__ lutd, int lutw, int W, int H, int D,
+    int P, int ppitch, int pitch, double eta, double sigma, int decay_fn, float *__restrict__ map,
+    float *__restrict__ Smap, float *__restrict__ sigmap, float *__restrict__ weight)
+{
+    int bx, by;
+    u64 startX, startY, endX, endY;
+    online_window(state[2], W, H, sigma, bx, by, startX, startY, endX, endY);
+    const u64 i = startX + blockIdx.x, j = startY + blockIdx.y;
+    if (i >= endX || j >= endY)
+        return;
+    const size_t n = (size_t)(j * (u64)W + i);
+    int dx = (int)i - bx, dy = (int)j - by;
+    dx = dx < 0 ? -dx : dx;
+    dy = dy < 0 ? -dy : dy;
+    const double h = lutd[(size_t)dy * lutw + dx];   // calculateNeighbourhoodWeight(i,j,bx,by,sigma) :915
+    online_node_update<KIND, true>(n, h, threadIdx.x, blockDim.x, xs, xp, yp, D, P, ppitch, pitch, eta, decay_fn,
+                                   map, Smap, sigmap, weight);
+}
+
 // residual / distance of the BMU after the update (:946), addBmu, MSE, lastBMU
 template <bool CLR>
-__global__ __launch_bounds__(64) void online_post_kernel(OnlineArgs a, u64 *__restrict__ hits,
-                                                         u64 *__restrict__ lastbmu_out,
-                                                         float *__restrict__ residual, float fB,
-                                                         int add_hit)
+__device__ __forceinline__ void online_post(const OnlineArgs &a, u64 bmu, int lane, u64 *hits, u64 *lastbmu_out,
+                                            float *residual, float fB, int add_hit)
 {
-    const int lane = threadIdx.x & 63, k = lane & 7;
-    const u64 bmu = a.state[2];
+    const int k = lane & 7;
     const float *ma = a.d.ma + (size_t)bmu * a.d.ldm, *mb = a.d.mb + (size_t)bmu * a.d.ldm;
     if (residual) {
         for (int d = lane; d < a.d.L; d += 64)
@@ -251,11 +281,59 @@ __global__ __launch_bounds__(64) void online_post_kernel(OnlineArgs a, u64 *__re
     }
 }
 
+template <bool CLR>
+__global__ __launch_bounds__(64) void online_post_kernel(OnlineArgs a, u64 *__restrict__ hits,
+                                                         u64 *__restrict__ lastbmu_out,
+                                                         float *__restrict__ residual, float fB,
+                                                         int add_hit)
+{
+    online_post<CLR>(a, a.state[2], threadIdx.x & 63, hits, lastbmu_out, residual, fB, add_hit);
+}
+
+// sigma <= 1 (Som.cpp:891: findLocalBmu, indicator neighbourhood, window of at most 6x6 nodes):
+// the whole trainSingle step in ONE small launch -- wave 0 walks the local search, each wave then
+// updates window nodes round-robin, wave 0 finishes with the residual / bookkeeping.
+template <int KIND>
+__global__ __launch_bounds__(256) void online_small_kernel(
+    OnlineArgs a, const float *__restrict__ xs, const float *__restrict__ xp, const float *__restrict__ yp,
+    const double *__restrict__ lutd, int lutw, int D, int P, int ppitch, int pitch, double eta, double sigma,
+    int decay_fn, float *map, float *Smap, float *sigmap, float *weight, u64 *hits, u64 *lastbmu_io,
+    float *residual, float fB, int add_hit)   // no __restrict__: a.d.ma aliases map, lastbmu_io is read and written
+{
+    constexpr bool CLR = KIND == VSOM_CLR;
+    __shared__ u64 sbmu;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        const u64 b = online_local_search<CLR>(a, lastbmu_io, lane);
+        if (lane == 0)
+            sbmu = b;
+    }
+    __syncthreads();
+    const u64 bmu = sbmu;
+    int bx, by;
+    u64 startX, startY, endX, endY;
+    online_window(bmu, a.W, a.H, sigma, bx, by, startX, startY, endX, endY);
+    const u64 nx = endX > startX ? endX - startX : 0, ny = endY > startY ? endY - startY : 0;
+    for (u64 idx = (u64)wave; idx < nx * ny; idx += (u64)(blockDim.x >> 6)) {
+        const u64 i = startX + idx % nx, j = startY + idx / nx;
+        int dx = (int)i - bx, dy = (int)j - by;
+        dx = dx < 0 ? -dx : dx;
+        dy = dy < 0 ? -dy : dy;
+        const double h = lutd[(size_t)dy * lutw + dx];
+        online_node_update<KIND, false>((size_t)(j * (u64)a.W + i), h, lane, 64, xs, xp, yp, D, P, ppitch, pitch,
+                                        eta, decay_fn, map, Smap, sigmap, weight);
+    }
+    __syncthreads();   // the BMU row may have been rewritten by another wave of this workgroup
+    if (wave == 0)
+        online_post<CLR>(a, bmu, lane, hits, lastbmu_io, residual, fB, add_hit);
+}
+
 __global__ void online_init_kernel(u64 *state, float *fstate)
 {
     state[0] = ~0ull;
     state[1] = 0ull;
     state[2] = 0ull;
+    state[3] = 0ull;
     fstate[0] = 0.f;
     fstate[1] = 0.f;
 }
@@ -318,12 +396,23 @@ static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const f
             hipLaunchKernelGGL(online_scan_kernel<true>, grid, dim3(256), 0, c->stream, a);
         else
             hipLaunchKernelGGL(online_scan_kernel<false>, grid, dim3(256), 0, c->stream, a);
+        // (fusing this tiny launch into the scan through an arrival ticket measured 6 us SLOWER per
+        //  sample: 2048 fenced atomics on one word)
         hipLaunchKernelGGL(online_resolve_kernel, dim3(1), dim3(64), 0, c->stream, c->onl_state);
     } else {
-        if (clr)
-            hipLaunchKernelGGL(online_local_kernel<true>, dim3(1), dim3(64), 0, c->stream, a, lastbmu_dev);
+        // sigma <= 1: one fused launch (local search + <=6x6 window + post)
+#define LAUNCH_SMALL(KIND)                                                                                  \
+    hipLaunchKernelGGL(online_small_kernel<KIND>, dim3(1), dim3(256), 0, c->stream, a, xs, xp, yp, lutd, lutw, \
+                       (int)c->D, (int)c->part_len, (int)c->part_pitch, (int)c->pitch, eta, sigma, decay_fn, \
+                       c->map, c->S, c->sigma, c->weight, c->hits, lastbmu_dev, residual_dev, fB, add_hit)
+        if (c->transform == VSOM_CLR)
+            LAUNCH_SMALL(VSOM_CLR);
+        else if (c->transform == VSOM_MEDIAN)
+            LAUNCH_SMALL(VSOM_MEDIAN);
         else
-            hipLaunchKernelGGL(online_local_kernel<false>, dim3(1), dim3(64), 0, c->stream, a, lastbmu_dev);
+            LAUNCH_SMALL(VSOM_STANDARD);
+#undef LAUNCH_SMALL
+        return VSOM_OK;
     }
     // maximal window extents: trunc(b+2.5s) - trunc(b-2.5s) <= floor(5s)+1, clipped to the map
     double ext = std::floor(5.0 * sigma) + 2.0;
