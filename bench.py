@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--sigma", type=float, default=32.0)
     ap.add_argument("--strong", action="store_true", help="fixed total chunk (strong scaling)")
     ap.add_argument("--local", action="store_true", help="time the later-epoch (findLocalBmu) pass")
+    ap.add_argument("--fma", action="store_true",
+                    help="opt-in contracted update arithmetic (within 1e-5 of the reference, not bit-identical)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--nchunks", type=int, default=4, help="distinct resident chunks cycled over")
@@ -126,6 +128,8 @@ def main():
     ctx = vsom_amd.Context(W, H, D, capi.STANDARD, device=local_rank)
     ctx.set_state(map=init_map)
     ctx.set_stream(stream.cuda_stream)
+    if args.fma:
+        ctx.set_update_mode(capi.UPDATE_FMA)
     chunks = [torch.from_numpy(c).to(dev) for c in chunks_host]
     torch.cuda.synchronize()
 
@@ -190,6 +194,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "update_arithmetic": "fma (opt-in, 1e-5 relative)" if args.fma else "strict (bit-identical to the CPU oracle)",
             "config": {"workload": (f"{W}x{H} map, {D}-dim MNIST-like synthetic, standard transformation, "
                                     f"trainBatchSomEpoch({'findBmu' if is_first else 'findLocalBmu'} + update), "
                                     f"chunk B={Bper}/GPU ({Bglob} total), sigma={args.sigma}"),

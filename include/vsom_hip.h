@@ -63,6 +63,15 @@ typedef enum vsom_bmu_mode {
     VSOM_BMU_SHORTLIST = 2  /* force the MFMA shortlist path                           */
 } vsom_bmu_mode;
 
+/* arithmetic of the phase-2 chain kernel */
+typedef enum vsom_update_mode {
+    VSOM_UPDATE_STRICT = 0, /* one rounding per fp32 operation: bit-identical to the reference's SSE2
+                               build (default)                                                    */
+    VSOM_UPDATE_FMA = 1     /* M = fma(c,d,M), S = fma(w*d,d,S): 1/3 fewer VALU ops, results within
+                               1e-5 relative of the reference (Standard transformation only;
+                               other transformations ignore the setting)                          */
+} vsom_update_mode;
+
 /* selectors for vsom_device_ptr / vsom_get_timing */
 typedef enum vsom_buffer {
     VSOM_BUF_MAP = 0,      /* float   [N][D]                                    */
@@ -100,6 +109,7 @@ void vsom_destroy(vsom_ctx *ctx);
 int vsom_set_stream(vsom_ctx *ctx, void *hip_stream);
 int vsom_synchronize(vsom_ctx *ctx);
 int vsom_set_bmu_mode(vsom_ctx *ctx, int mode);
+int vsom_set_update_mode(vsom_ctx *ctx, int mode);
 /* diagnostics of the last MFMA-shortlist search (synchronises): out[0] = samples that had to be
  * redone by the exact-order kernel, out[1] = shortlisted candidates in total, out[2] = samples
  * searched, out[3] = number of shortlist searches so far */

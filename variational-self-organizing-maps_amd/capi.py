@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libvsom_hip.so")
 STANDARD, MEDIAN, CLR = 0, 1, 2
 EXPONENTIAL, INVERSE_PROPORTIONAL, BATCHMAP = 0, 1, 2
 BMU_AUTO, BMU_EXACT, BMU_SHORTLIST = 0, 1, 2
+UPDATE_STRICT, UPDATE_FMA = 0, 1
 BUF_MAP, BUF_SIGMA, BUF_S, BUF_WEIGHT, BUF_HITS, BUF_LASTBMU, BUF_SQRES, BUF_CHUNK = range(8)
 T_STAGE, T_BMU, T_FINISH, T_CW, T_UPDATE, T_ONLINE, T_SIGMA, T_COUNT = range(8)
 TIMER_NAMES = ["stage", "bmu", "finish", "cw", "update", "online", "sigma"]
@@ -23,7 +24,7 @@ TIMER_NAMES = ["stage", "bmu", "finish", "cw", "update", "online", "sigma"]
 # every symbol include/vsom_hip.h declares (tests/test_capi_symbols.py checks the header too)
 SYMBOLS = [
     "vsom_last_error", "vsom_device_count", "vsom_create", "vsom_destroy", "vsom_set_stream",
-    "vsom_synchronize", "vsom_set_bmu_mode", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
+    "vsom_synchronize", "vsom_set_bmu_mode", "vsom_set_update_mode", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
     "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_get_last_bmu",
     "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_bmu_local_batch",
     "vsom_distances", "vsom_batch_phase1_async", "vsom_batch_finish_async",
@@ -70,6 +71,7 @@ def lib():
     L.vsom_set_stream.argtypes = [vp, vp]
     L.vsom_synchronize.argtypes = [vp]
     L.vsom_set_bmu_mode.argtypes = [vp, C.c_int]
+    L.vsom_set_update_mode.argtypes = [vp, C.c_int]
     L.vsom_get_shortlist_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
     for name in ("vsom_depth", "vsom_nodes", "vsom_residual_len", "vsom_pitch", "vsom_chunk_pitch"):
         getattr(L, name).argtypes = [vp]
@@ -159,6 +161,9 @@ class Context:
 
     def set_bmu_mode(self, mode):
         check(lib().vsom_set_bmu_mode(self._h, int(mode)))
+
+    def set_update_mode(self, mode):
+        check(lib().vsom_set_update_mode(self._h, int(mode)))
 
     def shortlist_stats(self):
         out = (C.c_uint32 * 4)()

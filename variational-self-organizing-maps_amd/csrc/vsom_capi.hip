@@ -233,6 +233,14 @@ int vsom_get_shortlist_stats(vsom_ctx *c, uint32_t *out)
     return VSOM_OK;
 }
 
+int vsom_set_update_mode(vsom_ctx *c, int mode)
+{
+    if (!c || (mode != VSOM_UPDATE_STRICT && mode != VSOM_UPDATE_FMA))
+        return vsom_fail(VSOM_ERR_INVALID, "bad update mode");
+    c->update_mode = mode;
+    return VSOM_OK;
+}
+
 uint32_t vsom_depth(const vsom_ctx *c) { return c ? c->D : 0; }
 uint32_t vsom_nodes(const vsom_ctx *c) { return c ? c->N : 0; }
 uint32_t vsom_residual_len(const vsom_ctx *c) { return c ? c->part_len : 0; }

@@ -283,12 +283,16 @@ int vsom_load_asm_module(vsom_ctx *c)
         return VSOM_OK;
     hipModule_t mod;
     VSOM_HIP_CHECK(hipModuleLoadData(&mod, vsom_update_hsaco));
-    hipFunction_t f16, f14;
+    hipFunction_t f16, f14, m16, m14;
     VSOM_HIP_CHECK(hipModuleGetFunction(&f16, mod, "vsom_update_std_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&f14, mod, "vsom_update_std_rd14_gfx950"));
+    VSOM_HIP_CHECK(hipModuleGetFunction(&m16, mod, "vsom_update_fma_rd16_gfx950"));
+    VSOM_HIP_CHECK(hipModuleGetFunction(&m14, mod, "vsom_update_fma_rd14_gfx950"));
     c->upd_module = mod;
     c->upd_fn16 = f16;
     c->upd_fn14 = f14;
+    c->upd_fma16 = m16;
+    c->upd_fma14 = m14;
     return VSOM_OK;
 }
 
@@ -416,7 +420,9 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
                                      HIP_LAUNCH_PARAM_END};
                     // XCD-aware grid: x = 8 * slice quads, y = node groups / 8 (see gen_update_asm.py)
-                    VSOM_HIP_CHECK(hipModuleLaunchKernel(rd == 14 ? (hipFunction_t)c->upd_fn14 : (hipFunction_t)c->upd_fn16,
+                    const bool fma = c->update_mode == VSOM_UPDATE_FMA;
+                    void *fn = rd == 14 ? (fma ? c->upd_fma14 : c->upd_fn14) : (fma ? c->upd_fma16 : c->upd_fn16);
+                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn,
                                                          8 * ((nfull + 3) / 4), (gx + 7) / 8, 1, 256, 1, 1, 0, c->stream,
                                                          nullptr, extra));
                     dbase = (int)(nfull * rd);
