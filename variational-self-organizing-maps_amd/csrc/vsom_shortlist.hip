@@ -95,24 +95,27 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict
             for (int r = 0; r < 16; ++r)
                 tot[i][j][r] = 0.f;
 
-    float4 pa[4], pb[4];
+    constexpr int F4R = GK / 4;               // float4 per tile row
+    constexpr int NLD = GT * F4R / 256;       // float4 per thread per operand
+    float4 pa[NLD], pb[NLD];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             int f = tid + 256 * i;
-            int row = f >> 3, c4 = (f & 7) * 4;
+            int row = f / F4R, c4 = (f % F4R) * 4;
             int s = sbase + row, n = nbase + row;
-            pa[i] = s < s1 ? *reinterpret_cast<const float4 *>(X + (size_t)s * ldx + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            pb[i] = n < N ? *reinterpret_cast<const float4 *>(M + (size_t)n * ldm + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool kin = k0 + c4 < Kp;    // Kp is a multiple of 32, GK may be 64
+            pa[i] = (s < s1 && kin) ? *reinterpret_cast<const float4 *>(X + (size_t)s * ldx + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[i] = (n < N && kin) ? *reinterpret_cast<const float4 *>(M + (size_t)n * ldm + k0 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     gload(0);
     for (int k0 = 0; k0 < Kp; k0 += GK) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             int f = tid + 256 * i;
-            int row = f >> 3, c4 = (f & 7) * 4;
+            int row = f / F4R, c4 = (f % F4R) * 4;
             *reinterpret_cast<float4 *>(&As[row * GLD + c4]) = pa[i];
             *reinterpret_cast<float4 *>(&Bs[row * GLD + c4]) = pb[i];
         }
