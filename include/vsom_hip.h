@@ -145,6 +145,19 @@ int vsom_bmu_local_batch(vsom_ctx *ctx, uint64_t *idx_out_host, float *dist_out_
 int vsom_distances(vsom_ctx *ctx, const uint64_t *nodes_host, const uint64_t *rows_host,
                    size_t count, float *dist_out_host);
 
+/* ---- consumers of the search outside the training loop (SURVEY 8f "next" rows) --------------
+ * Som::findRestrictedBmu (Som.cpp:313-332) for every sample of the chunk: argmin over node 0 and
+ * the nodes with bmuHits >= min_hits.  Overwrites the chunk's lastBMU / sqres like vsom_bmu_batch. */
+int vsom_bmu_restricted_batch(vsom_ctx *ctx, uint64_t min_hits, uint64_t *idx_out_host,
+                              float *dist_out_host);
+/* Som::euclidianWeightedDist of EVERY node for chunk row `row` (input of findRestrictedBmd,
+ * Som.cpp:457-487); dist_out_host[N]. */
+int vsom_distances_row(vsom_ctx *ctx, size_t row, float *dist_out_host);
+/* Som::euclidianWeightedDistRaw(pos, v, ones, ones) (Som.cpp:143-157) for `count` pairs; v is
+ * chunk row vrows[i] (from_map = 0) or model vector vrows[i] (from_map = 1, the U-matrix case). */
+int vsom_distances_raw(vsom_ctx *ctx, const uint64_t *nodes_host, const uint64_t *vrows_host,
+                       size_t count, int from_map, float *dist_out_host);
+
 /* ---- batch epoch: Som::trainBatchSomEpoch (Som.cpp:756-879) ----------------------------
  * phase 1 (:762-806) over samples [s0,s1): BMU (findBmu when is_first else findLocalBmu)
  *   + per-sample ||residual||^2;  finish: bmuHits += 1, fp32 MSE in sample order;

@@ -88,6 +88,12 @@ def lib():
     L.vso_train_online_chunk.argtypes = [sp, fp, C.c_size_t, u64p, C.c_double, C.c_double, C.c_int]
     L.vso_train_online.argtypes = [sp, fp, szp, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
                                    C.c_double, C.c_double, C.c_int, fp]
+    L.vso_find_restricted_bmu.restype = C.c_size_t
+    L.vso_find_restricted_bmu.argtypes = [sp, fp, C.c_uint64]
+    L.vso_find_restricted_bmd.argtypes = [sp, fp, C.c_uint64, C.POINTER(C.c_double)]
+    L.vso_dist_raw.restype = C.c_double
+    L.vso_dist_raw.argtypes = [sp, C.c_size_t, fp]
+    L.vso_update_umatrix.argtypes = [sp, C.POINTER(C.c_double)]
     L.vso_max_threads.restype = C.c_int
     _lib = L
     return L
@@ -200,6 +206,26 @@ class OracleSom:
     def find_local_bmu(self, v, last):
         v = _as_f32(v)
         return int(lib().vso_find_local_bmu(self._p, _f(v), int(last)))
+
+    # --- consumers of the search / U-matrix -------------------
+    def find_restricted_bmu(self, v, min_hits):
+        v = _as_f32(v)
+        return int(lib().vso_find_restricted_bmu(self._p, _f(v), int(min_hits)))
+
+    def find_restricted_bmd(self, v, min_hits):
+        v = _as_f32(v)
+        out = np.empty(self.n_nodes, np.float64)
+        lib().vso_find_restricted_bmd(self._p, _f(v), int(min_hits), out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def dist_raw(self, pos, v):
+        v = _as_f32(v)
+        return float(lib().vso_dist_raw(self._p, int(pos), _f(v)))
+
+    def update_umatrix(self):
+        out = np.empty(self.n_nodes, np.float64)
+        lib().vso_update_umatrix(self._p, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
 
     # --- batch path -----------------------------------------------------
     def _chk(self, X):

@@ -781,3 +781,141 @@ float vso_batch_epoch_faithful(vso_som *som, const float *X, size_t B,
     free(S);
     return mse;
 }
+
+/* ================= "next" rows ================= */
+
+/* ---- Som::findRestrictedBmu: Som.cpp:313-332 ---- */
+size_t vso_find_restricted_bmu(const vso_som *som, const float *v, uint64_t min_hits)
+{
+    size_t N = som->width * som->height;
+    size_t L = vso_comparer_len(som->transform, som->depth);
+    float *scratch = (float *)malloc((L ? L : 1) * sizeof(float));
+    double minDist = (double)dist_scratch(som, 0, v, scratch); /* node 0 seeds whatever its hits :316-317 */
+    size_t minIndex = 0;
+    for (size_t i = 0; i < N; ++i) {
+        double cur = (double)dist_scratch(som, i, v, scratch);
+        if (cur < minDist && som->hits[i] >= min_hits) { /* :322 */
+            minDist = cur;
+            minIndex = i;
+        }
+    }
+    free(scratch);
+    return minIndex;
+}
+
+/* ---- Som::findRestrictedBmd: Som.cpp:457-487 ---- */
+void vso_find_restricted_bmd(const vso_som *som, const float *v, uint64_t min_hits, double *out)
+{
+    size_t N = som->width * som->height;
+    size_t L = vso_comparer_len(som->transform, som->depth);
+    float *scratch = (float *)malloc((L ? L : 1) * sizeof(float));
+    double C = 0;
+    for (size_t i = 0; i < N; ++i) {
+        if (som->hits[i] >= min_hits) {
+            double d = (double)dist_scratch(som, i, v, scratch); /* :470 */
+            d = exp(-d * d / 2);                                  /* :473 */
+            out[i] = d;
+            C += d;                                               /* :476 */
+        } else {
+            out[i] = 0;
+        }
+    }
+    for (size_t i = 0; i < N; ++i)
+        out[i] /= C; /* :483-484 */
+    free(scratch);
+}
+
+/* ---- Som::euclidianWeightedDistRaw: Som.cpp:143-157 (valid = weights = 1) ----
+ * a = (M - v)/sM ; b = ((M - v) * validEigen)/sM ; a.dot(b) in Eigen's redux order (Q1). */
+double vso_dist_raw(const vso_som *som, size_t pos, const float *v)
+{
+    size_t D = som->depth;
+    const float *M = som->map + pos * D, *sg = som->sigma + pos * D;
+    /* the products a_d*b_d are summed in the order of vso_dot_self; reuse its structure */
+    float *prod = (float *)malloc((D ? D : 1) * sizeof(float));
+    for (size_t d = 0; d < D; ++d) {
+        float sM = sg[d] < 0.00001f ? 0.00001f : sg[d]; /* :150 */
+        float r = M[d] - v[d];
+        float a = r / sM;
+        float rb = r * (1.0f * 1.0f);                   /* validEigen = valid*weights :153 */
+        float b = rb / sM;
+        prod[d] = a * b;
+    }
+    /* Eigen redux over the products (same tree as vso_dot_self, without squaring) */
+    float res;
+    size_t n = D, aligned2 = (n / 8) * 8, aligned = (n / 4) * 4;
+    if (n == 0) {
+        res = 0.f;
+    } else if (aligned) {
+        float p0[4], p1[4];
+        for (int k = 0; k < 4; ++k)
+            p0[k] = prod[k];
+        if (aligned > 4) {
+            for (int k = 0; k < 4; ++k)
+                p1[k] = prod[4 + k];
+            for (size_t idx = 8; idx < aligned2; idx += 8) {
+                for (int k = 0; k < 4; ++k)
+                    p0[k] = p0[k] + prod[idx + k];
+                for (int k = 0; k < 4; ++k)
+                    p1[k] = p1[k] + prod[idx + 4 + k];
+            }
+            for (int k = 0; k < 4; ++k)
+                p0[k] = p0[k] + p1[k];
+            if (aligned > aligned2)
+                for (int k = 0; k < 4; ++k)
+                    p0[k] = p0[k] + prod[aligned2 + k];
+        }
+        float t02 = p0[0] + p0[2], t13 = p0[1] + p0[3];
+        res = t02 + t13;
+        for (size_t idx = aligned; idx < n; ++idx)
+            res = res + prod[idx];
+    } else {
+        res = prod[0];
+        for (size_t idx = 1; idx < n; ++idx)
+            res = res + prod[idx];
+    }
+    free(prod);
+    return (double)res;
+}
+
+/* ---- Som::updateUMatrix: Som.cpp:999-1111 ---- */
+void vso_update_umatrix(const vso_som *som, double *U)
+{
+    const size_t width = som->width, height = som->height, D = som->depth;
+    const double diagonalFactor = 0.3;
+#define RAW(ii, jj, ni, nj) vso_dist_raw(som, (ii) * width + (jj), som->map + ((ni) * width + (nj)) * D)
+    for (size_t i = 0; i < height; ++i) {
+        for (size_t j = 0; j < width; ++j) {
+            double u;
+            if (j > 0 && i > 0 && j < (width - 1) && i < (height - 1)) {
+                u = (RAW(i, j, i, j - 1) + RAW(i, j, i, j + 1) + RAW(i, j, i + 1, j) + RAW(i, j, i - 1, j) +
+                     RAW(i, j, i - 1, j - 1) * diagonalFactor + RAW(i, j, i + 1, j - 1) * diagonalFactor +
+                     RAW(i, j, i - 1, j + 1) * diagonalFactor + RAW(i, j, i + 1, j + 1) * diagonalFactor) / 8;
+            } else if (i == 0 && j > 0 && j < (width - 1)) {
+                u = (RAW(i, j, i, j - 1) + RAW(i, j, i, j + 1) + RAW(i, j, i + 1, j) +
+                     RAW(i, j, i + 1, j - 1) * diagonalFactor + RAW(i, j, i + 1, j + 1) * diagonalFactor) / 5;
+            } else if (i == (height - 1) && j > 0 && j < (width - 1)) {
+                u = (RAW(i, j, i, j - 1) + RAW(i, j, i, j + 1) + RAW(i, j, i - 1, j) +
+                     RAW(i, j, i - 1, j - 1) * diagonalFactor + RAW(i, j, i - 1, j + 1) * diagonalFactor) / 5;
+            } else if (j == 0 && i > 0 && i < (height - 1)) {
+                u = (RAW(i, j, i, j + 1) + RAW(i, j, i + 1, j) + RAW(i, j, i - 1, j) +
+                     RAW(i, j, i - 1, j + 1) * diagonalFactor + RAW(i, j, i + 1, j + 1) * diagonalFactor) / 5;
+            } else if (j == (width - 1) && i > 0 && i < (height - 1)) {
+                u = (RAW(i, j, i, j - 1) + RAW(i, j, i + 1, j) + RAW(i, j, i - 1, j) +
+                     RAW(i, j, i - 1, j - 1) * diagonalFactor + RAW(i, j, i + 1, j - 1) * diagonalFactor) / 5;
+            } else if (j == 0 && i == 0) {
+                u = (RAW(i, j, i, j + 1) + RAW(i, j, i + 1, j) + RAW(i, j, i + 1, j + 1) * diagonalFactor) / 3;
+            } else if (j == (width - 1) && i == 0) {
+                u = (RAW(i, j, i, j - 1) + RAW(i, j, i + 1, j) + RAW(i, j, i + 1, j - 1) * diagonalFactor) / 3;
+            } else if (j == 0 && i == (height - 1)) {
+                u = (RAW(i, j, i, j + 1) + RAW(i, j, i - 1, j) + RAW(i, j, i - 1, j + 1) * diagonalFactor) / 3;
+            } else if (j == (width - 1) && i == (height - 1)) {
+                u = (RAW(i, j, i, j - 1) + RAW(i, j, i - 1, j) + RAW(i, j, i - 1, j - 1) * diagonalFactor) / 3;
+            } else {
+                u = 0;
+            }
+            U[i * width + j] = u;
+        }
+    }
+#undef RAW
+}

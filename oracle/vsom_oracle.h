@@ -125,6 +125,16 @@ void vso_train_online(vso_som *som, const float *X, const size_t *chunk_off,
                       size_t nchunks, size_t epochs, double eta0, double eta_decay,
                       double sigma0, double sigma_decay, int decay_fn, float *mse_out);
 
+/* ---- "next" rows of SURVEY 8f (consumers of the BMU search; U-matrix) ------------------------ */
+/* Som::findRestrictedBmu (Som.cpp:313-332): node 0 seeds unconditionally. */
+size_t vso_find_restricted_bmu(const vso_som *som, const float *v, uint64_t min_hits);
+/* Som::findRestrictedBmd (Som.cpp:457-487): out[N] doubles. */
+void vso_find_restricted_bmd(const vso_som *som, const float *v, uint64_t min_hits, double *out);
+/* Som::euclidianWeightedDistRaw (Som.cpp:143-157) with valid == weights == 1. */
+double vso_dist_raw(const vso_som *som, size_t pos, const float *v);
+/* Som::updateUMatrix (Som.cpp:999-1111): U[N] doubles. */
+void vso_update_umatrix(const vso_som *som, double *U);
+
 /* CPU-baseline variant that mirrors the reference's per-call temporaries
  * (heap vector per Comparer/Stepper call, neuron copy) -- timing honesty only,
  * results identical to vso_batch_epoch(nthreads=1). */

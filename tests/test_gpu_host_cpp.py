@@ -118,3 +118,60 @@ def test_custom_transformation_is_rejected_not_emulated(dumps):
     _, out, err = dumps
     assert "custom_transformation_rejected=1 kind=-1" in out
     assert "no CPU fallback" in err
+
+
+def test_next_rows_restricted_bmu_bmd_umatrix_evaluate(dumps):
+    d, _, _ = dumps
+    rows = make_rows(50, 9, 12345)
+    o = po.OracleSom(10, 10, 9)
+    o.random_initialize(21, 1.0)
+    o.train_batch(rows, [0, 50], 2, 4.0, 0.2, nthreads=2)
+    st = read_dump(os.path.join(d, "next_state.bin"))
+    check_state(st, o)
+    v = rows[3]
+    lines = open(os.path.join(d, "next_rows.txt")).read().split("\n")
+    a, b, c = [int(t) for t in lines[0].split()]
+    assert (a, b, c) == (o.find_restricted_bmu(v, 1), o.find_restricted_bmu(v, 3), o.find_restricted_bmu(v, 1000))
+    assert c == 0                                          # nothing qualifies: node 0 seeds (Som.cpp:316-317)
+    bmd = np.fromfile(os.path.join(d, "bmd.bin"), np.float64)
+    exp = o.find_restricted_bmd(v, 1)
+    assert (bmd == exp).all() or np.allclose(bmd, exp, rtol=1e-15, atol=0)
+    um = np.fromfile(os.path.join(d, "umatrix.bin"), np.float64)
+    assert (um == o.update_umatrix()).all()
+    tok = lines[1].split()
+    assert float.fromhex(tok[0]) == o.dist_raw(17, v)
+    # evaluate on all-continuous data = running mean of the BMU distances (Som.cpp:519)
+    err = 0.0
+    for i in range(50):
+        err += 1.0 / (i + 1.0) * (o.dist(o.find_bmu(rows[i]), rows[i]) - err)
+    assert float.fromhex(tok[1]) == err
+    # measureSimilarity (Som.cpp:631-714) restated
+    def measure(nsig, minhits):
+        maxv, maxrow, last, success = np.float32(-99999999.0), 0, False, True
+        i = 0
+        while i < 51:
+            if i == 50:
+                i, last = maxrow, True
+            pos = o.find_restricted_bmu(rows[i], minhits)
+            sg, m = o.sigma[pos], o.map[pos]
+            sM = np.where(sg > np.float32(1e-5), np.float32(1e-5), sg).astype(np.float32)
+            with np.errstate(all="ignore"):
+                delta = ((rows[i] - m) / sM / np.float32(nsig)).astype(np.float32)
+            mn, mx = m - sM * np.float32(nsig), m + sM * np.float32(nsig)
+            for k in range(9):
+                if delta[k] > maxv:
+                    maxv, maxrow = np.float32(abs(delta[k])), i
+                if last and (rows[i][k] < mn[k] or rows[i][k] > mx[k]):
+                    success = False
+            if last:
+                break
+            i += 1
+        return int(success)
+    assert int(tok[2]) == measure(3, 1) and int(tok[3]) == measure(1000000, 1)
+    assert lines[2].strip() == "1"
+    # CLR U-matrix
+    oc = po.OracleSom(5, 4, 4, po.CLR)
+    oc.random_initialize(5, 1.0)
+    oc.sigma[...] = (0.25 + 0.01 * (np.arange(20 * 12) % 7)).astype(np.float32).reshape(20, 12)
+    umc = np.fromfile(os.path.join(d, "umatrix_clr.bin"), np.float64)
+    assert (umc == oc.update_umatrix()).all()

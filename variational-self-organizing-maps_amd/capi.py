@@ -27,7 +27,7 @@ SYMBOLS = [
     "vsom_synchronize", "vsom_set_bmu_mode", "vsom_set_update_mode", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
     "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_get_last_bmu",
     "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_bmu_local_batch",
-    "vsom_distances", "vsom_batch_phase1_async", "vsom_batch_finish_async",
+    "vsom_distances", "vsom_bmu_restricted_batch", "vsom_distances_row", "vsom_distances_raw", "vsom_batch_phase1_async", "vsom_batch_finish_async",
     "vsom_batch_phase2_async", "vsom_batch_epoch_async", "vsom_batch_epoch", "vsom_get_mse",
     "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk",
     "vsom_neighbourhood_weight", "vsom_device_ptr", "vsom_chunk_size", "vsom_pitch",
@@ -88,6 +88,9 @@ def lib():
     L.vsom_bmu_batch.argtypes = [vp, u64p, fp]
     L.vsom_bmu_local_batch.argtypes = [vp, u64p, fp]
     L.vsom_distances.argtypes = [vp, u64p, u64p, C.c_size_t, fp]
+    L.vsom_bmu_restricted_batch.argtypes = [vp, C.c_uint64, u64p, fp]
+    L.vsom_distances_row.argtypes = [vp, C.c_size_t, fp]
+    L.vsom_distances_raw.argtypes = [vp, u64p, u64p, C.c_size_t, C.c_int, fp]
     L.vsom_batch_phase1_async.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_int]
     L.vsom_batch_finish_async.argtypes = [vp]
     L.vsom_batch_phase2_async.argtypes = [vp, C.c_double, C.c_size_t, C.c_size_t]
@@ -246,6 +249,24 @@ class Context:
         assert nodes.size == rows.size
         out = np.empty(nodes.size, np.float32)
         check(lib().vsom_distances(self._h, _u(nodes), _u(rows), nodes.size, _f(out)))
+        return out
+
+    def bmu_restricted_batch(self, min_hits):
+        B = self.chunk_size
+        idx, dist = np.empty(B, np.uint64), np.empty(B, np.float32)
+        check(lib().vsom_bmu_restricted_batch(self._h, int(min_hits), _u(idx), _f(dist)))
+        return idx, dist
+
+    def distances_row(self, row):
+        out = np.empty(self.n_nodes, np.float32)
+        check(lib().vsom_distances_row(self._h, int(row), _f(out)))
+        return out
+
+    def distances_raw(self, nodes, vrows, from_map):
+        nodes = np.ascontiguousarray(nodes, dtype=np.uint64)
+        vrows = np.ascontiguousarray(vrows, dtype=np.uint64)
+        out = np.empty(nodes.size, np.float32)
+        check(lib().vsom_distances_raw(self._h, _u(nodes), _u(vrows), nodes.size, int(bool(from_map)), _f(out)))
         return out
 
     # ---- batch epoch ---------------------------------------------------

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
                                                           u64 *__restrict__ partial, int pstride,
                                                           unsigned char *__restrict__ nan0,
                                                           const int *__restrict__ slist,
-                                                          const unsigned *__restrict__ scount)
+                                                          const unsigned *__restrict__ scount,
+                                                          const u64 *__restrict__ hits, u64 min_hits)
 {
     // optional indirection: process only the samples listed by the shortlist path
     // (vsom_shortlist.hip); s0/s1 then index the list and workgroups beyond its length exit
@@ -255,7 +256,9 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int n = nbase + tx + 16 * j;
-            u64 k = n < N ? vsom_key(dist[i][j], (uint32_t)n) : ~0ull;
+            // findRestrictedBmu (Som.cpp:316-322): node 0 seeds unconditionally, others need the hits
+            const bool allowed = n < N && (hits == nullptr || n == 0 || hits[n] >= min_hits);
+            u64 k = allowed ? vsom_key(dist[i][j], (uint32_t)n) : ~0ull;
             kmin = k < kmin ? k : kmin;
         }
         keys[(ty + 16 * i) * 16 + tx] = kmin;
@@ -303,7 +306,8 @@ __global__ void bmu_reduce_kernel(const u64 *__restrict__ partial, int pstride, 
     }
 }
 
-int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount)
+int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount,
+                                 const u64 *hits, u64 min_hits)
 {
     if (s1 <= s0)
         return VSOM_OK;
@@ -321,15 +325,26 @@ int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *sli
     dim3 grid((unsigned)ntn, (unsigned)nts);
     if (c->transform == VSOM_CLR)
         hipLaunchKernelGGL(bmu_tile_kernel<true>, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
-                           (int)c->N, c->partial, (int)c->Bcap, c->nan0, slist, scount);
+                           (int)c->N, c->partial, (int)c->Bcap, c->nan0, slist, scount, hits, min_hits);
     else
         hipLaunchKernelGGL(bmu_tile_kernel<false>, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
-                           (int)c->N, c->partial, (int)c->Bcap, c->nan0, slist, scount);
+                           (int)c->N, c->partial, (int)c->Bcap, c->nan0, slist, scount, hits, min_hits);
     hipLaunchKernelGGL(bmu_reduce_kernel, dim3((unsigned)((s1 - s0 + 255) / 256)), dim3(256), 0,
                        c->stream, c->partial, (int)c->Bcap, ntn, c->nan0, (int)s0, (int)s1, c->lastbmu,
                        c->sqres, slist, scount);
     VSOM_HIP_CHECK(hipGetLastError());
     return VSOM_OK;
+}
+
+int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount)
+{
+    return launch_bmu_full_exact_masked(c, s0, s1, slist, scount, nullptr, 0);
+}
+
+int launch_bmu_restricted(vsom_ctx *c, u64 min_hits)
+{
+    TimerScope ts(c, VSOM_T_BMU);
+    return launch_bmu_full_exact_masked(c, 0, c->B, nullptr, nullptr, c->hits, min_hits);
 }
 
 int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1);
@@ -498,6 +513,86 @@ int launch_pair_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *rows_dev, siz
     else
         hipLaunchKernelGGL(pair_dist_kernel<false>, grid, dim3(256), 0, c->stream, a, nodes_dev,
                            rows_dev, (int)count, out_dev);
+    VSOM_HIP_CHECK(hipGetLastError());
+    return VSOM_OK;
+}
+
+// every node against one chunk row (input of Som::findRestrictedBmd)
+template <bool CLR>
+__global__ __launch_bounds__(256) void row_dist_kernel(DistArgs a, int row, int N, float *__restrict__ out)
+{
+    const int gid = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 3);
+    const int k = threadIdx.x & 7;
+    const int n = gid < N ? gid : N - 1;
+    float d = vsom_group_dist<CLR>(a.xa + (size_t)row * a.ldx, a.xb + (size_t)row * a.ldx,
+                                   a.ma + (size_t)n * a.ldm, a.mb + (size_t)n * a.ldm, a.L, k);
+    if (gid < N && k == 0)
+        out[gid] = d;
+}
+
+int launch_row_dist(vsom_ctx *c, size_t row, float *out_dev)
+{
+    DistArgs a = make_dist_args(c);
+    dim3 grid((unsigned)(((size_t)c->N * 8 + 255) / 256));
+    if (c->transform == VSOM_CLR)
+        hipLaunchKernelGGL(row_dist_kernel<true>, grid, dim3(256), 0, c->stream, a, (int)row, (int)c->N, out_dev);
+    else
+        hipLaunchKernelGGL(row_dist_kernel<false>, grid, dim3(256), 0, c->stream, a, (int)row, (int)c->N, out_dev);
+    VSOM_HIP_CHECK(hipGetLastError());
+    return VSOM_OK;
+}
+
+// Som::euclidianWeightedDistRaw (Som.cpp:143-157), valid = weights = 1:
+//   a = (M - v)/sM, b = ((M - v)*1)/sM = a, sum of a*b in Eigen's reduction order;
+//   sM = sigma < 1e-5 ? 1e-5 : sigma.  8 lanes per pair (one per accumulator class).
+__global__ __launch_bounds__(256) void raw_dist_kernel(const float *__restrict__ map, const float *__restrict__ sigma,
+                                                       int ldm, const float *__restrict__ vbase, int ldv, int D,
+                                                       int P, int ppitch, int v_is_model,
+                                                       const u64 *__restrict__ nodes, const u64 *__restrict__ vrows,
+                                                       int count, float *__restrict__ out)
+{
+    const int gid = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 3);
+    const int k = threadIdx.x & 7;
+    const int p = gid < count ? gid : count - 1;
+    const float *M = map + (size_t)nodes[p] * ldm, *sg = sigma + (size_t)nodes[p] * ldm;
+    const float *v = vbase + (size_t)vrows[p] * ldv;
+    auto prod = [&](int d) {
+        // logical element d of a model vector: CLR rows are stored [A(P) | pad | B(P) | pad]
+        const int pm = d < P ? d : ppitch + (d - P);
+        const int pv = v_is_model ? pm : d;
+        float s = sg[pm] < 0.00001f ? 0.00001f : sg[pm];
+        float r = M[pm] - v[pv];
+        float a = r / s;
+        return a * a;
+    };
+    const int D8 = D & ~7;
+    float acc = 0.f;
+    for (int d = k; d < D8; d += 8)
+        acc = acc + prod(d);
+    float q = acc + __shfl_xor(acc, 4);
+    const int rem = D - D8;
+    if (rem >= 4)
+        q = q + prod(D8 + (k & 3));
+    float t = q + __shfl_xor(q, 2);
+    float res = t + __shfl_xor(t, 1);
+    for (int tt = (rem >= 4 ? 4 : 0); tt < rem; ++tt)
+        res = res + prod(D8 + tt);
+    if (gid < count && k == 0)
+        out[gid] = res;
+}
+
+int launch_raw_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *vrows_dev, size_t count, int from_map,
+                    float *out_dev)
+{
+    if (count == 0)
+        return VSOM_OK;
+    if (c->transform == VSOM_CLR && !from_map)
+        return vsom_fail(VSOM_ERR_UNSUPPORTED, "euclidianWeightedDistRaw against a sample needs depth == sample length");
+    dim3 grid((unsigned)((count * 8 + 255) / 256));
+    hipLaunchKernelGGL(raw_dist_kernel, grid, dim3(256), 0, c->stream, c->map, c->sigma, (int)c->pitch,
+                       from_map ? c->map : c->Xs, from_map ? (int)c->pitch : (int)c->xpitch, (int)c->D,
+                       (int)c->part_len, (int)c->part_pitch, from_map ? 1 : 0, nodes_dev, vrows_dev, (int)count,
+                       out_dev);
     VSOM_HIP_CHECK(hipGetLastError());
     return VSOM_OK;
 }

@@ -476,6 +476,70 @@ int vsom_distances(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *rows
     return rc;
 }
 
+int vsom_bmu_restricted_batch(vsom_ctx *c, uint64_t min_hits, uint64_t *idx_out_host, float *dist_out_host)
+{
+    CHECK_CTX(c);
+    if (c->B == 0)
+        return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
+    int rc = launch_bmu_restricted(c, min_hits);
+    if (rc)
+        return rc;
+    return copy_search_results(c, idx_out_host, dist_out_host);
+}
+
+int vsom_distances_row(vsom_ctx *c, size_t row, float *dist_out_host)
+{
+    CHECK_CTX(c);
+    if (row >= c->B || !dist_out_host)
+        return vsom_fail(VSOM_ERR_INVALID, "row out of range or null output");
+    float *dd = nullptr;
+    VSOM_HIP_CHECK(hipMalloc(&dd, (size_t)c->N * 4));
+    int rc = launch_row_dist(c, row, dd);
+    if (rc == VSOM_OK) {
+        (void)hipMemcpyAsync(dist_out_host, dd, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->stream);
+        if (hipStreamSynchronize(c->stream) != hipSuccess)
+            rc = vsom_fail(VSOM_ERR_HIP, "row distance kernel failed");
+    }
+    (void)hipFree(dd);
+    return rc;
+}
+
+int vsom_distances_raw(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *vrows_host, size_t count,
+                       int from_map, float *dist_out_host)
+{
+    CHECK_CTX(c);
+    if (count == 0)
+        return VSOM_OK;
+    if (!nodes_host || !vrows_host || !dist_out_host)
+        return vsom_fail(VSOM_ERR_INVALID, "null argument");
+    for (size_t i = 0; i < count; ++i)
+        if (nodes_host[i] >= c->N || vrows_host[i] >= (from_map ? (uint64_t)c->N : (uint64_t)c->B))
+            return vsom_fail(VSOM_ERR_INVALID, "pair index out of range");
+    u64 *dn = nullptr, *dr = nullptr;
+    float *dd = nullptr;
+    int rc = VSOM_OK;
+    if (hipMalloc(&dn, count * 8) != hipSuccess || hipMalloc(&dr, count * 8) != hipSuccess ||
+        hipMalloc(&dd, count * 4) != hipSuccess) {
+        rc = vsom_fail(VSOM_ERR_NOMEM, "hipMalloc failed");
+    } else {
+        (void)hipMemcpyAsync(dn, nodes_host, count * 8, hipMemcpyHostToDevice, c->stream);
+        (void)hipMemcpyAsync(dr, vrows_host, count * 8, hipMemcpyHostToDevice, c->stream);
+        rc = launch_raw_dist(c, dn, dr, count, from_map, dd);
+        if (rc == VSOM_OK) {
+            (void)hipMemcpyAsync(dist_out_host, dd, count * 4, hipMemcpyDeviceToHost, c->stream);
+            if (hipStreamSynchronize(c->stream) != hipSuccess)
+                rc = vsom_fail(VSOM_ERR_HIP, "raw distance kernel failed");
+        }
+    }
+    if (dn)
+        (void)hipFree(dn);
+    if (dr)
+        (void)hipFree(dr);
+    if (dd)
+        (void)hipFree(dd);
+    return rc;
+}
+
 int vsom_batch_phase1_async(vsom_ctx *c, size_t s0, size_t s1, int is_first)
 {
     CHECK_CTX(c);

@@ -298,8 +298,8 @@ public:
     double static calculateNeighbourhoodWeight(const size_t &currentX, const size_t &currentY, const size_t &bmuX,
                                                const size_t &bmuY, const double &currentSigma);
 
-    // ---- analysis members outside the hot path: declared for source compatibility; they throw
-    //      std::logic_error in this build (SURVEY.md 8f lists them as the next rows) ---------------
+    // ---- consumers of the search outside the training loop: distances and
+    //      (restricted) BMU searches on the device, scalar post-processing on the host ------------
     double evaluate(const DataSet &dataset) const;
     int measureSimilarity(const DataSet *dataset, int numberOfSigmas, size_t minBmuHits) const;
     int autoEncoder(const DataSet *dataset, size_t minBmuHits) const;

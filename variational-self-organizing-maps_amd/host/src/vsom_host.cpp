@@ -14,6 +14,8 @@
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
+#include <random>
+#include <ctime>
 
 // ---------------------------------------------------------------------------------------------
 // Transformation (reference src/Transformation.cpp:3-167).  Host evaluation of the built-in hooks
@@ -797,25 +799,229 @@ void Som::train(DataSet &data, size_t numberOfEpochs, double eta0, double etaDec
     _isTraining = false;
 }
 
-// ---- members outside the hot path ----------------------------------------------------------------
-#define VSOM_NOT_IN_SCOPE(name) throw std::logic_error(name ": outside the MI355X hot-path build (SURVEY.md 8f)")
-double Som::evaluate(const DataSet &) const { VSOM_NOT_IN_SCOPE("Som::evaluate"); }
-int Som::measureSimilarity(const DataSet *, int, size_t) const { VSOM_NOT_IN_SCOPE("Som::measureSimilarity"); }
-int Som::autoEncoder(const DataSet *, size_t) const { VSOM_NOT_IN_SCOPE("Som::autoEncoder"); }
-size_t Som::variationalAutoEncoder(const DataSet *, size_t) const { VSOM_NOT_IN_SCOPE("Som::variationalAutoEncoder"); }
-SomIndex Som::findRestrictedBmu(const Eigen::VectorXf &, const Eigen::VectorXf &, const size_t, const Eigen::VectorXf &) const
+// ---- consumers of the search outside the training loop --------------------
+// The distance work (restricted BMU search, all-node distances, raw sigma-normalised distances)
+// runs on the device; the scalar post-processing follows the reference line by line on the host.
+
+// Som.cpp:313-332
+SomIndex Som::findRestrictedBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &, const size_t minBmuHits,
+                                const Eigen::VectorXf &) const
 {
-    VSOM_NOT_IN_SCOPE("Som::findRestrictedBmu");
+    stageOne(v);
+    uint64_t idx = 0;
+    check(vsom_bmu_restricted_batch(ctx, minBmuHits, &idx, nullptr), "vsom_bmu_restricted_batch");
+    return SomIndex((size_t)idx % width, (size_t)idx / width);
 }
-std::vector<double> Som::findRestrictedBmd(const Eigen::VectorXf &, const Eigen::VectorXf &, size_t, const Eigen::VectorXf &) const
+
+// Som.cpp:457-487
+std::vector<double> Som::findRestrictedBmd(const Eigen::VectorXf &v, const Eigen::VectorXf &, size_t minBmuHits,
+                                           const Eigen::VectorXf &) const
 {
-    VSOM_NOT_IN_SCOPE("Som::findRestrictedBmd");
+    stageOne(v);
+    refreshHost();
+    const size_t N = width * height;
+    std::vector<float> d(N);
+    check(vsom_distances_row(ctx, 0, d.data()), "vsom_distances_row");
+    std::vector<double> dist(N, -1);
+    double C = 0;
+    for (size_t i = 0; i < N; ++i) {
+        if (hHits[i] >= minBmuHits) {
+            dist[i] = (double)d[i];
+            dist[i] = (double)std::exp(-dist[i] * dist[i] / 2);   // :473
+            C += dist[i];
+        } else
+            dist[i] = 0;
+    }
+    for (size_t i = 0; i < N; ++i)
+        dist[i] /= C;
+    return dist;
 }
-double Som::euclidianWeightedDistRaw(const size_t &, const Eigen::VectorXf &, const Eigen::VectorXf &, const Eigen::VectorXf &) const
+
+// Som.cpp:143-157 (the built-in use passes valid = weights = 1; other masks are not supported here)
+double Som::euclidianWeightedDistRaw(const size_t &pos, const Eigen::VectorXf &v, const Eigen::VectorXf &,
+                                     const Eigen::VectorXf &) const
 {
-    VSOM_NOT_IN_SCOPE("Som::euclidianWeightedDistRaw");
+    stageOne(v);
+    uint64_t node = pos, row = 0;
+    float d = 0.f;
+    check(vsom_distances_raw(ctx, &node, &row, 1, 0, &d), "vsom_distances_raw");
+    return (double)d;
 }
-void Som::updateUMatrix(const Eigen::VectorXf &) { VSOM_NOT_IN_SCOPE("Som::updateUMatrix"); }
+
+// Som.cpp:999-1111: mean sigma-normalised distance to the 3/5/8 neighbours, diagonals weighted 0.3
+void Som::updateUMatrix(const Eigen::VectorXf &)
+{
+    requireDevicePath("updateUMatrix");
+    // neighbour offsets in the order the reference adds them for an interior node (:1017-1024):
+    // W, E, S(i+1), N(i-1), NW(i-1,j-1), SW(i+1,j-1), NE(i-1,j+1), SE(i+1,j+1)
+    static const int DI[8] = {0, 0, 1, -1, -1, 1, -1, 1};
+    static const int DJ[8] = {-1, 1, 0, 0, -1, -1, 1, 1};
+    const size_t N = width * height;
+    std::vector<uint64_t> nodes, nbrs;
+    std::vector<int> slot;   // slot[node*8 + k] = index into the pair list or -1
+    slot.assign(N * 8, -1);
+    for (size_t i = 0; i < height; ++i)
+        for (size_t j = 0; j < width; ++j)
+            for (int k = 0; k < 8; ++k) {
+                long ni = (long)i + DI[k], nj = (long)j + DJ[k];
+                if (ni < 0 || nj < 0 || ni >= (long)height || nj >= (long)width)
+                    continue;
+                slot[(i * width + j) * 8 + k] = (int)nodes.size();
+                nodes.push_back(i * width + j);
+                nbrs.push_back((size_t)ni * width + (size_t)nj);
+            }
+    std::vector<float> d(nodes.size());
+    if (!nodes.empty())
+        check(vsom_distances_raw(ctx, nodes.data(), nbrs.data(), nodes.size(), 1, d.data()), "vsom_distances_raw");
+    const double diagonalFactor = 0.3;
+    auto R = [&](size_t n, int k) { return (double)d[(size_t)slot[n * 8 + k]]; };
+    enum { Wk = 0, Ek = 1, Sk = 2, Nk = 3, NWk = 4, SWk = 5, NEk = 6, SEk = 7 };
+    for (size_t i = 0; i < height; ++i)
+        for (size_t j = 0; j < width; ++j) {
+            const size_t n = i * width + j;
+            double u;
+            if (j > 0 && i > 0 && j < (width - 1) && i < (height - 1))
+                u = (R(n, Wk) + R(n, Ek) + R(n, Sk) + R(n, Nk) + R(n, NWk) * diagonalFactor + R(n, SWk) * diagonalFactor +
+                     R(n, NEk) * diagonalFactor + R(n, SEk) * diagonalFactor) / 8;
+            else if (i == 0 && j > 0 && j < (width - 1))
+                u = (R(n, Wk) + R(n, Ek) + R(n, Sk) + R(n, SWk) * diagonalFactor + R(n, SEk) * diagonalFactor) / 5;
+            else if (i == (height - 1) && j > 0 && j < (width - 1))
+                u = (R(n, Wk) + R(n, Ek) + R(n, Nk) + R(n, NWk) * diagonalFactor + R(n, NEk) * diagonalFactor) / 5;
+            else if (j == 0 && i > 0 && i < (height - 1))
+                u = (R(n, Ek) + R(n, Sk) + R(n, Nk) + R(n, NEk) * diagonalFactor + R(n, SEk) * diagonalFactor) / 5;
+            else if (j == (width - 1) && i > 0 && i < (height - 1))
+                u = (R(n, Wk) + R(n, Sk) + R(n, Nk) + R(n, NWk) * diagonalFactor + R(n, SWk) * diagonalFactor) / 5;
+            else if (j == 0 && i == 0)
+                u = (R(n, Ek) + R(n, Sk) + R(n, SEk) * diagonalFactor) / 3;
+            else if (j == (width - 1) && i == 0)
+                u = (R(n, Wk) + R(n, Sk) + R(n, SWk) * diagonalFactor) / 3;
+            else if (j == 0 && i == (height - 1))
+                u = (R(n, Ek) + R(n, Nk) + R(n, NEk) * diagonalFactor) / 3;
+            else if (j == (width - 1) && i == (height - 1))
+                u = (R(n, Wk) + R(n, Nk) + R(n, NWk) * diagonalFactor) / 3;
+            else
+                u = 0;
+            uMatrix[n] = u;
+        }
+}
+
+// Som.cpp:490-523.  The reference's `ones` array is constructed but never filled (ArrayXf(rows,1),
+// :495); it is taken to be all ones here.  log is libm's logf (Eigen's vectorised plog may differ
+// in the last bits).
+double Som::evaluate(const DataSet &data) const
+{
+    requireDevicePath("evaluate");
+    const size_t n = data.size();
+    if (n == 0)
+        return 0.0;
+    refreshHost();
+    check(vsom_upload_chunk(ctx, data.contiguous().data(), n), "vsom_upload_chunk");
+    std::vector<uint64_t> bmu(n);
+    std::vector<float> dist(n);
+    check(vsom_bmu_batch(ctx, bmu.data(), dist.data()), "vsom_bmu_batch");   // findBmu + euclidianWeightedDist(bmu)
+    const Eigen::ArrayXi continuous = data.getContinuous(), binary = data.getBinary();
+    double error = 0;
+    for (size_t i = 0; i < n; i++) {
+        const Eigen::VectorXi validity = data.getValidity(i);
+        const Eigen::VectorXf x = data.getData(i);
+        double bsum = 0;   // binaryError.dot(binaryError)
+        const size_t dlen = std::min<size_t>((size_t)x.size(), depth);
+        float acc = 0.f;
+        for (size_t d = 0; d < dlen; ++d) {
+            const float val = (float)(validity[(Eigen::Index)d] * continuous[(Eigen::Index)d]);
+            const float m = hMap[(size_t)bmu[i] * depth + d];
+            float be = std::log(m) * x[(Eigen::Index)d] + std::log(1.0f - m) * (1.0f - x[(Eigen::Index)d]);
+            if (std::isnan(be) || std::isinf(be))
+                be = -99999.f;                                             // :512
+            be = be * (float)binary[(Eigen::Index)d] * val;                // :514
+            acc += be * be;
+        }
+        bsum = (double)acc;
+        error += 1. / (static_cast<double>(i) + 1.0) * ((double)dist[i] + std::sqrt(bsum) - error);   // :519
+    }
+    return error;
+}
+
+// Som.cpp:631-714
+int Som::measureSimilarity(const DataSet *data, int numOfSigmas, size_t minBmuHits) const
+{
+    requireDevicePath("measureSimilarity");
+    const size_t n = data->size();
+    if (n == 0)
+        return true;
+    refreshHost();
+    check(vsom_upload_chunk(ctx, data->contiguous().data(), n), "vsom_upload_chunk");
+    std::vector<uint64_t> bmus(n);
+    check(vsom_bmu_restricted_batch(ctx, minBmuHits, bmus.data(), nullptr), "vsom_bmu_restricted_batch");
+    bool success = true;
+    float maxValue{-99999999.f};
+    size_t maxValueDataSetRow{0};
+    bool last{false};
+    for (size_t i = 0; i < n + 1; i++) {
+        if (i == n) {
+            i = maxValueDataSetRow;
+            last = true;
+        }
+        const Eigen::VectorXf v = data->getData(i);
+        const size_t pos = (size_t)bmus[i];
+        const Eigen::VectorXi validEigen = data->getValidity(i);
+        for (Eigen::Index d = 0; d < v.size() && (size_t)d < depth; d++) {
+            const float sg = hSigma[pos * depth + (size_t)d], m = hMap[pos * depth + (size_t)d];
+            const float sM = sg > 0.00001f ? 0.00001f : sg;                 // :658 (select as written)
+            float delta = (v[d] - m) / sM / (float)numOfSigmas;            // :671
+            const float mn = m - sM * (float)numOfSigmas, mx = m + sM * (float)numOfSigmas;   // :675-677
+            if (delta > maxValue) {
+                maxValue = static_cast<float>(std::fabs(delta));
+                maxValueDataSetRow = i;
+            }
+            if (validEigen[d] && last)
+                if ((v[d] < mn || v[d] > mx) && validEigen[d])
+                    success = false;
+        }
+        if (last)
+            break;
+    }
+    return success;
+}
+
+// Som.cpp:525-566: draws a model vector from the restricted distribution of each sample; returns the
+// draw of the LAST sample (as the reference does).  Non-deterministic (std::random_device).
+size_t Som::variationalAutoEncoder(const DataSet *data, size_t minBmuHits) const
+{
+    requireDevicePath("variationalAutoEncoder");
+    std::random_device rd;
+    std::mt19937 gen(rd());
+    size_t modelVector{0};
+    for (size_t i = 0; i < data->size(); ++i) {
+        Eigen::VectorXf v = data->getData(i);
+        Eigen::VectorXf val = data->getValidity(i).cast<float>();
+        auto probability = findRestrictedBmd(v, val, minBmuHits, data->getWeights());
+        std::discrete_distribution<size_t> d(probability.begin(), probability.end());
+        modelVector = d(gen);
+    }
+    return modelVector;
+}
+
+// Som.cpp:568-623: prints a logit-approximated normal sample per feature around a drawn model vector
+int Som::autoEncoder(const DataSet *data, size_t minBmuHits) const
+{
+    requireDevicePath("autoEncoder");
+    std::srand((unsigned)(time(NULL) + clock()));
+    for (size_t i = 0; i < data->size(); i++) {
+        Eigen::VectorXf v = data->getData(i);
+        auto bmuInt = variationalAutoEncoder(data, minBmuHits);
+        SomIndex bmu(bmuInt % width, bmuInt / width);
+        const Eigen::VectorXf sg = getSigmaNeuron(bmu), m = getNeuron(bmu);
+        for (Eigen::Index k = 0; k < v.size(); k++) {
+            std::cout << v(k) << "\n";
+            double L = (double)(std::rand() % (int)(1000)) / 1000;
+            double Nn = std::log(L / (1 - L)) / 1.6 * sg[k] + m[k];
+            std::cout << data->getName((size_t)k) << "\t" << Nn << "\t\n";
+        }
+        std::cout << "\n";
+    }
+    return true;
+}
 
 // ---- checkpoint: lossless little-endian binary of this build (the reference's Octave text format,
 //      Som.cpp:1209-1597, is a "next" row) --------------------------------------------------------------

@@ -103,6 +103,45 @@ int main(int argc, char **argv)
         Som loaded{(out + "/ckpt.vsom").c_str()};
         dump(out + "/single_loaded.bin", loaded, {});
     }
+    // ---- consumers of the search: restricted BMU / BMD, U-matrix, evaluate, measureSimilarity ----
+    {
+        ArrayDataLoader loader(rows.data(), NROWS, J);
+        DataSet ds(loader);
+        Som som{W, H, ds, Transformation::Standard(loader.getNames())};
+        som.randomInitialize(21, 1);
+        som.train(ds, 2, 0.0, 0.0, 4.0, 0.2, Som::WeigthDecayFunction::BatchMap);   // gives hits, sigma
+        ds.loadNextDataFromStream();
+        Eigen::VectorXf v(J), ones = Eigen::VectorXf::Ones(J);
+        for (size_t d = 0; d < J; ++d)
+            v[d] = rows[3 * J + d];
+        std::ofstream f(out + "/next_rows.txt");
+        f << som.getIndex(som.findRestrictedBmu(v, ones, 1, ones)) << " " << som.getIndex(som.findRestrictedBmu(v, ones, 3, ones))
+          << " " << som.getIndex(som.findRestrictedBmu(v, ones, 1000, ones)) << "\n";
+        auto bmd = som.findRestrictedBmd(v, ones, 1, ones);
+        std::ofstream fb(out + "/bmd.bin", std::ios::binary);
+        fb.write((const char *)bmd.data(), bmd.size() * 8);
+        som.updateUMatrix(ones);
+        auto um = som.getUMatrix().getData();
+        std::ofstream fu(out + "/umatrix.bin", std::ios::binary);
+        fu.write((const char *)um.data(), um.size() * 8);
+        f << std::hexfloat << som.euclidianWeightedDistRaw(17, v, ones, ones) << " " << som.evaluate(ds) << " "
+          << som.measureSimilarity(&ds, 3, 1) << " " << som.measureSimilarity(&ds, 1000000, 1) << "\n";
+        size_t drawn = som.variationalAutoEncoder(&ds, 1);
+        f << (drawn < W * H ? 1 : 0) << "\n";
+        dump(out + "/next_state.bin", som, {});
+        // CLR U-matrix (perf_tests.cpp:335-352 runs updateUMatrix on a CLR map)
+        auto t = Transformation::CombinatorialLinearRegression({});
+        Som clr{5, 4, t.Length(4), t};
+        clr.randomInitialize(5, 1);
+        std::vector<float> sg(20 * 12);
+        for (size_t k = 0; k < sg.size(); ++k)
+            sg[k] = 0.25f + 0.01f * (float)(k % 7);
+        clr.setState(nullptr, sg.data(), nullptr, nullptr, nullptr);
+        clr.updateUMatrix(Eigen::VectorXf::Ones(12));
+        auto umc = clr.getUMatrix().getData();
+        std::ofstream fc(out + "/umatrix_clr.bin", std::ios::binary);
+        fc.write((const char *)umc.data(), umc.size() * 8);
+    }
     // ---- a custom std::function transformation cannot run on the device: train() reports, no fallback ----
     {
         Transformation custom{.Comparer = [](const Eigen::VectorXf &, const Eigen::VectorXf &m, const Eigen::VectorXf &,
