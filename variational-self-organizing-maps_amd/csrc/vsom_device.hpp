@@ -50,7 +50,7 @@ __device__ __forceinline__ float vsom_group_dist(const float *xa, const float *x
 {
     const int L8 = L & ~7;
     float acc = 0.f;
-#pragma unroll 7
+#pragma unroll 14
     for (int d = k; d < L8; d += 8) {
         float r = vsom_resid<CLR>(xa[d], CLR ? xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
         float p = r * r;
