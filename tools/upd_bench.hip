@@ -293,63 +293,8 @@ __global__ __launch_bounds__(256) void upd_v3(const float *__restrict__ Xs, int 
 }
 
 
-// ---------------- V4: cw loads in inline asm with hand-counted vmcnt (PF-deep ring), x SMEM 1-deep ----------------
-#define VS_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
-template <int RD, int PF>
-__global__ __launch_bounds__(256) void upd_v4(const float *__restrict__ Xs, int ldx, const float2 *__restrict__ cw, int ldn, int B,
-                                             int nloc, int D, int nslices, float *__restrict__ map, float *__restrict__ S_out, int pitch)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int slice = blockIdx.y * 4 + wave;
-    if (slice >= nslices) return;
-    const int d0 = slice * RD;
-    const int nl = blockIdx.x * 64 + lane;
-    float M[RD], S[RD];
-#pragma unroll
-    for (int k = 0; k < RD; ++k) { M[k] = 0.f; S[k] = 0.f; }
-    const float2 *cwp = cw + nl;
-    const size_t rowb = (size_t)ldn * sizeof(float2);
-    cfp xr = (cfp)(Xs + d0);
-    float2 buf[PF];
-    const char *ap = reinterpret_cast<const char *>(cwp);
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        buf[u] = make_float2(0.f, 0.f);
-        asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(buf[u]) : "v"(ap) : "memory");
-        ap += rowb;
-    }
-    float xa[RD], xb[RD];
-    loadx<RD>(xa, xr);
-    for (int j = 0; j < B; j += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; u += 2) {
-            VS_WAIT_LGKM0();
-            __builtin_amdgcn_sched_barrier(0);
-            loadx<RD>(xb, xr + (size_t)(j + u + 1) * ldx);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(buf[u]) : "n"(PF - 1) : "memory");
-            step<RD>(M, S, xa, buf[u].x, buf[u].y);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(buf[u]) : "v"(ap) : "memory");
-            ap += rowb;
-            VS_WAIT_LGKM0();
-            __builtin_amdgcn_sched_barrier(0);
-            loadx<RD>(xa, xr + (size_t)(j + u + 2) * ldx);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(buf[u + 1]) : "n"(PF - 1) : "memory");
-            step<RD>(M, S, xb, buf[u + 1].x, buf[u + 1].y);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("global_load_dwordx2 %0, %1, off" : "+v"(buf[u + 1]) : "v"(ap) : "memory");
-            ap += rowb;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < RD; ++k)
-        if (d0 + k < D) { map[(size_t)nl * pitch + d0 + k] = M[k]; S_out[(size_t)nl * pitch + d0 + k] = S[k]; }
-}
-
+// (V4, an inline-asm ring of loads inside a HIP loop, faulted on the GPU: hipcc re-orders around the
+//  asm statements; the ring lives in the generated assembly kernel instead -- csrc/gen_update_asm.py)
 
 // ---------------- V5: x and cw tiles through LDS by global_load_lds (DMA), 2 buffers ----------------
 template <int RD, int TJ, int WPB>

@@ -112,6 +112,4 @@ int launch_row_dist(vsom_ctx *c, size_t row, float *out_dev);
 int launch_raw_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *vrows_dev, size_t count, int from_map,
                     float *out_dev);
 int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1);
-int launch_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn, size_t B,
-                        const float *x_dev_padded, bool single);
 int ensure_lut(vsom_ctx *c, double sigma);
