@@ -144,6 +144,8 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    with torch.cuda.stream(stream):
+        trainer.flush()
     torch.cuda.synchronize()
     ctx.get_timing(reset=True)
     ctx.enable_timing(True)
@@ -153,6 +155,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    with torch.cuda.stream(stream):
+        trainer.flush()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -66,6 +66,7 @@ def _worker(rank, world, port, case, ret):
         for ep, first in enumerate((True, False)):
             eng.load_chunk(X)
             tr_.epoch(sigma, first)
+            tr_.flush()
             out[f"lb{ep}"] = eng._lb.copy()
             out[f"mse{ep}"] = np.float32(eng._mse)
         out.update(map=eng.o.map.copy(), sigma=eng.o.sigma.copy(), weight=eng.o.weight.copy(),

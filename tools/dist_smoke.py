@@ -20,14 +20,17 @@ stream = torch.cuda.Stream(device=dev)
 ctx = vsom_amd.Context(W, H, D); ctx.set_state(map=init); ctx.set_stream(stream.cuda_stream)
 eng = vdist.HipEngine(ctx, dev)
 xt = torch.from_numpy(X).to(dev)
-def forced(t, world, rank, group=None):
-    dist.all_gather_into_tensor(t, t.clone(), group=group)       # world 1: gathers onto itself
-    dist.broadcast(t, src=0, group=group)
+def forced(t, world, rank, group=None, async_op=False):
+    src = t.clone()
+    w1 = dist.all_gather_into_tensor(t, src, group=group, async_op=async_op)   # world 1: gathers onto itself
+    w2 = dist.broadcast(t, src=0, group=group, async_op=async_op)
+    return [(w1, src), (w2, None)] if async_op else []
 vdist._gather_rows = forced
 tr = vdist.ShardedBatchTrainer(eng, 0, 1)
 with torch.cuda.stream(stream):
     eng.load_chunk_device(xt)
     tr.epoch(5.0, True)
+    tr.flush()
 torch.cuda.synchronize()
 ref = vsom_amd.Context(W, H, D); ref.set_state(map=init); ref.upload_chunk(X); ref.batch_epoch(5.0, True)
 a, b = ctx.get_state(), ref.get_state()

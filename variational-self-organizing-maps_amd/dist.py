@@ -80,19 +80,27 @@ class HipEngine:
         return self.ctx.get_mse()
 
 
-def _gather_rows(t, world, rank, group=None):
-    """All ranks end up with every rank's contiguous row shard of `t` (dim 0), in place."""
+def _gather_rows(t, world, rank, group=None, async_op=False):
+    """All ranks end up with every rank's contiguous row shard of `t` (dim 0), in place.
+    With async_op the collective is only enqueued; returns what must be kept alive / waited on."""
     total = t.shape[0]
     if world == 1:
-        return
+        return []
+    pending = []
     if total % world == 0:
         lo, hi = shard_bounds(total, world, rank)
-        dist.all_gather_into_tensor(t, t[lo:hi].clone(), group=group)
+        src = t[lo:hi].clone()
+        w = dist.all_gather_into_tensor(t, src, group=group, async_op=async_op)
+        if async_op:
+            pending.append((w, src))
     else:
         for r in range(world):
             lo, hi = shard_bounds(total, world, r)
             if hi > lo:
-                dist.broadcast(t[lo:hi], src=r, group=group)
+                w = dist.broadcast(t[lo:hi], src=r, group=group, async_op=async_op)
+                if async_op:
+                    pending.append((w, None))
+    return pending
 
 
 class ShardedBatchTrainer:
@@ -101,6 +109,13 @@ class ShardedBatchTrainer:
 
     def __init__(self, engine, rank=0, world=1, group=None):
         self.e, self.rank, self.world, self.group = engine, rank, world, group
+        self._pending = []
+
+    def flush(self):
+        """Wait for the sigmaMap / weightMap gathers of the last epoch (call before reading state)."""
+        for work, _keep in self._pending:
+            work.wait()
+        self._pending = []
 
     def epoch(self, sigma, is_first):
         e, w, r = self.e, self.world, self.rank
@@ -110,10 +125,12 @@ class ShardedBatchTrainer:
         _gather_rows(e.sqres, w, r, self.group)       # B x 4 B
         e.finish()
         n0, n1 = shard_bounds(e.N, w, r)
+        self.flush()                                  # phase 2 rewrites the rows the last gathers read
         e.phase2(sigma, n0, n1)
-        _gather_rows(e.map_rows, w, r, self.group)    # N x pitch x 4 B
-        _gather_rows(e.sigma_rows, w, r, self.group)
-        _gather_rows(e.weight, w, r, self.group)
+        _gather_rows(e.map_rows, w, r, self.group)    # N x pitch x 4 B: the next search needs it now
+        # sigmaMap / weightMap are not read by the next phase 1: gather them behind it
+        self._pending += _gather_rows(e.sigma_rows, w, r, self.group, async_op=True)
+        self._pending += _gather_rows(e.weight, w, r, self.group, async_op=True)
 
 
 class OracleEngineBase:
