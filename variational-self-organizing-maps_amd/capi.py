@@ -126,6 +126,11 @@ def device_count():
     return int(lib().vsom_device_count())
 
 
+def model_length(transform, in_len):
+    """Transformation::Length (Transformation.cpp:33-36,71-74,162-165): J, or J(J-1) for CLR."""
+    return int(in_len) * (int(in_len) - 1) if int(transform) == CLR else int(in_len)
+
+
 def neighbourhood_weight(cx, cy, bx, by, sigma):
     return float(lib().vsom_neighbourhood_weight(cx, cy, bx, by, float(sigma)))
 
