@@ -600,25 +600,49 @@ int launch_raw_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *vrows_dev, siz
 // ------------------------------------------------------------------------------------------
 // finish: bmuHits and MSE (Som.cpp:777-781 / 800-804), sample order fixed (Q13)
 // ------------------------------------------------------------------------------------------
-#define FIN_TILE 4096
+#define FIN_TILE 8192
 __global__ __launch_bounds__(256) void finish_kernel(const u64 *__restrict__ lastbmu,
                                                      const float *__restrict__ sqres, int B,
                                                      u64 *__restrict__ hits, float *__restrict__ mse)
 {
-    __shared__ float q[FIN_TILE];
+    // the running sum is serial by definition (fp32, sample order); everything around it is not:
+    // 255 threads fill the next tile (divisions, bmuHits atomics) while thread 0 adds the current
+    // one out of LDS, 16 values (4 x ds_read_b128) per dependent burst.
+    __shared__ __attribute__((aligned(16))) float q[2][FIN_TILE];
     const float fB = (float)B;
     float run = 0.f;
-    for (int base = 0; base < B; base += FIN_TILE) {
-        int n = B - base < FIN_TILE ? B - base : FIN_TILE;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int ntiles = (B + FIN_TILE - 1) / FIN_TILE;
+    auto fill = [&](int t) {
+        const int base = t * FIN_TILE;
+        const int n = B - base < FIN_TILE ? B - base : FIN_TILE;
+        float *dst = q[t & 1];
+        for (int i = (int)threadIdx.x - 1; i < n; i += (int)blockDim.x - 1) {   // threads 1..255 only
             u64 idx = lastbmu[base + i];
-            atomicAdd(&hits[idx], 1ull);
-            q[i] = sqres[base + i] / fB;   // residual.squaredNorm() / (float)epochSize
+            atomicAdd(&hits[idx], 1ull);           // bmuHits[idx]++            :778
+            dst[i] = sqres[base + i] / fB;         // squaredNorm()/(float)epochSize :781
         }
-        __syncthreads();
+    };
+    if (threadIdx.x != 0)
+        fill(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
         if (threadIdx.x == 0) {
-            for (int i = 0; i < n; ++i)
-                run = run + q[i];
+            const int base = t * FIN_TILE;
+            const int n = B - base < FIN_TILE ? B - base : FIN_TILE;
+            const float *src = q[t & 1];
+            int i = 0;
+            for (; i + 16 <= n; i += 16) {
+                const float4 a = *(const float4 *)(src + i), b = *(const float4 *)(src + i + 4),
+                             cc = *(const float4 *)(src + i + 8), d = *(const float4 *)(src + i + 12);
+                run = run + a.x; run = run + a.y; run = run + a.z; run = run + a.w;
+                run = run + b.x; run = run + b.y; run = run + b.z; run = run + b.w;
+                run = run + cc.x; run = run + cc.y; run = run + cc.z; run = run + cc.w;
+                run = run + d.x; run = run + d.y; run = run + d.z; run = run + d.w;
+            }
+            for (; i < n; ++i)
+                run = run + src[i];
+        } else if (t + 1 < ntiles) {
+            fill(t + 1);
         }
         __syncthreads();
     }

@@ -134,6 +134,8 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
     c->xpitch = roundup(c->J, VSOM_TK);
     if (const char *e = std::getenv("VSOM_NO_ASM"))
         c->use_asm = !(e[0] == '1');   // debugging aid: HIP update kernel instead of the hand-scheduled one
+    if (const char *e = std::getenv("VSOM_NO_CHAIN"))
+        c->use_chain = !(e[0] == '1');  // debugging aid: lane = node update kernel on small maps too
 
     int rc = VSOM_OK;
     do {

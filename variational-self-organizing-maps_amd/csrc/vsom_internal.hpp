@@ -20,6 +20,10 @@
 
 typedef unsigned long long u64;
 
+// lane = node update kernels yield ceil(N/64)*ceil(D/16) wavefronts; at or below this many the
+// (node, dim)-per-lane chain kernel is used instead (1024 SIMDs on the chip)
+#define VSOM_CHAIN_MAX_WAVES 256
+
 #define VSOM_TK 32          // K-chunk of the tile kernels; row pitches are multiples of it
 
 struct vsom_ctx {
@@ -68,6 +72,7 @@ struct vsom_ctx {
     void *upd_module = nullptr, *upd_fn16 = nullptr, *upd_fn14 = nullptr, *upd_fma16 = nullptr, *upd_fma14 = nullptr;
     int update_mode = VSOM_UPDATE_STRICT;
     bool use_asm = true;
+    bool use_chain = true;
 
     // online path scratch
     float *v_dev = nullptr;         // one sample, padded

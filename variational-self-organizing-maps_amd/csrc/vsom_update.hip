@@ -116,10 +116,78 @@ __global__ __launch_bounds__(256) void cw_kernel(const int2 *__restrict__ bxy, i
         weight[node] = run;   // :875
 }
 
+// Same chain with 16 lanes per node (4 nodes per wavefront, N/4 wavefronts) for maps too small to
+// occupy the chip with quads: lane q of a group looks up / divides / stores sample j+q of each
+// round of 16; the serial prefix runs redundantly in all 16 lanes, fed by ds_bpermute broadcasts.
+template <bool LUT_LDS>
+__global__ __launch_bounds__(256) void cw16_kernel(const int2 *__restrict__ bxy, int B, int n0, int n1,
+                                                   int W, int H, const float *__restrict__ lut,
+                                                   int lutw, int luth, float2 *__restrict__ cw, int ldn,
+                                                   float *__restrict__ weight)
+{
+    extern __shared__ float slut[];
+    if (LUT_LDS) {
+        for (int i = threadIdx.x; i < lutw * luth; i += blockDim.x)
+            slut[i] = lut[i];
+        __syncthreads();
+    }
+    const float *tab = LUT_LDS ? slut : lut;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = gid & 15;
+    const int nl = gid >> 4;
+    const int node = n0 + nl;
+    const bool valid = node < n1;
+    int cx = 0, cy = 0;
+    if (valid)
+        vsom_somindex((u64)node, (u64)W, (u64)H, cx, cy);   // SomIndex(*this, index) (Som.cpp:816)
+    float run = 0.f;                                         // sumOfWeights :840
+    const int nlo = valid ? nl : 0;
+    const int B16 = B & ~15;
+    int j = 0;
+    int2 b = B16 > 0 ? bxy[q] : make_int2(0, 0);
+    for (; j < B16; j += 16) {
+        int dx = cx - b.x, dy = cy - b.y;
+        dx = dx < 0 ? -dx : dx;
+        dy = dy < 0 ? -dy : dy;
+        const float w = tab[dy * lutw + dx];     // (float)calculateNeighbourhoodWeight(...)  :851
+        if (j + 16 < B16)
+            b = bxy[j + 16 + q];
+        float wk[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            wk[k] = __shfl(w, k, 16);
+        float Wm = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            run = run + wk[k];                   // :857, samples j..j+15 in order
+            Wm = q == k ? run : Wm;
+        }
+        if (valid)
+            cw[cw2_index(j + q, ldn, nlo)] = make_float2(w / Wm, w);   // c = w/W :864 (0/0 -> NaN, Q7)
+    }
+    for (; j < B; ++j) {   // tail, every lane of the group redundantly; lane 0 stores
+        int2 bb = bxy[j];
+        int dx = cx - bb.x, dy = cy - bb.y;
+        dx = dx < 0 ? -dx : dx;
+        dy = dy < 0 ? -dy : dy;
+        float w = tab[dy * lutw + dx];
+        run = run + w;
+        if (valid && q == 0)
+            cw[cw2_index(j, ldn, nlo)] = make_float2(w / run, w);
+    }
+    if (valid && q == 0)
+        weight[node] = run;   // :875
+}
+
 // Eigen scalar_sign_op<float>: NaN -> NaN, else (a>0)-(a<0) as float (Transformation.cpp:50)
 __device__ __forceinline__ float vsom_sign(float a)
 {
-    return a > 0.f ? 1.f : (a < 0.f ? -1.f : (a != a ? a : 0.f));
+    // straight-line selects (v_cmp + v_cndmask, no exec-mask branches): a + 0.f is +0 for +-0 and
+    // NaN for NaN (not foldable under strict IEEE semantics), then the two signs override it
+    float s = a + 0.f;
+    s = a > 0.f ? 1.f : s;
+    s = a < 0.f ? -1.f : s;
+    return s;
 }
 
 // Standard / Median: lane = node, RD dims per lane, 4 waves per workgroup = 4 dim slices
@@ -175,6 +243,104 @@ __global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ X
                 sigma[node * pitch + d0 + k] = sqrtf(S[k] / Wf);     // :873
             }
         }
+    }
+}
+
+// Standard / Median on maps whose node count cannot fill the chip with lane = node (fewer than a
+// few hundred wavefronts, e.g. C4: 64x64x32): lane = one (node, dim) chain.  A group of DL =
+// 2^dl_log2 consecutive lanes covers DL consecutive dims of one node (x is a coalesced row
+// segment, (c,w) a same-address broadcast), 256/DL nodes per workgroup, blockIdx.y = dim slice.
+// Loads of the next U samples are issued before the current U are consumed.  Same fp32 operation
+// sequence per chain as update_kernel, so the results are bit-identical.
+template <bool MEDIAN, int U, bool FMA>
+__global__ __launch_bounds__(256) void update_chain_kernel(const float *__restrict__ Xs, int ldx,
+                                                           const float2 *__restrict__ cw, int ldn, int B,
+                                                           int n0, int nloc, int D, int dl_log2,
+                                                           float *__restrict__ map,
+                                                           float *__restrict__ sigma, int pitch,
+                                                           const float *__restrict__ weight)
+{
+    static_assert(U % 2 == 0, "pairs of samples share one float4 of (c,w)");
+    const int DL = 1 << dl_log2;
+    const int nl = blockIdx.x * (256 >> dl_log2) + ((int)threadIdx.x >> dl_log2);
+    const int d = blockIdx.y * DL + ((int)threadIdx.x & (DL - 1));
+    const bool valid = nl < nloc && d < D;
+    const int nlc = nl < nloc ? nl : nloc - 1;
+    const int dc = d < D ? d : D - 1;
+
+    const float *xp = Xs + dc;
+    const float4 *cp = (const float4 *)cw + nlc;      // pair row r at cp[r * ldn]
+    float M = 0.f, S = 0.f;                           // :843-844
+
+    // two register sets used alternately (no copies): while one is consumed the loads of the
+    // following group are already in flight into the other
+    float xa[U], xb[U];
+    float4 ca[U / 2], cb[U / 2];
+    const int nfull = B / U;
+    auto load = [&](float (&x)[U], float4 (&cv)[U / 2], int g) {
+        // clamped to the last full group: re-reads it, never past the buffers
+        g = g < nfull ? g : nfull - 1;
+        const float *xq = xp + (size_t)g * U * ldx;
+        const float4 *cq = cp + (size_t)g * (U / 2) * ldn;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            x[u] = xq[(size_t)u * ldx];
+#pragma unroll
+        for (int u = 0; u < U / 2; ++u)
+            cv[u] = cq[(size_t)u * ldn];
+    };
+    auto steps = [&](const float (&x)[U], const float4 (&cv)[U / 2]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float c = (u & 1) ? cv[u >> 1].z : cv[u >> 1].x;
+            const float w = (u & 1) ? cv[u >> 1].w : cv[u >> 1].y;
+            float dl = x[u] - M;            // Stepper (Transformation.cpp:12 / :50)
+            if (MEDIAN)
+                dl = vsom_sign(dl);
+            if (FMA) {                      // opt-in contracted arithmetic (VSOM_UPDATE_FMA)
+                M = __builtin_fmaf(c, dl, M);
+                S = __builtin_fmaf(w * dl, dl, S);
+            } else {
+                float t = c * dl;
+                M = M + t;                  // :864
+                float s = w * dl;
+                s = s * dl;
+                S = S + s;                  // :867
+            }
+        }
+    };
+    if (nfull > 0)
+        load(xa, ca, 0);
+    int g = 0;
+    for (; g + 2 <= nfull; g += 2) {
+        load(xb, cb, g + 1);
+        steps(xa, ca);
+        load(xa, ca, g + 2);
+        steps(xb, cb);
+    }
+    if (g < nfull)
+        steps(xa, ca);
+    for (int j = nfull * U; j < B; ++j) {
+        const float2 v = cw[cw2_index(j, ldn, nlc)];
+        float dl = xp[(size_t)j * ldx] - M;
+        if (MEDIAN)
+            dl = vsom_sign(dl);
+        if (FMA) {
+            M = __builtin_fmaf(v.x, dl, M);
+            S = __builtin_fmaf(v.y * dl, dl, S);
+        } else {
+            float t = v.x * dl;
+            M = M + t;
+            float s = v.y * dl;
+            s = s * dl;
+            S = S + s;
+        }
+    }
+    if (valid) {
+        const size_t node = (size_t)(n0 + nl);
+        const float Wf = weight[node];
+        map[node * pitch + d] = M;                   // :870
+        sigma[node * pitch + d] = sqrtf(S / Wf);     // :873
     }
 }
 
@@ -370,14 +536,14 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         hipLaunchKernelGGL(bxy_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, c->stream,
                            c->lastbmu, (int)c->B, (int)c->W, (int)c->H, c->bxy);
         const size_t lut_bytes = (size_t)c->lut_w * c->lut_h * sizeof(float);
-        if (lut_bytes <= 64 * 1024)
-            hipLaunchKernelGGL(cw_kernel<true>, dim3((unsigned)((nloc * 4 + 255) / 256)), dim3(256), lut_bytes,
-                               c->stream, c->bxy, (int)c->B, (int)n0, (int)n1, (int)c->W, (int)c->H, c->lut,
-                               (int)c->lut_w, (int)c->lut_h, c->cw, (int)ldn, c->weight);
-        else
-            hipLaunchKernelGGL(cw_kernel<false>, dim3((unsigned)((nloc * 4 + 255) / 256)), dim3(256), 0,
-                               c->stream, c->bxy, (int)c->B, (int)n0, (int)n1, (int)c->W, (int)c->H, c->lut,
-                               (int)c->lut_w, (int)c->lut_h, c->cw, (int)ldn, c->weight);
+        const bool lds = lut_bytes <= 64 * 1024;
+        // quads give nloc/16 wavefronts; below one per SIMD use 16 lanes per node (nloc/4 wavefronts)
+        const bool wide = nloc / 16 < 1024 && c->B >= 64;
+        auto kern = wide ? (lds ? cw16_kernel<true> : cw16_kernel<false>) : (lds ? cw_kernel<true> : cw_kernel<false>);
+        const size_t lanes = nloc * (wide ? 16 : 4);
+        hipLaunchKernelGGL(kern, dim3((unsigned)((lanes + 255) / 256)), dim3(256), lds ? lut_bytes : 0, c->stream,
+                           c->bxy, (int)c->B, (int)n0, (int)n1, (int)c->W, (int)c->H, c->lut, (int)c->lut_w,
+                           (int)c->lut_h, c->cw, (int)ldn, c->weight);
         VSOM_HIP_CHECK(hipGetLastError());
     }
     int sig_cols = 0;   // columns left as raw S by the assembly kernel
@@ -391,6 +557,20 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
             hipLaunchKernelGGL(update_clr_kernel<RP>, grid, dim3(256), 0, c->stream, c->XP, c->YP,
                                (int)c->part_pitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
                                (int)c->part_len, (int)c->part_pitch, nsl, c->map, c->sigma,
+                               (int)c->pitch, c->weight);
+        } else if ((size_t)gx * ((c->D + 15) / 16) <= VSOM_CHAIN_MAX_WAVES && c->use_chain) {
+            // lane = node would leave most SIMDs idle: one lane per (node, dim) chain instead
+            int dl_log2 = 0;
+            while ((1u << dl_log2) < c->D && dl_log2 < 6)
+                ++dl_log2;
+            const unsigned DL = 1u << dl_log2;
+            dim3 grid((unsigned)((nloc + (256 / DL) - 1) / (256 / DL)), (c->D + DL - 1) / DL);
+            constexpr int U = 8;
+            auto kern = c->transform == VSOM_MEDIAN ? update_chain_kernel<true, U, false>
+                        : (c->update_mode == VSOM_UPDATE_FMA ? update_chain_kernel<false, U, true>
+                                                             : update_chain_kernel<false, U, false>);
+            hipLaunchKernelGGL(kern, grid, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->cw, (int)ldn,
+                               (int)c->B, (int)n0, (int)nloc, (int)c->D, dl_log2, c->map, c->sigma,
                                (int)c->pitch, c->weight);
         } else {
             constexpr int RD = 16;
