@@ -216,7 +216,7 @@ def main():
             "mse_last": mse,
             "bmu_shortlist_last": sl_stats,
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # the CPU leg runs at N=1 only (contract)
             out["cpu_baseline"] = cpu_baseline(args, chunks_host[0][:Bper], init_map)
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -8,7 +8,7 @@
 //  bmu_local_kernel  : Som::findLocalBmu (Som.cpp:335-454), one wavefront per sample,
 //                      8 candidates x 8 accumulator classes across the 64 lanes.
 //  pair_dist_kernel  : Som::euclidianWeightedDist for arbitrary (node,row) pairs.
-//  finish_kernel     : bmuHits[idx] += 1 and the fp32 MSE running sum in sample order
+//  hits/mse_kernel   : bmuHits[idx] += 1 and the fp32 MSE running sum in sample order
 //                      (Som.cpp:777-781).
 //  stage kernels     : chunk re-layout (zero-padded rows; CLR x'/y' expansion).
 #include "vsom_device.hpp"
@@ -600,14 +600,31 @@ int launch_raw_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *vrows_dev, siz
 // ------------------------------------------------------------------------------------------
 // finish: bmuHits and MSE (Som.cpp:777-781 / 800-804), sample order fixed (Q13)
 // ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hits_kernel(const u64 *__restrict__ lastbmu, int B, u64 *__restrict__ hits)
+{
+    // bmuHits[idx]++ (:778).  BMUs cluster on few nodes, and same-address atomics serialise in L2:
+    // each wavefront first merges its equal indices (one atomic per distinct value).
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < B;
+    const u64 idx = in ? lastbmu[i] : 0;
+    bool todo = in;
+    while (__any(todo)) {
+        const u64 lead = __shfl(idx, __ffsll((long long)__ballot(todo)) - 1);
+        const bool mine = todo && idx == lead;
+        const u64 m = __ballot(mine);
+        if (mine && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)
+            atomicAdd(&hits[lead], (u64)__popcll(m));
+        todo = todo && !mine;
+    }
+}
+
 #define FIN_TILE 8192
-__global__ __launch_bounds__(256) void finish_kernel(const u64 *__restrict__ lastbmu,
-                                                     const float *__restrict__ sqres, int B,
-                                                     u64 *__restrict__ hits, float *__restrict__ mse)
+__global__ __launch_bounds__(1024) void mse_kernel(const float *__restrict__ sqres, int B,
+                                                   float *__restrict__ mse)
 {
     // the running sum is serial by definition (fp32, sample order); everything around it is not:
-    // 255 threads fill the next tile (divisions, bmuHits atomics) while thread 0 adds the current
-    // one out of LDS, 16 values (4 x ds_read_b128) per dependent burst.
+    // the other threads fill the next tile (divisions) while thread 0 adds the current one out of
+    // LDS, 16 values (4 x ds_read_b128) per dependent burst.
     __shared__ __attribute__((aligned(16))) float q[2][FIN_TILE];
     const float fB = (float)B;
     float run = 0.f;
@@ -616,13 +633,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const u64 *__restrict__ las
         const int base = t * FIN_TILE;
         const int n = B - base < FIN_TILE ? B - base : FIN_TILE;
         float *dst = q[t & 1];
-        for (int i = (int)threadIdx.x - 1; i < n; i += (int)blockDim.x - 1) {   // threads 1..255 only
-            u64 idx = lastbmu[base + i];
-            atomicAdd(&hits[idx], 1ull);           // bmuHits[idx]++            :778
+        for (int i = (int)threadIdx.x - 64; i < n; i += (int)blockDim.x - 64)   // wavefronts 1.. only
             dst[i] = sqres[base + i] / fB;         // squaredNorm()/(float)epochSize :781
-        }
     };
-    if (threadIdx.x != 0)
+    if (threadIdx.x >= 64)
         fill(0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
@@ -641,7 +655,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const u64 *__restrict__ las
             }
             for (; i < n; ++i)
                 run = run + src[i];
-        } else if (t + 1 < ntiles) {
+        } else if (threadIdx.x >= 64 && t + 1 < ntiles) {
             fill(t + 1);
         }
         __syncthreads();
@@ -652,9 +666,28 @@ __global__ __launch_bounds__(256) void finish_kernel(const u64 *__restrict__ las
 
 int launch_finish(vsom_ctx *c)
 {
-    TimerScope ts(c, VSOM_T_FINISH);
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, c->stream, c->lastbmu, c->sqres,
-                       (int)c->B, c->hits, c->mse);
+    {
+        TimerScope ts(c, VSOM_T_FINISH);
+        hipLaunchKernelGGL(hits_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, c->stream, c->lastbmu,
+                           (int)c->B, c->hits);
+        VSOM_HIP_CHECK(hipGetLastError());
+    }
+    // the serial MSE sum (~5 ns per sample) reads sqres and writes mse only: it runs on the side
+    // stream beside phase 2 and is joined at the end of launch_phase2 / by the next entry point
+    VSOM_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
+    VSOM_HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, c->aux_stream, c->sqres, (int)c->B, c->mse);
     VSOM_HIP_CHECK(hipGetLastError());
+    VSOM_HIP_CHECK(hipEventRecord(c->ev_join, c->aux_stream));
+    c->aux_pending = true;
+    return VSOM_OK;
+}
+
+int vsom_join_aux(vsom_ctx *c)
+{
+    if (c->aux_pending) {
+        VSOM_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        c->aux_pending = false;
+    }
     return VSOM_OK;
 }

@@ -48,6 +48,17 @@ static inline uint32_t roundup(uint32_t v, uint32_t m) { return (v + m - 1) / m 
         hipError_t _e = hipSetDevice((ctx)->device);                   \
         if (_e != hipSuccess)                                          \
             return vsom_fail(VSOM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_e)); \
+        if (int _rc = vsom_join_aux(ctx))                              \
+            return _rc;                                                \
+    } while (0)
+// phase 2 runs beside the side stream's work and joins it at its end
+#define CHECK_CTX_NOJOIN(ctx)                                          \
+    do {                                                               \
+        if (!(ctx))                                                    \
+            return vsom_fail(VSOM_ERR_INVALID, "null context");        \
+        hipError_t _e = hipSetDevice((ctx)->device);                   \
+        if (_e != hipSuccess)                                          \
+            return vsom_fail(VSOM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_e)); \
     } while (0)
 
 extern "C" {
@@ -84,6 +95,14 @@ static int free_all(vsom_ctx *c)
     }
     if (c->upd_module)
         (void)hipModuleUnload((hipModule_t)c->upd_module);
+    if (c->aux_stream) {
+        (void)hipStreamSynchronize(c->aux_stream);
+        (void)hipStreamDestroy(c->aux_stream);
+    }
+    if (c->ev_fork)
+        (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join)
+        (void)hipEventDestroy(c->ev_join);
     if (c->own_stream)
         (void)hipStreamDestroy(c->own_stream);
     return 0;
@@ -134,12 +153,17 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
     c->xpitch = roundup(c->J, VSOM_TK);
     if (const char *e = std::getenv("VSOM_NO_ASM"))
         c->use_asm = !(e[0] == '1');   // debugging aid: HIP update kernel instead of the hand-scheduled one
+    if (const char *e = std::getenv("VSOM_CW_MODE"))
+        c->cw_mode = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);
     if (const char *e = std::getenv("VSOM_NO_CHAIN"))
         c->use_chain = !(e[0] == '1');  // debugging aid: lane = node update kernel on small maps too
 
     int rc = VSOM_OK;
     do {
-        if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
             rc = vsom_fail(VSOM_ERR_HIP, "hipStreamCreate failed");
             break;
         }
@@ -197,6 +221,8 @@ void vsom_destroy(vsom_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream)
+        (void)hipStreamSynchronize(c->aux_stream);
     free_all(c);
     delete c;
 }
@@ -560,7 +586,7 @@ int vsom_batch_finish_async(vsom_ctx *c)
 
 int vsom_batch_phase2_async(vsom_ctx *c, double sigma, size_t n0, size_t n1)
 {
-    CHECK_CTX(c);
+    CHECK_CTX_NOJOIN(c);
     if (n0 > n1 || n1 > c->N)
         return vsom_fail(VSOM_ERR_INVALID, "node range out of bounds");
     if (c->B == 0)

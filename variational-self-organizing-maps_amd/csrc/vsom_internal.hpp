@@ -35,6 +35,10 @@ struct vsom_ctx {
     int bmu_mode = VSOM_BMU_AUTO;
 
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // side stream for work that only has to finish before the next entry point (the MSE sum)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool aux_pending = false;
 
     // model state
     float *map = nullptr, *sigma = nullptr, *S = nullptr, *weight = nullptr;
@@ -73,6 +77,7 @@ struct vsom_ctx {
     int update_mode = VSOM_UPDATE_STRICT;
     bool use_asm = true;
     bool use_chain = true;
+    int cw_mode = 0;                // 0 role-split kernel, 1 quad kernel, 2 16-lane kernel (VSOM_CW_MODE, debugging)
 
     // online path scratch
     float *v_dev = nullptr;         // one sample, padded
@@ -112,6 +117,7 @@ int launch_bmu_local(vsom_ctx *c, size_t s0, size_t s1);          // findLocalBm
 int launch_pair_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *rows_dev, size_t count,
                      float *out_dev);
 int launch_finish(vsom_ctx *c);
+int vsom_join_aux(vsom_ctx *c);      // make ctx->stream wait for the side stream's pending work
 int launch_bmu_restricted(vsom_ctx *c, u64 min_hits);
 int launch_row_dist(vsom_ctx *c, size_t row, float *out_dev);
 int launch_raw_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *vrows_dev, size_t count, int from_map,

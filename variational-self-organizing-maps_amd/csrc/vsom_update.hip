@@ -179,6 +179,156 @@ __global__ __launch_bounds__(256) void cw16_kernel(const int2 *__restrict__ bxy,
         weight[node] = run;   // :875
 }
 
+// Role-split neighbourhood chain: one workgroup (9 wavefronts) serves NW nodes and walks the chunk
+// in tiles of T samples (NW*T = 2048) through LDS.  Wavefront 0 does nothing but the serial part --
+// the fp32 prefix W_j = W_{j-1} + w_j of tile t (one LDS read, one add, one LDS write per sample);
+// wavefronts 1..8 meanwhile look up w for tile t+1 and turn tile t-1 into (c = w/W, w) pairs,
+// stored as one float4 per node and sample pair.  No redundant chain work, so the time per
+// workgroup is the chain's own ~B dependent adds instead of B x (lookup + division + chain).
+#define CWP_WT 512                               // worker threads
+#define CWP_THREADS (64 + CWP_WT)
+template <int NW, int T, bool LUT_LDS>
+__global__ __launch_bounds__(CWP_THREADS) void cwp_kernel(const int2 *__restrict__ bxy, int B, int n0, int n1,
+                                                          int W, int H, const float *__restrict__ lut,
+                                                          int lutw, int luth, float2 *__restrict__ cw, int ldn,
+                                                          float *__restrict__ weight)
+{
+    static_assert(NW * T == 2048 && CWP_WT % NW == 0 && T % 2 == 0 && T <= CWP_WT, "worker mapping");
+    constexpr int LK = NW * T / CWP_WT;          // lookups per worker thread and tile (4)
+    constexpr int PK = LK / 2;                   // sample pairs per worker thread and tile (2)
+    constexpr int SS = CWP_WT / NW;              // sample stride between a thread's elements
+    extern __shared__ __attribute__((aligned(16))) unsigned char cwp_smem[];
+    float *wL = (float *)cwp_smem;               // [3][T][NW]  w of tiles t-1, t, t+1
+    float *WL = wL + 3 * T * NW;                 // [2][T][NW]  prefix sums of tiles t-1, t
+    int2 *bL = (int2 *)(WL + 2 * T * NW);        // [3][T]      BMU coordinates of tiles t .. t+2
+    float *slut = (float *)(bL + 3 * T);
+    const int tid = threadIdx.x;
+    if (LUT_LDS) {
+        for (int i = tid; i < lutw * luth; i += CWP_THREADS)
+            slut[i] = lut[i];
+    }
+    const float *tab = LUT_LDS ? slut : lut;
+    const int ntiles = (B + T - 1) / T;
+    const int nloc = n1 - n0;
+    const int wt = tid - 64;                     // worker thread 0..511 (wavefronts 1..8)
+    const int lnode = (wt < 0 ? tid : wt) & (NW - 1);
+    const int s0 = wt < 0 ? 0 : wt / NW;         // first sample (lookup) / pair (emit) of this thread
+    const int nl = blockIdx.x * NW + lnode;
+    const bool valid = nl < nloc;
+    int cx = 0, cy = 0;
+    if (valid)
+        vsom_somindex((u64)(n0 + nl), (u64)W, (u64)H, cx, cy);   // SomIndex(*this, index) (Som.cpp:816)
+
+    auto load_bxy = [&](int t) {                 // workers: coordinates of tile t -> ring slot t%3
+        if (t < ntiles && wt < T) {
+            const int j = t * T + wt;
+            bL[(t % 3) * T + wt] = j < B ? bxy[j] : make_int2(0, 0);
+        }
+    };
+    // Both worker stages read everything first and write afterwards: the compiler does not move LDS
+    // reads across LDS writes, so this is what keeps several reads in flight per thread.
+    auto lookup = [&](int t) {                   // workers: w of tile t
+        float *dst = wL + (t % 3) * T * NW;
+        const int2 *bsrc = bL + (t % 3) * T;
+        const int nt = B - t * T < T ? B - t * T : T;
+        int2 b[LK];
+        float w[LK];
+#pragma unroll
+        for (int k = 0; k < LK; ++k)
+            b[k] = bsrc[s0 + k * SS];            // rows beyond nt hold (0,0) or stale coordinates: harmless
+#pragma unroll
+        for (int k = 0; k < LK; ++k) {
+            int dx = cx - b[k].x, dy = cy - b[k].y;
+            dx = dx < 0 ? -dx : dx;
+            dy = dy < 0 ? -dy : dy;
+            dx = dx < lutw ? dx : lutw - 1;
+            dy = dy < luth ? dy : luth - 1;
+            w[k] = tab[dy * lutw + dx];          // (float)calculateNeighbourhoodWeight(...) :851
+        }
+#pragma unroll
+        for (int k = 0; k < LK; ++k)
+            if (s0 + k * SS < nt)
+                dst[(s0 + k * SS) * NW + lnode] = w[k];
+    };
+    auto emit = [&](int t) {                     // workers: (c,w) pairs of tile t
+        const float *ws = wL + (t % 3) * T * NW;
+        const float *Ws = WL + (t & 1) * T * NW;
+        const int nt = B - t * T < T ? B - t * T : T;
+        float w0[PK], w1[PK], W0[PK], W1[PK];
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+            const int s = (s0 + k * SS) * 2;
+            w0[k] = ws[s * NW + lnode];
+            W0[k] = Ws[s * NW + lnode];
+            w1[k] = ws[(s + 1) * NW + lnode];
+            W1[k] = Ws[(s + 1) * NW + lnode];
+        }
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+            const int s = (s0 + k * SS) * 2;
+            float4 o;
+            o.x = w0[k] / W0[k];                 // c = w/W :864 (0/0 -> NaN, Q7)
+            o.y = w0[k];
+            const bool two = s + 1 < nt;         // odd tail: the partner slot is never read
+            o.z = two ? w1[k] / W1[k] : 0.f;
+            o.w = two ? w1[k] : 0.f;
+            if (valid && s < nt)
+                ((float4 *)cw)[(size_t)((t * T + s) >> 1) * ldn + nl] = o;
+        }
+    };
+
+    float run = 0.f;                             // sumOfWeights :840
+    if (wt >= 0) {
+        load_bxy(0);
+        load_bxy(1);
+    }
+    __syncthreads();
+    if (wt >= 0)
+        lookup(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (wt >= 0) {
+            load_bxy(t + 2);
+            if (t + 1 < ntiles)
+                lookup(t + 1);
+            if (t > 0)
+                emit(t - 1);
+        } else {
+            const float *ws = wL + (t % 3) * T * NW;
+            float *Ws = WL + (t & 1) * T * NW;
+            const int nt = B - t * T < T ? B - t * T : T;
+            int s = 0;
+            // 16 reads issued together, then the 16 dependent additions, then the 16 writes
+            for (; s + 16 <= nt; s += 16) {
+                float r[16], o[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    r[k] = ws[(s + k) * NW + lnode];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    run = run + r[k];                        // :857
+                    o[k] = run;
+                }
+                if (tid < NW) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        Ws[(s + k) * NW + lnode] = o[k];
+                }
+            }
+            for (; s < nt; ++s) {
+                run = run + ws[s * NW + lnode];
+                if (tid < NW)
+                    Ws[s * NW + lnode] = run;
+            }
+        }
+        __syncthreads();
+    }
+    if (wt >= 0)
+        emit(ntiles - 1);
+    else if (tid < NW && valid)
+        weight[n0 + nl] = run;                   // :875
+}
+
 // Eigen scalar_sign_op<float>: NaN -> NaN, else (a>0)-(a<0) as float (Transformation.cpp:50)
 __device__ __forceinline__ float vsom_sign(float a)
 {
@@ -513,7 +663,7 @@ int ensure_lut(vsom_ctx *c, double sigma)
 int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
 {
     if (n1 <= n0 || c->B == 0)
-        return VSOM_OK;
+        return vsom_join_aux(c);
     int rc = ensure_lut(c, sigma);
     if (rc)
         return rc;
@@ -536,14 +686,42 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         hipLaunchKernelGGL(bxy_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, c->stream,
                            c->lastbmu, (int)c->B, (int)c->W, (int)c->H, c->bxy);
         const size_t lut_bytes = (size_t)c->lut_w * c->lut_h * sizeof(float);
-        const bool lds = lut_bytes <= 64 * 1024;
-        // quads give nloc/16 wavefronts; below one per SIMD use 16 lanes per node (nloc/4 wavefronts)
-        const bool wide = nloc / 16 < 1024 && c->B >= 64;
-        auto kern = wide ? (lds ? cw16_kernel<true> : cw16_kernel<false>) : (lds ? cw_kernel<true> : cw_kernel<false>);
-        const size_t lanes = nloc * (wide ? 16 : 4);
-        hipLaunchKernelGGL(kern, dim3((unsigned)((lanes + 255) / 256)), dim3(256), lds ? lut_bytes : 0, c->stream,
-                           c->bxy, (int)c->B, (int)n0, (int)n1, (int)c->W, (int)c->H, c->lut, (int)c->lut_w,
-                           (int)c->lut_h, c->cw, (int)ldn, c->weight);
+        bool piped = false;
+        if (c->cw_mode == 0) {
+            // role-split kernel: NW nodes per workgroup so that the grid still covers the CUs
+            const bool lds = lut_bytes <= 96 * 1024;
+            const int nw = nloc >= 16384 ? 64 : (nloc >= 8192 ? 32 : 16);
+            const int T = 2048 / nw;
+            const size_t smem = (size_t)5 * 2048 * sizeof(float) + (size_t)3 * T * sizeof(int2) + (lds ? lut_bytes : 0);
+            const void *fn = nw == 64 ? (lds ? (const void *)cwp_kernel<64, 32, true> : (const void *)cwp_kernel<64, 32, false>)
+                           : nw == 32 ? (lds ? (const void *)cwp_kernel<32, 64, true> : (const void *)cwp_kernel<32, 64, false>)
+                                      : (lds ? (const void *)cwp_kernel<16, 128, true> : (const void *)cwp_kernel<16, 128, false>);
+            if (smem <= 64 * 1024 ||
+                hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess) {
+                const int2 *bxy = c->bxy;
+                int B = (int)c->B, in0 = (int)n0, in1 = (int)n1, iW = (int)c->W, iH = (int)c->H, lw = (int)c->lut_w,
+                    lh = (int)c->lut_h, ildn = (int)ldn;
+                const float *lut = c->lut;
+                float2 *cwp = c->cw;
+                float *wgt = c->weight;
+                void *args[] = {&bxy, &B, &in0, &in1, &iW, &iH, &lut, &lw, &lh, &cwp, &ildn, &wgt};
+                VSOM_HIP_CHECK(hipLaunchKernel(fn, dim3((unsigned)((nloc + nw - 1) / nw)), dim3(CWP_THREADS), args, smem,
+                                               c->stream));
+                piped = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (!piped) {
+            const bool lds = lut_bytes <= 64 * 1024;
+            // quads give nloc/16 wavefronts; below one per SIMD use 16 lanes per node (nloc/4 wavefronts)
+            const bool wide = c->cw_mode == 2 || (c->cw_mode != 1 && nloc / 16 < 1024 && c->B >= 64);
+            auto kern = wide ? (lds ? cw16_kernel<true> : cw16_kernel<false>) : (lds ? cw_kernel<true> : cw_kernel<false>);
+            const size_t lanes = nloc * (wide ? 16 : 4);
+            hipLaunchKernelGGL(kern, dim3((unsigned)((lanes + 255) / 256)), dim3(256), lds ? lut_bytes : 0, c->stream,
+                               c->bxy, (int)c->B, (int)n0, (int)n1, (int)c->W, (int)c->H, c->lut, (int)c->lut_w,
+                               (int)c->lut_h, c->cw, (int)ldn, c->weight);
+        }
         VSOM_HIP_CHECK(hipGetLastError());
     }
     int sig_cols = 0;   // columns left as raw S by the assembly kernel
@@ -632,5 +810,5 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                            c->sigma, (int)c->pitch, sig_cols, (int)n0, (int)nloc, c->weight);
         VSOM_HIP_CHECK(hipGetLastError());
     }
-    return VSOM_OK;
+    return vsom_join_aux(c);   // the MSE sum forked by launch_finish ran beside the kernels above
 }
