@@ -44,13 +44,13 @@ __device__ __forceinline__ u64 vsom_key(float d, uint32_t node)
 // of Eigen's SSE linear-vectorised redux:
 //   q_k = p0_k + p1_k ; [+ one more packet] ; (q0+q2)+(q1+q3) ; + scalar tail.
 // All 8 lanes return the same value.  xa/xb/ma/mb are the row pointers of the pair.
-template <bool CLR>
+template <bool CLR, int UNR = 14>
 __device__ __forceinline__ float vsom_group_dist(const float *xa, const float *xb,
                                                  const float *ma, const float *mb, int L, int k)
 {
     const int L8 = L & ~7;
     float acc = 0.f;
-#pragma unroll 14
+#pragma unroll UNR
     for (int d = k; d < L8; d += 8) {
         float r = vsom_resid<CLR>(xa[d], CLR ? xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
         float p = r * r;

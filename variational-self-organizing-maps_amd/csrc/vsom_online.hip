@@ -2,30 +2,42 @@
 // Som::trainBasicSom (Som.cpp:1159-1171) on gfx950.
 //
 // The path is strictly sequential in samples (sample j's BMU search reads the map sample j-1
-// wrote), so one sample = four small launches enqueued back to back on the context stream,
-// without host synchronisation:
+// wrote), so one sample = two launches (sigma > 1) or one (sigma <= 1) enqueued back to back on
+// the context stream, without host synchronisation:
 //   online_scan_kernel    sigma > 1: Som::findBmu, 8 lanes per node (one per Eigen accumulator
-//                         class), atomicMin on an order-preserving (distance, index) key
-//   online_resolve_kernel key + node-0-NaN rule -> BMU index
-//   online_local_kernel   sigma <= 1: Som::findLocalBmu from lastBMU (one wavefront)
+//                         class), atomicMin on an order-preserving (distance, index) key.  Key and node-0-NaN flag are double-buffered by
+//                         sample parity, so no launch is needed to resolve / re-arm them.
 //   online_window_kernel  the +-2.5 sigma window (Som.cpp:899-944): one workgroup per window
 //                         node, elementwise over the model vector; weightMap / map / SMap /
-//                         sigmaMap updated with the reference's double->float narrowing (Q11)
-//   online_post_kernel    residual + distance of the BMU after the update (:946), addBmu
-//                         (:1189-1192), MSE running sum (:1167), lastBMU (:895)
+//                         sigmaMap updated with the reference's double->float narrowing (Q11).
+//                         The workgroup that owns the BMU node then does the post step: residual
+//                         + distance of the BMU after the update (:946), addBmu (:1189-1192), MSE
+//                         running sum (:1167), lastBMU (:895), re-arming the other parity's key.
+//   online_small_kernel   sigma <= 1: Som::findLocalBmu + <=6x6 window + post in one launch
 // The bandwidth roofline of one sample is 4*N*D (scan) + 20*k*D (k window nodes) bytes.
 #include "vsom_device.hpp"
 #include <cmath>
 #include <algorithm>
 
-// onl_state: [0] argmin key, [1] node-0-NaN flag, [2] BMU index ; onl_f: [0] dist, [1] mse sum
+// onl_state: [0],[1] argmin key of even / odd samples, [2],[3] their node-0-NaN flags ;
+// onl_f: [0] dist, [1] mse sum
 struct OnlineArgs {
     DistArgs d;          // xa/xb point at the sample's row(s)
     u64 *state;
     float *fstate;
     int N, W, H;
+    int par;             // sample parity: which key / flag this sample uses
 };
 
+// BMU of the sample from its scan results; a NaN distance at node 0 pins it to 0 (Som.cpp:293-299)
+__device__ __forceinline__ u64 online_resolve(const u64 *state, int par)
+{
+    return state[2 + par] ? 0ull : (state[par] & 0xFFFFFFFFull);
+}
+
+#ifndef VSOM_SCAN_UNR
+#define VSOM_SCAN_UNR 14
+#endif
 template <bool CLR>
 __global__ __launch_bounds__(256) void online_scan_kernel(OnlineArgs a)
 {
@@ -33,11 +45,11 @@ __global__ __launch_bounds__(256) void online_scan_kernel(OnlineArgs a)
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int node = gid >> 3, k = threadIdx.x & 7;
     const int nc = node < a.N ? node : a.N - 1;
-    float d = vsom_group_dist<CLR>(a.d.xa, a.d.xb, a.d.ma + (size_t)nc * a.d.ldm,
-                                   a.d.mb + (size_t)nc * a.d.ldm, a.d.L, k);
+    float d = vsom_group_dist<CLR, VSOM_SCAN_UNR>(a.d.xa, a.d.xb, a.d.ma + (size_t)nc * a.d.ldm,
+                                                  a.d.mb + (size_t)nc * a.d.ldm, a.d.L, k);
     u64 key = (node < a.N) ? vsom_key(d, (uint32_t)node) : ~0ull;
     if (node == 0 && k == 0)
-        a.state[1] = (d != d) ? 1ull : 0ull;
+        a.state[2 + a.par] = (d != d) ? 1ull : 0ull;
     // wave min, then block min, then one atomic per block
     for (int off = 32; off >= 8; off >>= 1) {
         u64 o = __shfl_xor(key, off);
@@ -51,15 +63,7 @@ __global__ __launch_bounds__(256) void online_scan_kernel(OnlineArgs a)
         u64 m = skey[0];
         for (int i = 1; i < 4; ++i)
             m = skey[i] < m ? skey[i] : m;
-        atomicMin(&a.state[0], m);
-    }
-}
-
-__global__ void online_resolve_kernel(u64 *state)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        // a NaN distance at node 0 pins the BMU to 0 (Som.cpp:293-299)
-        state[2] = state[1] ? 0ull : (state[0] & 0xFFFFFFFFull);
+        atomicMin(&a.state[a.par], m);
     }
 }
 
@@ -128,15 +132,6 @@ __device__ __forceinline__ u64 online_local_search(const OnlineArgs &a, const u6
         }
     }
     return minIndex;   // identical in every lane
-}
-
-template <bool CLR>
-__global__ __launch_bounds__(64) void online_local_kernel(OnlineArgs a, const u64 *__restrict__ lastbmu)
-{
-    const int lane = threadIdx.x & 63;
-    const u64 minIndex = online_local_search<CLR>(a, lastbmu, lane);
-    if (lane == 0)
-        a.state[2] = minIndex;
 }
 
 __device__ __forceinline__ float onl_sign(float a)
@@ -234,29 +229,6 @@ __device__ __forceinline__ void online_window(u64 bmu, int W, int H, double sigm
     endY = (u64)eyd;
 }
 
-// one workgroup per node of the (maximal) window; nodes outside the actual window exit
-template <int KIND>
-__global__ __launch_bounds__(256) void online_window_kernel(
-    const float *__restrict__ xs, const float *__restrict__ xp, const float *__restrict__ yp,
-    const u64 *__restrict__ state, const double *__restrict__ lutd, int lutw, int W, int H, int D,
-    int P, int ppitch, int pitch, double eta, double sigma, int decay_fn, float *__restrict__ map,
-    float *__restrict__ Smap, float *__restrict__ sigmap, float *__restrict__ weight)
-{
-    int bx, by;
-    u64 startX, startY, endX, endY;
-    online_window(state[2], W, H, sigma, bx, by, startX, startY, endX, endY);
-    const u64 i = startX + blockIdx.x, j = startY + blockIdx.y;
-    if (i >= endX || j >= endY)
-        return;
-    const size_t n = (size_t)(j * (u64)W + i);
-    int dx = (int)i - bx, dy = (int)j - by;
-    dx = dx < 0 ? -dx : dx;
-    dy = dy < 0 ? -dy : dy;
-    const double h = lutd[(size_t)dy * lutw + dx];   // calculateNeighbourhoodWeight(i,j,bx,by,sigma) :915
-    online_node_update<KIND, true>(n, h, threadIdx.x, blockDim.x, xs, xp, yp, D, P, ppitch, pitch, eta, decay_fn,
-                                   map, Smap, sigmap, weight);
-}
-
 // residual / distance of the BMU after the update (:946), addBmu, MSE, lastBMU
 template <bool CLR>
 __device__ __forceinline__ void online_post(const OnlineArgs &a, u64 bmu, int lane, u64 *hits, u64 *lastbmu_out,
@@ -276,18 +248,41 @@ __device__ __forceinline__ void online_post(const OnlineArgs &a, u64 bmu, int la
         if (add_hit)
             hits[bmu] += 1ull;               // addBmu (:1165, :1189-1192)
         *lastbmu_out = bmu;                  // lastBMU = by*W + bx (:895)
-        a.state[0] = ~0ull;                  // re-arm the argmin key for the next sample
-        a.state[1] = 0ull;
     }
 }
 
-template <bool CLR>
-__global__ __launch_bounds__(64) void online_post_kernel(OnlineArgs a, u64 *__restrict__ hits,
-                                                         u64 *__restrict__ lastbmu_out,
-                                                         float *__restrict__ residual, float fB,
-                                                         int add_hit)
+// one workgroup per node of the (maximal) window; nodes outside the actual window exit.  The
+// workgroup of the BMU node finishes the sample (post step) once its own update is visible.
+template <int KIND>
+__global__ __launch_bounds__(256) void online_window_kernel(
+    OnlineArgs a, const float *__restrict__ xs, const float *__restrict__ xp, const float *__restrict__ yp,
+    const double *__restrict__ lutd, int lutw, int D, int P, int ppitch, int pitch, double eta, double sigma,
+    int decay_fn, float *map, float *Smap, float *sigmap, float *weight, u64 *hits, u64 *lastbmu_out,
+    float *residual, float fB, int add_hit)   // no __restrict__: a.d.ma aliases map
 {
-    online_post<CLR>(a, a.state[2], threadIdx.x & 63, hits, lastbmu_out, residual, fB, add_hit);
+    constexpr bool CLR = KIND == VSOM_CLR;
+    const u64 bmu = online_resolve(a.state, a.par);
+    int bx, by;
+    u64 startX, startY, endX, endY;
+    online_window(bmu, a.W, a.H, sigma, bx, by, startX, startY, endX, endY);
+    const u64 i = startX + blockIdx.x, j = startY + blockIdx.y;
+    if (i >= endX || j >= endY)
+        return;
+    const size_t n = (size_t)(j * (u64)a.W + i);
+    int dx = (int)i - bx, dy = (int)j - by;
+    dx = dx < 0 ? -dx : dx;
+    dy = dy < 0 ? -dy : dy;
+    const double h = lutd[(size_t)dy * lutw + dx];   // calculateNeighbourhoodWeight(i,j,bx,by,sigma) :915
+    online_node_update<KIND, true>(n, h, threadIdx.x, blockDim.x, xs, xp, yp, D, P, ppitch, pitch, eta, decay_fn,
+                                   map, Smap, sigmap, weight);
+    if (n != (size_t)bmu)        // the BMU always lies inside its own window (sigma > 1)
+        return;
+    __syncthreads();             // this workgroup's writes of the BMU row are visible to its wave 0
+    if (threadIdx.x < 64) {
+        online_post<CLR>(a, bmu, threadIdx.x, hits, lastbmu_out, residual, fB, add_hit);
+        if (threadIdx.x == 0)
+            a.state[a.par ^ 1] = ~0ull;   // arm the next sample's key (nobody reads it during this launch)
+    }
 }
 
 // sigma <= 1 (Som.cpp:891: findLocalBmu, indicator neighbourhood, window of at most 6x6 nodes):
@@ -331,7 +326,7 @@ __global__ __launch_bounds__(256) void online_small_kernel(
 __global__ void online_init_kernel(u64 *state, float *fstate)
 {
     state[0] = ~0ull;
-    state[1] = 0ull;
+    state[1] = ~0ull;
     state[2] = 0ull;
     state[3] = 0ull;
     fstate[0] = 0.f;
@@ -373,9 +368,10 @@ static int ensure_lutd(vsom_ctx *c, double sigma, const double **out, int *lutw)
 // enqueue one trainSingle on sample rows (xs / xp / yp), lastBMU in/out at `lastbmu_dev`
 static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const float *yp,
                           double eta, double sigma, int decay_fn, u64 *lastbmu_dev,
-                          float *residual_dev, float fB, int add_hit, const double *lutd, int lutw)
+                          float *residual_dev, float fB, int add_hit, const double *lutd, int lutw, int par)
 {
     OnlineArgs a;
+    a.par = par & 1;
     const bool clr = c->transform == VSOM_CLR;
     a.d.xa = clr ? xp : xs;
     a.d.xb = clr ? yp : xs;
@@ -396,9 +392,6 @@ static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const f
             hipLaunchKernelGGL(online_scan_kernel<true>, grid, dim3(256), 0, c->stream, a);
         else
             hipLaunchKernelGGL(online_scan_kernel<false>, grid, dim3(256), 0, c->stream, a);
-        // (fusing this tiny launch into the scan through an arrival ticket measured 6 us SLOWER per
-        //  sample: 2048 fenced atomics on one word)
-        hipLaunchKernelGGL(online_resolve_kernel, dim3(1), dim3(64), 0, c->stream, c->onl_state);
     } else {
         // sigma <= 1: one fused launch (local search + <=6x6 window + post)
 #define LAUNCH_SMALL(KIND)                                                                                  \
@@ -422,11 +415,10 @@ static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const f
     int bs = L >= 256 ? 256 : ((L + 63) / 64) * 64;
     if (bs < 64)
         bs = 64;
-#define LAUNCH_WIN(KIND)                                                                          \
-    hipLaunchKernelGGL(online_window_kernel<KIND>, wgrid, dim3(bs), 0, c->stream, xs, xp, yp,      \
-                       c->onl_state, lutd, lutw, (int)c->W, (int)c->H, (int)c->D, (int)c->part_len, \
-                       (int)c->part_pitch, (int)c->pitch, eta, sigma, decay_fn, c->map, c->S,      \
-                       c->sigma, c->weight)
+#define LAUNCH_WIN(KIND)                                                                                    \
+    hipLaunchKernelGGL(online_window_kernel<KIND>, wgrid, dim3(bs), 0, c->stream, a, xs, xp, yp, lutd, lutw,   \
+                       (int)c->D, (int)c->part_len, (int)c->part_pitch, (int)c->pitch, eta, sigma, decay_fn, \
+                       c->map, c->S, c->sigma, c->weight, c->hits, lastbmu_dev, residual_dev, fB, add_hit)
     if (c->transform == VSOM_CLR)
         LAUNCH_WIN(VSOM_CLR);
     else if (c->transform == VSOM_MEDIAN)
@@ -434,12 +426,6 @@ static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const f
     else
         LAUNCH_WIN(VSOM_STANDARD);
 #undef LAUNCH_WIN
-    if (clr)
-        hipLaunchKernelGGL(online_post_kernel<true>, dim3(1), dim3(64), 0, c->stream, a, c->hits,
-                           lastbmu_dev, residual_dev, fB, add_hit);
-    else
-        hipLaunchKernelGGL(online_post_kernel<false>, dim3(1), dim3(64), 0, c->stream, a, c->hits,
-                           lastbmu_dev, residual_dev, fB, add_hit);
     return VSOM_OK;
 }
 
@@ -450,6 +436,8 @@ int vsom_train_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn,
     if (!c)
         return vsom_fail(VSOM_ERR_INVALID, "null context");
     VSOM_HIP_CHECK(hipSetDevice(c->device));
+    if (int jrc = vsom_join_aux(c))
+        return jrc;
     if (decay_fn != VSOM_EXPONENTIAL && decay_fn != VSOM_INVERSE_PROPORTIONAL)
         return vsom_fail(VSOM_ERR_INVALID, "online training needs Exponential or InverseProportional");
     if (c->B == 0)
@@ -468,7 +456,7 @@ int vsom_train_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn,
             const float *xp = c->XP ? c->XP + j * c->part_pitch : nullptr;
             const float *yp = c->YP ? c->YP + j * c->part_pitch : nullptr;
             rc = enqueue_single(c, xs, xp, yp, eta, sigma, decay_fn, c->lastbmu + j, nullptr, fB, 1,
-                                lutd, lutw);
+                                lutd, lutw, (int)(j & 1));
             if (rc)
                 return rc;
         }
@@ -487,6 +475,8 @@ int vsom_train_single(vsom_ctx *c, const float *v_host, double eta, double sigma
     if (!c)
         return vsom_fail(VSOM_ERR_INVALID, "null context");
     VSOM_HIP_CHECK(hipSetDevice(c->device));
+    if (int jrc = vsom_join_aux(c))
+        return jrc;
     if (!v_host || !last_bmu)
         return vsom_fail(VSOM_ERR_INVALID, "null argument");
     if (decay_fn != VSOM_EXPONENTIAL && decay_fn != VSOM_INVERSE_PROPORTIONAL)
@@ -523,7 +513,7 @@ int vsom_train_single(vsom_ctx *c, const float *v_host, double eta, double sigma
     {
         TimerScope ts(c, VSOM_T_ONLINE);
         hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f);
-        rc = enqueue_single(c, xs, xp, yp, eta, sigma, decay_fn, lb, res, 1.0f, 0, lutd, lutw);
+        rc = enqueue_single(c, xs, xp, yp, eta, sigma, decay_fn, lb, res, 1.0f, 0, lutd, lutw, 0);
         if (rc)
             return rc;
         VSOM_HIP_CHECK(hipGetLastError());
