@@ -139,15 +139,17 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict
                 a[i] = *reinterpret_cast<const float4 *>(&As[(wm * 64 + i * 32 + lr) * GLD + kb + 4 * lh]);
                 b[i] = *reinterpret_cast<const float4 *>(&Bs[(wn * 64 + i * 32 + lr) * GLD + kb + 4 * lh]);
             }
+            // k order per accumulator is unchanged (x, y, z, w); consecutive MFMAs go to different
+            // accumulators so none waits for the previous one's result
+            const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+            const float bv[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], bv[j][c], acc[i][j], 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -175,9 +177,10 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict
                 if (col1 < N)
                     G[(size_t)(row - s0) * ldg + col1] = g1;
             }
-            float mn = col0 < N ? g0 : inf;
-            mn = (col1 < N && g1 < mn) ? g1 : mn;
-            mn = mn == mn ? mn : inf;
+            // exact minimum of the finite entries (select_kernel skips tiles by it): NaN -> +inf
+            const float m0 = (col0 < N && g0 == g0) ? g0 : inf;
+            const float m1 = (col1 < N && g1 == g1) ? g1 : inf;
+            float mn = m1 < m0 ? m1 : m0;
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) {   // the 32 lanes that share this row
                 float o = __shfl_xor(mn, off);
@@ -240,23 +243,23 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         const float thr = m + T;
         if (!(thr < 3.0e38f))
             bad = true;                                      // nothing finite to compare with
-        // pass 2: collect candidates (order irrelevant: the key min decides)
-        const float4 *g4 = reinterpret_cast<const float4 *>(g);   // rows are ldg (x128) floats long
+        // pass 2: collect candidates (order irrelevant: the key min decides).  tmin[t] is the exact
+        // minimum of the non-NaN entries of columns [64t, 64t+64), so only tiles with tmin <= thr
+        // can hold a candidate: one coalesced 256-byte read per such tile instead of the whole row.
+        const float *tm = tmin + (size_t)(s - s0) * ntm;
         const u64 below = (1ull << lane) - 1ull;
-        for (int i0 = 0; i0 < N && !bad; i0 += 256) {
-            const int i = i0 + lane * 4;
-            float4 v = i < N ? g4[i >> 2] : make_float4(thr, thr, thr, thr);
-            const bool c0 = i < N && v.x <= thr, c1 = i + 1 < N && v.y <= thr;
-            const bool c2 = i + 2 < N && v.z <= thr, c3 = i + 3 < N && v.w <= thr;
-            if (__ballot(c0 | c1 | c2 | c3) == 0ull)
-                continue;
-            const bool cs[4] = {c0, c1, c2, c3};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u64 mask = __ballot(cs[e]);
-                unsigned before = (unsigned)__popcll(mask & below);
-                if (cs[e] && cnt + before < SL_CMAX)
-                    cand[wave][cnt + before] = (unsigned)(i + e);
+        for (int t0 = 0; t0 < ntm && !bad; t0 += 64) {
+            const int t = t0 + lane;
+            u64 hm = __ballot(t < ntm && tm[t] <= thr);
+            while (hm) {
+                const int tl = __ffsll((long long)hm) - 1;
+                hm &= hm - 1ull;
+                const int i = (t0 + tl) * 64 + lane;
+                const bool c = i < N && g[i] <= thr;
+                const u64 mask = __ballot(c);
+                const unsigned before = (unsigned)__popcll(mask & below);
+                if (c && cnt + before < SL_CMAX)
+                    cand[wave][cnt + before] = (unsigned)i;
                 cnt += (unsigned)__popcll(mask);
             }
         }
