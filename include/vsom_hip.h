@@ -130,6 +130,18 @@ int vsom_get_state(vsom_ctx *ctx, float *map, float *sigma, float *S, float *wei
 int vsom_upload_chunk(vsom_ctx *ctx, const float *x_host, size_t B);
 /* same, samples already resident in HBM (no PCIe copy) */
 int vsom_set_chunk_device(vsom_ctx *ctx, const float *x_dev, size_t B);
+/* Double-buffered ingest: the reference reloads every chunk from its loader each
+ * epoch (Som.cpp:737, DataSet.cpp:118-160), so the host->device copy of chunk i+1 should run while
+ * chunk i trains.  vsom_prefetch_chunk copies B x J floats into the context's NEXT raw device buffer
+ * on a copy stream and returns at once when x_host is pinned (vsom_host_alloc); the current chunk is
+ * untouched.  vsom_commit_chunk makes the prefetched chunk current: the compute stream waits for the
+ * copy, stages it and zeroes lastBMU -- the same state vsom_upload_chunk of the same data leaves.
+ * vsom_prefetch_wait blocks until the copy has left x_host (then the host buffer may be rewritten). */
+int vsom_host_alloc(void **out, size_t bytes);   /* pinned host memory */
+int vsom_host_free(void *p);
+int vsom_prefetch_chunk(vsom_ctx *ctx, const float *x_host, size_t B);
+int vsom_prefetch_wait(vsom_ctx *ctx);
+int vsom_commit_chunk(vsom_ctx *ctx);
 /* DataSet::getLastBMU (DataSet.cpp:60-69) */
 int vsom_get_last_bmu(vsom_ctx *ctx, uint64_t *out_host);
 int vsom_set_last_bmu(vsom_ctx *ctx, const uint64_t *in_host);
@@ -169,7 +181,7 @@ int vsom_batch_finish_async(vsom_ctx *ctx);
 int vsom_batch_phase2_async(vsom_ctx *ctx, double sigma, size_t n0, size_t n1);
 int vsom_batch_epoch_async(vsom_ctx *ctx, double sigma, int is_first);
 int vsom_batch_epoch(vsom_ctx *ctx, double sigma, int is_first, float *mse_out);
-/* MSE of the last finish (synchronises) */
+/* MSE of the last finish / online chunk (synchronises) */
 int vsom_get_mse(vsom_ctx *ctx, float *mse_out);
 
 /* ---- online path -----------------------------------------------------------------------
@@ -180,7 +192,8 @@ int vsom_train_single(vsom_ctx *ctx, const float *v_host, double eta, double sig
                       uint64_t *last_bmu, int decay_fn, float *residual_out,
                       float *dist_out, uint64_t *bmu_out);
 /* inner loop of Som::trainBasicSom over the staged chunk (Som.cpp:1159-1171): B sequential
- * trainSingle steps + addBmu (:1189-1192) + MSE, without leaving the device.              */
+ * trainSingle steps + addBmu (:1189-1192) + MSE, without leaving the device.  With mse_out =
+ * NULL the call only enqueues (asynchronous); vsom_get_mse then returns the chunk's MSE.     */
 int vsom_train_online_chunk(vsom_ctx *ctx, double eta, double sigma, int decay_fn,
                             float *mse_out);
 

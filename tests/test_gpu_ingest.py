@@ -1,0 +1,92 @@
+"""GPU: double-buffered ingest (vsom_prefetch_chunk / vsom_commit_chunk).
+Committing a prefetched chunk must leave exactly the state vsom_upload_chunk of the same data
+leaves (staged rows, lastBMU zeroed -- DataSet.cpp:118-160), also when the next chunk's copy is
+started while the current chunk is still training, from pinned and from pageable host memory."""
+import numpy as np
+import pytest
+
+import gen
+import vsom_amd
+from vsom_amd import capi
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+@pytest.mark.parametrize("tr,J", [(po.STANDARD, 24), (po.CLR, 6)])
+def test_pipelined_chunks_match_oracle(pinned, tr, J):
+    W = H = 12
+    D = po.length(tr, J)
+    sizes = [300, 128, 77, 300]                 # ragged, last one re-uses the first slot's size
+    chunks = [gen.correlated(b, J, seed=10 + i) if tr == po.CLR else gen.blobs(b, J, 4, 1, 20 + i)
+              for i, b in enumerate(sizes)]
+    init = gen.random_map(W * H, D, seed=42)
+    orc = po.OracleSom(W, H, J, tr)
+    orc.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    ctx.set_state(map=init)
+
+    bufs = []
+    def host(i):
+        if not pinned:
+            return np.ascontiguousarray(chunks[i])
+        pb = capi.PinnedBuffer(chunks[i].shape)
+        pb.array[...] = chunks[i]
+        bufs.append(pb)
+        return pb.array
+
+    sigma = 5.0
+    ctx.prefetch_chunk(host(0))
+    for i in range(len(chunks)):
+        ctx.commit_chunk()
+        assert ctx.chunk_size == sizes[i]
+        ctx.batch_epoch_async(sigma, i == 0)
+        if i + 1 < len(chunks):
+            ctx.prefetch_chunk(host(i + 1))     # copy of chunk i+1 beside the epoch of chunk i
+        mse_g = ctx.get_mse()
+        lb = np.zeros(sizes[i], np.uint64)      # every load zeroes lastBMU (DataSet.cpp:136-137)
+        mse_o = orc.batch_epoch(chunks[i], lb, sigma, i == 0)
+        assert (ctx.get_last_bmu() == lb).all(), i
+        assert np.float32(mse_g) == np.float32(mse_o) or (np.isnan(mse_g) and np.isnan(mse_o)), i
+        st = ctx.get_state()
+        for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("weight", orc.weight)):
+            same = (_bits(st[k]) == _bits(ref)) | (np.isnan(st[k]) & np.isnan(ref))
+            assert same.all(), (i, k)
+        assert (st["hits"] == orc.hits).all()
+        sigma *= 0.9
+    ctx.close()
+    for b in bufs:
+        b.free()
+
+
+def test_commit_without_prefetch_is_an_error():
+    ctx = vsom_amd.Context(4, 4, 8)
+    with pytest.raises(capi.VsomError):
+        ctx.commit_chunk()
+    ctx.close()
+
+
+def test_online_chunk_mse_through_get_mse():
+    """vsom_train_online_chunk with mse_out = NULL only enqueues; vsom_get_mse returns its MSE."""
+    import ctypes as C
+    W = H = 8
+    J = 10
+    X = gen.blobs(64, J, 3, 1, 2)
+    init = gen.random_map(W * H, J, seed=42)
+    a = vsom_amd.Context(W, H, J)
+    a.set_state(map=init)
+    a.upload_chunk(X)
+    want = a.train_online_chunk(0.1, 3.0, capi.EXPONENTIAL)
+    b = vsom_amd.Context(W, H, J)
+    b.set_state(map=init)
+    b.upload_chunk(X)
+    capi.check(capi.lib().vsom_train_online_chunk(b._h, 0.1, 3.0, capi.EXPONENTIAL, None))
+    got = b.get_mse()
+    assert np.float32(got) == np.float32(want)
+    a.close()
+    b.close()

@@ -1,0 +1,151 @@
+"""Host-side data ingest: MnistDataLoader and SqliteDataLoader of the C++ host
+library, driven through DataSet like the reference's training drivers do.  The inputs are built
+here (IDX files with numpy, a SQLite database with Python's sqlite3 from the reference's own
+20-row fixture, tests/golden/ican_fixture.json); no GPU is needed.
+
+Expected behaviour (reference src/MnistDataLoader.cpp:47-84, src/SqliteDataLoader.cpp:465-548,
+src/DataSet.cpp:118-160): chunks of at most maxLoadCount rows in file / Id order, 784 raw pixel
+values + one-hot label per MNIST row, REAL columns in column-spec order per SQLite row, lastBMU
+zeroed on every load, and the stream wraps so that the second pass equals the first."""
+import json
+import os
+import sqlite3
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "variational-self-organizing-maps_amd", "host")
+EXE = os.path.join(HOST, "host_loader_test")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not os.path.exists(EXE):
+        import __graft_entry__
+        __graft_entry__.build()
+    assert os.path.exists(EXE), "host_loader_test was not built"
+    return EXE
+
+
+def run(exe, *args):
+    r = subprocess.run([exe, *[str(a) for a in args]], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    return r.stdout.splitlines()
+
+
+def parse(lines):
+    """-> list of passes, each a list of chunks (float32 arrays), plus the other lines"""
+    passes, chunks, rows, other = [], [], None, []
+    for ln in lines:
+        if ln.startswith("CHUNK"):
+            if rows is not None:
+                chunks.append(rows)
+            _, n, d = ln.split()
+            rows = np.zeros((0, int(d)), np.float32)
+            expect = int(n)
+        elif ln.startswith("ROW"):
+            vals, tail = ln[4:].split(" | ")
+            assert tail == "lastBMU 0 valid 1", tail
+            rows = np.vstack([rows, np.array(vals.split(), np.float64).astype(np.float32)[None, :]])
+        elif ln == "PASS_END":
+            if rows is not None:
+                chunks.append(rows)
+            passes.append(chunks)
+            chunks, rows = [], None
+        else:
+            other.append(ln)
+    return passes, other
+
+
+def write_idx(folder, images, labels):
+    n, h, w = images.shape
+    with open(os.path.join(folder, "train-images-idx3-ubyte"), "wb") as f:
+        f.write(struct.pack(">IIII", 0x803, n, h, w))
+        f.write(images.astype(np.uint8).tobytes())
+    with open(os.path.join(folder, "train-labels-idx1-ubyte"), "wb") as f:
+        f.write(struct.pack(">II", 0x801, n))
+        f.write(labels.astype(np.uint8).tobytes())
+
+
+@pytest.mark.parametrize("chunk", [0, 7, 10, 25, 64])
+def test_mnist_loader_chunks(exe, tmp_path, chunk):
+    rs = np.random.RandomState(7)
+    n = 25
+    images = rs.randint(0, 256, size=(n, 28, 28))
+    labels = rs.randint(0, 10, size=n)
+    write_idx(str(tmp_path), images, labels)
+    passes, other = parse(run(exe, "mnist", tmp_path, chunk))
+    assert other[0] == "DEPTH 794 NAME0 0x0 NAME783 27x27 NAME784 label:0"
+    want = np.concatenate([images.reshape(n, 784), np.eye(10)[labels]], axis=1).astype(np.float32)
+    for chunks in passes:                       # second pass: the stream wrapped to the start
+        sizes = [c.shape[0] for c in chunks]
+        if chunk == 0 or chunk >= n:
+            # one chunk with every row; then an empty read rewinds the stream (MnistDataLoader.cpp:53)
+            assert sizes[0] == n and sum(sizes) == n
+        else:
+            full = [chunk] * (n // chunk) + ([n % chunk] if n % chunk else [])
+            assert [s for s in sizes if s] == full
+        got = np.concatenate([c for c in chunks if c.shape[0]], axis=0)
+        assert got.shape == want.shape and (got == want).all()
+    assert len(passes) == 2
+
+
+def make_db(path, rows, names):
+    con = sqlite3.connect(path)
+    con.execute("CREATE TABLE ican (Id INTEGER PRIMARY KEY, %s)" % ", ".join(f"{c} REAL" for c in names))
+    con.execute("CREATE TABLE other (Id INTEGER PRIMARY KEY, X REAL)")
+    for i, r in enumerate(rows):
+        con.execute("INSERT INTO ican VALUES (%s)" % ",".join(["?"] * (len(names) + 1)), [i + 1, *map(float, r)])
+    con.commit()
+    con.close()
+
+
+@pytest.fixture(scope="module")
+def ican():
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "ican_fixture.json")))
+    return np.array(fx["rows"], np.float64), list("ABCDEFGHI")
+
+
+@pytest.mark.parametrize("chunk", [0, 6, 20, 50])
+def test_sqlite_loader_chunks(exe, tmp_path, ican, chunk):
+    rows, names = ican
+    db = os.path.join(str(tmp_path), "t.sq3")
+    make_db(db, rows, names)
+    cols = ["C", "A", "I"]                      # column-spec order decides the value order
+    passes, other = parse(run(exe, "sqlite", db, "ican", chunk, ",".join(cols)))
+    assert [o for o in other if o.startswith("TABLE")] == ["TABLE ican", "TABLE other"]
+    assert [o for o in other if o.startswith("COLUMN")] == ["COLUMN Id"] + ["COLUMN " + c for c in names]
+    want = rows[:, [names.index(c) for c in cols]].astype(np.float32)
+    assert len(passes) == 2
+    for chunks in passes:
+        sizes = [c.shape[0] for c in chunks]
+        n = len(rows)
+        if chunk == 0 or chunk >= n:
+            assert sizes == [n]
+        else:
+            assert sizes == [chunk] * (n // chunk) + ([n % chunk] if n % chunk else [])
+        got = np.concatenate(chunks, axis=0)
+        assert (got == want).all()
+
+
+def test_sqlite_column_spec_file(exe, tmp_path, ican):
+    """The reference's column-spec file format (tests/performance/data/columnSpec.txt:1-9):
+    name<TAB>weight[<TAB>binary]; selects table 'ican'."""
+    rows, names = ican
+    db = os.path.join(str(tmp_path), "t.sq3")
+    make_db(db, rows, names)
+    spec = os.path.join(str(tmp_path), "spec.txt")
+    with open(spec, "w") as f:
+        for c in names:
+            f.write(f"{c}\t{2 if c == 'B' else 1}" + ("\tbinary" if c == "E" else "") + "\n")
+    passes, other = parse(run(exe, "spec", db, spec, 8))
+    specs = [o.split() for o in other if o.startswith("SPEC")]
+    assert [s[1] for s in specs] == names
+    assert [float(s[2]) for s in specs] == [2.0 if c == "B" else 1.0 for c in names]
+    assert [int(s[3]) for s in specs] == [1 if c == "E" else 0 for c in names]
+    got = np.concatenate(passes[0], axis=0)
+    assert [c.shape[0] for c in passes[0]] == [8, 8, 4]
+    assert (got == rows.astype(np.float32)).all()

@@ -25,7 +25,8 @@ TIMER_NAMES = ["stage", "bmu", "finish", "cw", "update", "online", "sigma"]
 SYMBOLS = [
     "vsom_last_error", "vsom_device_count", "vsom_create", "vsom_destroy", "vsom_set_stream",
     "vsom_synchronize", "vsom_set_bmu_mode", "vsom_set_update_mode", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
-    "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_get_last_bmu",
+    "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_host_alloc", "vsom_host_free",
+    "vsom_prefetch_chunk", "vsom_prefetch_wait", "vsom_commit_chunk", "vsom_get_last_bmu",
     "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_bmu_local_batch",
     "vsom_distances", "vsom_bmu_restricted_batch", "vsom_distances_row", "vsom_distances_raw", "vsom_batch_phase1_async", "vsom_batch_finish_async",
     "vsom_batch_phase2_async", "vsom_batch_epoch_async", "vsom_batch_epoch", "vsom_get_mse",
@@ -82,6 +83,11 @@ def lib():
     L.vsom_get_state.argtypes = [vp, fp, fp, fp, fp, u64p]
     L.vsom_upload_chunk.argtypes = [vp, fp, C.c_size_t]
     L.vsom_set_chunk_device.argtypes = [vp, vp, C.c_size_t]
+    L.vsom_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.vsom_host_free.argtypes = [vp]
+    L.vsom_prefetch_chunk.argtypes = [vp, fp, C.c_size_t]
+    L.vsom_prefetch_wait.argtypes = [vp]
+    L.vsom_commit_chunk.argtypes = [vp]
     L.vsom_get_last_bmu.argtypes = [vp, u64p]
     L.vsom_set_last_bmu.argtypes = [vp, u64p]
     L.vsom_get_sqres.argtypes = [vp, fp]
@@ -133,6 +139,30 @@ def model_length(transform, in_len):
 
 def neighbourhood_weight(cx, cy, bx, by, sigma):
     return float(lib().vsom_neighbourhood_weight(cx, cy, bx, by, float(sigma)))
+
+
+class PinnedBuffer:
+    """Pinned host memory (vsom_host_alloc) exposed as a numpy float32 array."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(v) for v in shape)
+        n = int(np.prod(self.shape))
+        self._p = C.c_void_p()
+        check(lib().vsom_host_alloc(C.byref(self._p), max(n, 1) * 4))
+        buf = (C.c_float * max(n, 1)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=np.float32, count=n).reshape(self.shape)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            lib().vsom_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Context:
@@ -219,6 +249,18 @@ class Context:
 
     def set_chunk_device(self, dev_ptr, B):
         check(lib().vsom_set_chunk_device(self._h, C.c_void_p(int(dev_ptr)), int(B)))
+
+    def prefetch_chunk(self, X):
+        """Start the H2D copy of the NEXT chunk (async when X lives in pinned memory, see
+        pinned_array); the current chunk keeps training."""
+        assert X.dtype == np.float32 and X.flags.c_contiguous and X.ndim == 2 and X.shape[1] == self.in_len
+        check(lib().vsom_prefetch_chunk(self._h, _f(X), X.shape[0]))
+
+    def prefetch_wait(self):
+        check(lib().vsom_prefetch_wait(self._h))
+
+    def commit_chunk(self):
+        check(lib().vsom_commit_chunk(self._h))
 
     def get_last_bmu(self):
         out = np.empty(self.chunk_size, np.uint64)

@@ -99,6 +99,18 @@ static int free_all(vsom_ctx *c)
         (void)hipStreamSynchronize(c->aux_stream);
         (void)hipStreamDestroy(c->aux_stream);
     }
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (c->Xnext[i])
+            (void)hipFree(c->Xnext[i]);
+        if (c->ev_copied[i])
+            (void)hipEventDestroy(c->ev_copied[i]);
+        if (c->ev_staged[i])
+            (void)hipEventDestroy(c->ev_staged[i]);
+    }
     if (c->ev_fork)
         (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join)
@@ -163,7 +175,12 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
         if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_copied[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_copied[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_staged[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_staged[1], hipEventDisableTiming) != hipSuccess) {
             rc = vsom_fail(VSOM_ERR_HIP, "hipStreamCreate failed");
             break;
         }
@@ -399,6 +416,82 @@ int vsom_upload_chunk(vsom_ctx *c, const float *x_host, size_t B)
     if (rc)
         return rc;
     VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));   // x_host may be reused by the caller
+    return VSOM_OK;
+}
+
+int vsom_host_alloc(void **out, size_t bytes)
+{
+    if (!out)
+        return vsom_fail(VSOM_ERR_INVALID, "null output");
+    *out = nullptr;
+    if (bytes == 0)
+        return VSOM_OK;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return vsom_fail(VSOM_ERR_NOMEM, "hipHostMalloc failed");
+    }
+    return VSOM_OK;
+}
+
+int vsom_host_free(void *p)
+{
+    if (p)
+        VSOM_HIP_CHECK(hipHostFree(p));
+    return VSOM_OK;
+}
+
+int vsom_prefetch_chunk(vsom_ctx *c, const float *x_host, size_t B)
+{
+    CHECK_CTX_NOJOIN(c);
+    if (B > 0 && !x_host)
+        return vsom_fail(VSOM_ERR_INVALID, "x_host is null");
+    if (B > 0x7FFFFFFFull)
+        return vsom_fail(VSOM_ERR_INVALID, "chunk too large");
+    const int k = c->next_slot;
+    const size_t need = B * c->J;
+    // the staging kernels of the chunk committed from this slot two prefetches ago must be done
+    if (c->staged_valid[k])
+        VSOM_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_staged[k], 0));
+    if (need > c->Xnext_cap[k]) {
+        if (c->staged_valid[k])
+            VSOM_HIP_CHECK(hipEventSynchronize(c->ev_staged[k]));
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+        if (c->Xnext[k])
+            (void)hipFree(c->Xnext[k]);
+        c->Xnext[k] = nullptr;
+        c->Xnext_cap[k] = 0;
+        VSOM_HIP_CHECK(hipMalloc(&c->Xnext[k], need * 4));
+        c->Xnext_cap[k] = need;
+    }
+    if (need)
+        VSOM_HIP_CHECK(hipMemcpyAsync(c->Xnext[k], x_host, need * 4, hipMemcpyHostToDevice, c->copy_stream));
+    VSOM_HIP_CHECK(hipEventRecord(c->ev_copied[k], c->copy_stream));
+    c->Bnext = B;
+    c->ready_slot = k;
+    c->next_slot = k ^ 1;
+    return VSOM_OK;
+}
+
+int vsom_prefetch_wait(vsom_ctx *c)
+{
+    CHECK_CTX_NOJOIN(c);
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+    return VSOM_OK;
+}
+
+int vsom_commit_chunk(vsom_ctx *c)
+{
+    CHECK_CTX(c);
+    if (c->ready_slot < 0)
+        return vsom_fail(VSOM_ERR_INVALID, "no prefetched chunk to commit");
+    const int k = c->ready_slot;
+    c->ready_slot = -1;
+    VSOM_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_copied[k], 0));
+    int rc = vsom_set_chunk_device(c, c->Xnext[k], c->Bnext);
+    if (rc)
+        return rc;
+    VSOM_HIP_CHECK(hipEventRecord(c->ev_staged[k], c->stream));
+    c->staged_valid[k] = true;
     return VSOM_OK;
 }
 

@@ -49,6 +49,16 @@ struct vsom_ctx {
     float *Xs = nullptr, *XP = nullptr, *YP = nullptr;
     float *Xraw = nullptr;          // staging for host uploads (B x J, unpadded)
     size_t Xraw_cap = 0;
+    // double-buffered ingest: raw chunks land here on copy_stream while the current chunk trains
+    float *Xnext[2] = {nullptr, nullptr};
+    size_t Xnext_cap[2] = {0, 0};
+    size_t Bnext = 0;
+    int next_slot = 0;              // slot the next prefetch writes
+    int ready_slot = -1;            // slot holding a prefetched, not yet committed chunk
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copied[2] = {nullptr, nullptr};    // H2D copy into slot finished
+    hipEvent_t ev_staged[2] = {nullptr, nullptr};    // staging kernels that read slot finished
+    bool staged_valid[2] = {false, false};
     u64 *lastbmu = nullptr;
     float *sqres = nullptr;
     float *mse = nullptr;           // [1]

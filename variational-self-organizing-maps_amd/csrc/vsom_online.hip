@@ -462,6 +462,8 @@ int vsom_train_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn,
         }
         VSOM_HIP_CHECK(hipGetLastError());
     }
+    // vsom_get_mse reports the chunk's MSE for callers that passed mse_out = NULL (asynchronous use)
+    VSOM_HIP_CHECK(hipMemcpyAsync(c->mse, c->onl_f + 1, 4, hipMemcpyDeviceToDevice, c->stream));
     if (mse_out) {
         VSOM_HIP_CHECK(hipMemcpyAsync(mse_out, c->onl_f + 1, 4, hipMemcpyDeviceToHost, c->stream));
         VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));

@@ -93,6 +93,92 @@ private:
     std::vector<std::string> m_names;
 };
 
+// ----- MnistDataLoader -------------------------------------------------------------------------
+// Mirror of the reference's include/MnistDataLoader.hpp:9-51 / src/MnistDataLoader.cpp:9-134.
+// open(folder) remembers the folder; load() reads the next <= maxLoadCount images of
+// `folder/train-images-idx3-ubyte` + `train-labels-idx1-ubyte` (IDX, big-endian headers, magic
+// 0x803 / 0x801): 784 raw pixel values 0..255 as float followed by the one-hot label (10 values),
+// depth 794, valid = 1 (MnistDataLoader.cpp:61-81).  The stream position advances by the rows read
+// and returns to 0 after an empty read or a read of >= 60000 rows (:53-55).  Own IDX parser (the
+// reference delegates to extern/mnistReader).
+class MnistDataLoader : public IDataLoader {
+public:
+    MnistDataLoader(std::optional<size_t> maxLoadCount = std::nullopt, bool verbose = false);
+    size_t load() override;
+    std::vector<RowData> getPreview(size_t count) override;
+    bool open(const char *path) override;
+    std::vector<std::string> findAllColumns() override { return _names; }
+    void setColumnSpec(const std::vector<ColumnSpec>) noexcept override {}
+    const std::vector<ColumnSpec> getColumnSpec() noexcept override;
+    float getWeight(size_t index) override { return _weights.at(index); }
+    const std::vector<float> getWeights() const noexcept override { return _weights; }
+    const std::vector<int> &getBinary() const noexcept override { return _isBinary; }
+    const std::vector<int> &getContinuous() const noexcept override { return _isContinuous; }
+    std::string getName(size_t index) const noexcept override { return _names.at(index); }
+    const std::vector<std::string> getNames() const noexcept override { return _names; }
+    size_t getDepth() const noexcept override { return _names.size(); }
+    bool isAtStartOfDataStream() const noexcept override { return m_currentIndex == 0; }
+
+protected:
+    std::vector<float> _weights;
+    std::vector<int> _isBinary, _isContinuous;
+    std::vector<std::string> _names;
+    std::string _filePath;
+    bool _verbose;
+    std::vector<RowData> readRows(size_t skip, size_t limit) const;
+};
+
+// ----- SqliteDataLoader ------------------------------------------------------------------------
+// Mirror of the reference's include/SqliteDataLoader.hpp:11-103 / src/SqliteDataLoader.cpp for the
+// calls the training drivers and tests/performance/perf_tests.cpp:77-84 make: open, setTable,
+// setColumnSpec / column-spec file, findAllTables, findAllColumns, load (Id-range chunk query
+// `SELECT <cols>,Id FROM <table> WHERE Id>=? AND Id<=?`, SqliteDataLoader.cpp:481-548), getPreview.
+// The SQLite C library is bound at run time (dlopen of libsqlite3.so.0): the build image has the
+// shared object but no header, and the reference's vendored extern/sqlite/sqlite3.c is absent.
+struct sqlite3;
+class SqliteDataLoader : public IDataLoader {
+public:
+    SqliteDataLoader(const std::string &specFilePath, std::optional<size_t> maxLoadCount = std::nullopt,
+                     bool verbose = false);
+    SqliteDataLoader(bool db, const std::string &dbPath, std::optional<size_t> maxLoadCount = std::nullopt);
+    ~SqliteDataLoader() override;
+    SqliteDataLoader(const SqliteDataLoader &) = delete;
+    SqliteDataLoader &operator=(const SqliteDataLoader &) = delete;
+    void setTable(const std::string &name) noexcept { _tableName = name; }
+    void setColumnSpec(const std::vector<ColumnSpec> columnSpec) noexcept override;
+    const std::vector<ColumnSpec> getColumnSpec() noexcept override { return _columnSpec; }
+    size_t load() override;
+    std::vector<RowData> getPreview(size_t count) override;
+    bool open(const char *dbPath) override;
+    bool open() { return open(_dbPath.c_str()); }
+    std::vector<std::string> findAllColumns() override;
+    std::vector<std::string> findAllTables();
+    const std::vector<float> getWeights() const noexcept override;
+    float getWeight(size_t index) override { return _columnSpec.at(index).weight; }
+    const std::vector<int> &getBinary() const noexcept override { return _isBinary; }
+    const std::vector<int> &getContinuous() const noexcept override { return _isContinuous; }
+    std::string getName(size_t index) const noexcept override { return _columnSpec.at(index).name; }
+    const std::vector<std::string> getNames() const noexcept override;
+    size_t getDepth() const noexcept override { return vectorLength; }
+    bool isAtStartOfDataStream() const noexcept override { return !currentLoadId.has_value(); }
+
+protected:
+    std::vector<ColumnSpec> _columnSpec;
+    std::vector<std::string> _tableNames, _columnNames;
+    std::vector<int> _isBinary, _isContinuous;
+    std::string _tableName, _dbPath;
+    sqlite3 *db = nullptr;
+    bool _verbose = false, hasOpenDatabase = false;
+    size_t vectorLength = 0;
+    std::optional<long long> currentLoadId;
+    void loadColumnSpecData(const std::string &path);
+    std::vector<std::string> queryStrings(const std::string &sql);
+    long long queryInteger(const std::string &sql);
+    // rows with Id in [startId or MIN(Id), ...], at most maxCount ids wide; returns {rows, next id, MAX(Id)}
+    struct Fetch { std::vector<RowData> rows; std::optional<long long> nextId; long long maxId; };
+    Fetch fetch(std::optional<long long> startId, std::optional<size_t> maxCount);
+};
+
 // ===== DataSet ===============================================================================
 // Mirror of the reference's include/DataSet.hpp:10-62 (chunk container consumed by the hot path).
 
@@ -118,7 +204,7 @@ protected:
 public:
     DataSet(IDataLoader &dataLoader, bool verbose = false)
         : _loader{dataLoader}, depth{}, n{}, loadedNumberOfChunks{0}, _verbose{verbose} {}
-    ~DataSet() = default;
+    ~DataSet() = default;   // (copyable like the reference's: see the copy constructor below)
     const std::vector<DataRow> getAll() const;
     std::vector<DataRow> getAll();
     std::vector<Eigen::VectorXf> getPreviewData(size_t count) const;
@@ -141,11 +227,26 @@ public:
     void resetStreamLoadPosition() noexcept;
     void shuffle();
 
-    // [MI355X build] contiguous view of the current chunk for staging (B x depth, row-major)
-    const std::vector<float> &contiguous() const noexcept { return m_flat; }
+    // [MI355X build] contiguous B x depth row-major copy of the current chunk in PINNED host memory
+    // (two buffers used alternately, so the asynchronous host->device copy of one chunk can still be
+    // running while the next chunk is being loaded into the other)
+    const float *contiguous() const noexcept { return m_flat[m_cur].p; }
+    DataSet(const DataSet &other);
+    DataSet &operator=(const DataSet &) = delete;
 
 private:
-    std::vector<float> m_flat;
+    struct Pinned {
+        float *p = nullptr;
+        size_t cap = 0;
+        bool pinned = false;
+        Pinned() = default;
+        Pinned(const Pinned &) = delete;
+        Pinned &operator=(const Pinned &) = delete;
+        ~Pinned();
+        void reserve(size_t n);
+    };
+    Pinned m_flat[2];
+    int m_cur = 0;
 };
 
 // ===== SomIndex ==============================================================================

@@ -297,6 +297,10 @@ size_t DataSet::size() const { return n; }
 void DataSet::addVector(Eigen::VectorXf v)
 {
     if ((size_t)v.rows() == _loader.getDepth()) {
+        depth = _loader.getDepth();
+        m_flat[m_cur].reserve((data.size() + 1) * depth);
+        for (size_t d = 0; d < depth; ++d)
+            m_flat[m_cur].p[data.size() * depth + d] = v[(Eigen::Index)d];
         data.push_back(v);
         n += 1;
     } else {
@@ -306,6 +310,56 @@ void DataSet::addVector(Eigen::VectorXf v)
 
 void DataSet::resetStreamLoadPosition() noexcept { loadedNumberOfChunks = 0; }
 bool DataSet::hasReadWholeDataStream() const noexcept { return loadedNumberOfChunks > 0 && _loader.isAtStartOfDataStream(); }
+
+DataSet::Pinned::~Pinned()
+{
+    if (p && pinned)
+        (void)vsom_host_free(p);
+    else
+        std::free(p);
+}
+
+void DataSet::Pinned::reserve(size_t nfloats)
+{
+    if (nfloats <= cap)
+        return;
+    const size_t want = std::max(nfloats, cap * 2);
+    // pinned when a device is present (asynchronous copies); plain pageable memory otherwise, so the
+    // loaders / DataSet stay usable for inspection on a machine without a GPU (training still needs one)
+    void *q = nullptr;
+    bool qpinned = true;
+    if (vsom_host_alloc(&q, want * sizeof(float)) != 0 || !q) {
+        q = std::malloc(want * sizeof(float));
+        qpinned = false;
+        if (!q)
+            throw std::bad_alloc();
+    }
+    if (p) {
+        std::copy(p, p + cap, static_cast<float *>(q));
+        if (pinned)
+            (void)vsom_host_free(p);
+        else
+            std::free(p);
+    }
+    p = static_cast<float *>(q);
+    pinned = qpinned;
+    cap = want;
+}
+
+// the reference passes DataSet by value (SOM.hpp:78-82); the copy owns its row views and staging
+DataSet::DataSet(const DataSet &o)
+    : data{o.data}, valid{o.valid}, index{o.index}, lastBMU{o.lastBMU}, _loader{o._loader}, depth{o.depth}, n{o.n},
+      loadedNumberOfChunks{o.loadedNumberOfChunks}, _verbose{o._verbose}
+{
+    allData.reserve(o.allData.size());
+    for (size_t k = 0; k < o.allData.size() && k < data.size(); ++k)
+        allData.push_back(DataRow{&data[k], &valid[k], &lastBMU[k]});
+    const size_t nf = data.size() * depth;
+    if (nf && o.m_flat[o.m_cur].p) {
+        m_flat[0].reserve(nf);
+        std::copy(o.m_flat[o.m_cur].p, o.m_flat[o.m_cur].p + nf, m_flat[0].p);
+    }
+}
 
 // DataSet.cpp:118-160: reload, rebuild the row views, lastBMU := 0 (:136-137)
 void DataSet::loadNextDataFromStream()
@@ -326,13 +380,16 @@ void DataSet::loadNextDataFromStream()
     for (size_t k = 0; k < index.size(); ++k)
         index[k] = k;
     shuffle();
-    m_flat.resize(numberOfRows * depth);
+    // the other pinned buffer: an asynchronous copy of the previous chunk may still read the current one
+    m_cur ^= 1;
+    m_flat[m_cur].reserve(numberOfRows * depth);
+    float *flat = m_flat[m_cur].p;
     size_t cur = 0;
     for (auto &row : _loader.data) {
         data.push_back(row.values);
         valid.push_back(row.valid);
         for (size_t d = 0; d < depth; ++d)
-            m_flat[cur * depth + d] = row.values[(Eigen::Index)d];
+            flat[cur * depth + d] = row.values[(Eigen::Index)d];
         allData.push_back(DataRow{&data.back(), &valid.back(), &lastBMU[cur]});
         ++cur;
     }
@@ -674,7 +731,7 @@ float Som::trainBatchSomEpoch(DataSet &dataset, double currentSigma, bool isFirs
     const size_t B = dataset.size();
     if (B == 0)
         return 0.f;
-    check(vsom_upload_chunk(ctx, dataset.contiguous().data(), B), "vsom_upload_chunk");
+    check(vsom_upload_chunk(ctx, dataset.contiguous(), B), "vsom_upload_chunk");
     std::vector<uint64_t> lb(B);
     if (!isFirst) {
         for (size_t s = 0; s < B; ++s)
@@ -690,6 +747,10 @@ float Som::trainBatchSomEpoch(DataSet &dataset, double currentSigma, bool isFirs
     return mse;
 }
 
+// Som.cpp:716-754.  Same control flow; the chunk loop is software-pipelined: while the device trains
+// on chunk k (asynchronous epoch), the host loads chunk k+1 from the loader and starts its
+// host->device copy (vsom_prefetch_chunk from the DataSet's pinned staging buffer).  The reference
+// reloads every chunk every epoch (:737), so this overlap recurs for the whole run.
 void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, double sigmaDecay, bool)
 {
     requireDevicePath("trainBatchSom");
@@ -701,11 +762,41 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
             return;   // :729-730
         auto meanSquareError = float{0.0f};
         auto countDataChunks = size_t{0};
-        while (!data.hasReadWholeDataStream()) {   // :735
+        bool have = false;            // a loaded chunk is waiting in `data`, its copy is in flight
+        size_t B = 0;
+        if (!data.hasReadWholeDataStream()) {   // :735
             data.loadNextDataFromStream();
-            meanSquareError += trainBatchSomEpoch(data, sigma, i == 0);
+            B = data.size();
+            check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+            have = true;
+        }
+        while (have) {
+            const size_t Bcur = B;
+            if (Bcur > 0) {
+                check(vsom_commit_chunk(ctx), "vsom_commit_chunk");   // lastBMU := 0 (DataSet.cpp:136-137)
+                check(vsom_batch_epoch_async(ctx, sigma, i == 0 ? 1 : 0), "vsom_batch_epoch_async");
+            }
+            have = false;
+            const bool last = data.hasReadWholeDataStream();
+            if (last && Bcur > 0) {
+                // the chunk still held by `data` after the loop keeps its BMUs (Som.cpp:777,800)
+                std::vector<uint64_t> lb(Bcur);
+                check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
+                for (size_t s = 0; s < Bcur; ++s)
+                    data.getLastBMU(s) = (size_t)lb[s];
+            } else if (!last) {
+                data.loadNextDataFromStream();   // host work beside the device epoch
+                B = data.size();
+                check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+                have = true;
+            }
+            float mse = 0.f;
+            if (Bcur > 0)
+                check(vsom_get_mse(ctx, &mse), "vsom_get_mse");
+            meanSquareError += mse;
             ++countDataChunks;
         }
+        hostStale = true;
         meanSquareError /= static_cast<float>(countDataChunks);   // :743
         {
             const std::lock_guard<std::mutex> lock(metricsMutex);
@@ -752,21 +843,40 @@ void Som::trainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, doubl
         std::cout << "Epoch: " << i + 1 << "/" << numberOfEpochs << "\teta: " << eta << "\tsigma: " << sigma << "\n";
         float meanSquareError{0.0};
         size_t countDataChunks{0};
-        while (!data.hasReadWholeDataStream()) {
+        // same software pipeline as trainBatchSom: chunk k+1 is loaded and copied while the device
+        // walks the B sequential trainSingle steps of chunk k (:1161-1171)
+        bool have = false;
+        size_t B = 0;
+        if (!data.hasReadWholeDataStream()) {
             data.loadNextDataFromStream();
-            const size_t B = data.size();
-            if (B > 0) {
-                // the chunk's B sequential trainSingle + addBmu + MSE run on the device (:1161-1171)
-                check(vsom_upload_chunk(ctx, data.contiguous().data(), B), "vsom_upload_chunk");
-                float mse = 0.f;
-                check(vsom_train_online_chunk(ctx, eta, sigma, decay_code(weightDecayFunction), &mse),
+            B = data.size();
+            check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+            have = true;
+        }
+        while (have) {
+            const size_t Bcur = B;
+            if (Bcur > 0) {
+                check(vsom_commit_chunk(ctx), "vsom_commit_chunk");
+                check(vsom_train_online_chunk(ctx, eta, sigma, decay_code(weightDecayFunction), nullptr),
                       "vsom_train_online_chunk");
-                std::vector<uint64_t> lb(B);
-                check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
-                for (size_t s = 0; s < B; ++s)
-                    data.getLastBMU(s) = (size_t)lb[s];
-                meanSquareError += mse;
             }
+            have = false;
+            const bool last = data.hasReadWholeDataStream();
+            if (last && Bcur > 0) {
+                std::vector<uint64_t> lb(Bcur);
+                check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
+                for (size_t s = 0; s < Bcur; ++s)
+                    data.getLastBMU(s) = (size_t)lb[s];
+            } else if (!last) {
+                data.loadNextDataFromStream();
+                B = data.size();
+                check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+                have = true;
+            }
+            float mse = 0.f;
+            if (Bcur > 0)
+                check(vsom_get_mse(ctx, &mse), "vsom_get_mse");
+            meanSquareError += mse;
             ++countDataChunks;
         }
         meanSquareError /= static_cast<float>(countDataChunks);   // :1175
@@ -915,7 +1025,7 @@ double Som::evaluate(const DataSet &data) const
     if (n == 0)
         return 0.0;
     refreshHost();
-    check(vsom_upload_chunk(ctx, data.contiguous().data(), n), "vsom_upload_chunk");
+    check(vsom_upload_chunk(ctx, data.contiguous(), n), "vsom_upload_chunk");
     std::vector<uint64_t> bmu(n);
     std::vector<float> dist(n);
     check(vsom_bmu_batch(ctx, bmu.data(), dist.data()), "vsom_bmu_batch");   // findBmu + euclidianWeightedDist(bmu)
@@ -950,7 +1060,7 @@ int Som::measureSimilarity(const DataSet *data, int numOfSigmas, size_t minBmuHi
     if (n == 0)
         return true;
     refreshHost();
-    check(vsom_upload_chunk(ctx, data->contiguous().data(), n), "vsom_upload_chunk");
+    check(vsom_upload_chunk(ctx, data->contiguous(), n), "vsom_upload_chunk");
     std::vector<uint64_t> bmus(n);
     check(vsom_bmu_restricted_batch(ctx, minBmuHits, bmus.data(), nullptr), "vsom_bmu_restricted_batch");
     bool success = true;
