@@ -114,6 +114,25 @@ def test_search_single_copy_and_checkpoint(dumps):
         check_state(read_dump(os.path.join(d, name)), o, with_S=True)
 
 
+def test_octave_text_checkpoint(dumps):
+    """Som::save writes the reference's text format (Som.cpp:1209-1294) byte for byte; Som(const
+    char*) + Som::load read it back (six decimals, no SMap -- as the reference)."""
+    import octave_text
+    d, _, _ = dumps
+    src = read_dump(os.path.join(d, "single_text_src.bin"))
+    U = np.array([float.fromhex(t) for t in open(os.path.join(d, "umatrix.txt")).read().split()])
+    want = octave_text.render(10, 10, 9, src["map"], src["sigma"], src["weight"], src["hits"], U)
+    assert src["hits"][4 * 10 + 3] == 2                     # the two addBmu(SomIndex(3,4)) calls
+    assert open(os.path.join(d, "ckpt.txt")).read() == want
+    assert open(os.path.join(d, "ckpt2.txt")).read() == want
+    got = read_dump(os.path.join(d, "single_text_loaded.bin"))
+    assert (got["map"] == octave_text.round6(src["map"]).astype(np.float32)).all()
+    assert (got["sigma"] == octave_text.round6(src["sigma"]).astype(np.float32)).all()
+    assert (got["weight"] == octave_text.round6(src["weight"]).astype(np.float32)).all()
+    assert (got["hits"] == src["hits"]).all()
+    assert (got["S"] == 0).all()                            # not part of the format (Som.cpp:51-83 zeroes it)
+
+
 def test_custom_transformation_is_rejected_not_emulated(dumps):
     _, out, err = dumps
     assert "custom_transformation_rejected=1 kind=-1" in out

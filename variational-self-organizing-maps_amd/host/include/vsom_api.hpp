@@ -438,8 +438,9 @@ public:
     bool isCompatibleWithData(DataSet &data) const noexcept;
     void randomInitialize(int seed, float sigma);
     void addBmu(SomIndex position);
-    void save(const char *filename) const;
-    void load(const char *filename);
+    void save(const char *filename) const;   // Octave text format of the reference (Som.cpp:1209-1294)
+    void load(const char *filename);         // that format (Som.cpp:1343-1597), or saveBinary's
+    void saveBinary(const char *filename) const;   // [MI355X build] lossless, incl. SMap
 
     // ---- [MI355X build] bulk state access (row-major N x depth) and device selection -----------
     void setState(const float *map, const float *sigma, const float *S, const float *weight, const uint64_t *hits);

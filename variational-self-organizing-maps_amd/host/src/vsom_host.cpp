@@ -4,6 +4,7 @@
 // the drivers (train / trainBatchSom / trainBasicSom) restate the reference's control flow
 // (src/Som.cpp:716-754, 1113-1187) around those calls.  No training arithmetic runs here.
 #include "vsom_api.hpp"
+#include "vsom_checkpoint.hpp"
 #include "../../../include/vsom_hip.h"
 
 #include <algorithm>
@@ -474,9 +475,29 @@ Som::Som(size_t w, size_t h, size_t d, Transformation transformation) : transfor
     Construct(w, h, d, std::vector<std::string>{});
 }
 
+// Som.cpp:51-83: size the map from the file (getSizeFromFile), zero state, default (Standard)
+// transformation, then load.  A binary checkpoint of this build carries its own dimensions.
 Som::Som(const char *filename) : _isTraining{false}
 {
     width = height = depth = 0;
+    {
+        std::ifstream f(filename, std::ios::binary);
+        uint64_t magic = 0;
+        f.read((char *)&magic, sizeof(magic));
+        if (!f || magic != 0x314d4f5356ull) {
+            size_t w = 0, h = 0, d = 0;
+            if (!vsom::read_octave_dims(filename, w, h, d)) {
+                std::cout << "Could not open file " << filename << " for reading. Quitting...\n";
+                std::exit(EXIT_FAILURE);   // :1306-1310
+            }
+            width = w;
+            height = h;
+            depth = d;
+            inLen = d;
+            uMatrix.assign(width * height, 0.0);
+            createContext();
+        }
+    }
     load(filename);
 }
 
@@ -1135,9 +1156,31 @@ int Som::autoEncoder(const DataSet *data, size_t minBmuHits) const
 
 // ---- checkpoint: lossless little-endian binary of this build (the reference's Octave text format,
 //      Som.cpp:1209-1597, is a "next" row) --------------------------------------------------------------
+// Som.cpp:1209-1294: the Octave/Matlab text checkpoint, byte-compatible with the reference's writer
+// (vsom_checkpoint.cpp).  Like the reference's it keeps six decimals and no SMap; saveBinary below
+// is this build's lossless alternative.
 void Som::save(const char *fileName) const
 {
     requireDevicePath("save");
+    vsom::Checkpoint c;
+    c.width = width;
+    c.height = height;
+    c.depth = depth;
+    c.resize();
+    getState(c.map.data(), c.sigma.data(), nullptr, c.weight.data(), c.hits.data());
+    c.U = uMatrix;
+    c.U.resize(width * height, 0.0);
+    if (!vsom::write_octave(fileName, c)) {
+        std::cout << "Could not open file " << fileName << " for writing. Quitting...\n";
+        std::exit(EXIT_FAILURE);   // Som.cpp:1213-1217
+    }
+}
+
+// [MI355X build] lossless binary checkpoint (all five state arrays incl. SMap, the sample length
+// and the transformation kind); Som::load recognises it by its magic.
+void Som::saveBinary(const char *fileName) const
+{
+    requireDevicePath("saveBinary");
     const size_t N = width * height;
     std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
     std::vector<uint64_t> hh(N);
@@ -1145,7 +1188,7 @@ void Som::save(const char *fileName) const
     std::ofstream f(fileName, std::ios::binary);
     if (!f) {
         std::cout << "Could not open file " << fileName << " for writing. Quitting...\n";
-        std::exit(EXIT_FAILURE);   // Som.cpp:1213-1217
+        std::exit(EXIT_FAILURE);
     }
     const uint64_t hdr[6] = {0x314d4f5356ull /* "VSOM1" */, width, height, depth, inLen, (uint64_t)transform.kind()};
     f.write((const char *)hdr, sizeof(hdr));
@@ -1156,38 +1199,62 @@ void Som::save(const char *fileName) const
     f.write((const char *)hh.data(), hh.size() * 8);
 }
 
+// Som.cpp:1343-1597: reads the Octave text checkpoint into the EXISTING map (dimensions come from
+// the constructor, Som.cpp:51-83, or from the object as it is); SMap is not part of that format and
+// is left as it is.  A file that starts with this build's binary magic is loaded losslessly instead.
 void Som::load(const char *fileName)
 {
     std::ifstream f(fileName, std::ios::binary);
     if (!f) {
         std::cout << "Could not open file " << fileName << " for reading. Quitting...\n";
+        std::exit(EXIT_FAILURE);   // :1359-1363
+    }
+    uint64_t hdr[6] = {0, 0, 0, 0, 0, 0};
+    f.read((char *)hdr, sizeof(hdr));
+    if (f && hdr[0] == 0x314d4f5356ull) {
+        if (ctx)
+            vsom_destroy(ctx);
+        ctx = nullptr;
+        width = hdr[1];
+        height = hdr[2];
+        depth = hdr[3];
+        inLen = hdr[4];
+        transform = hdr[5] == vsom::Median ? Transformation::StandardMedianEstimator({})
+                    : hdr[5] == vsom::Clr  ? Transformation::CombinatorialLinearRegression({})
+                                           : Transformation::Standard({});
+        uMatrix.assign(width * height, 0.0);
+        createContext();
+        const size_t N = width * height;
+        std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
+        std::vector<uint64_t> hh(N);
+        f.read((char *)m.data(), m.size() * 4);
+        f.read((char *)s.data(), s.size() * 4);
+        f.read((char *)S.data(), S.size() * 4);
+        f.read((char *)w.data(), w.size() * 4);
+        f.read((char *)hh.data(), hh.size() * 8);
+        if (!f)
+            throw std::runtime_error("truncated VSOM1 checkpoint");
+        setState(m.data(), s.data(), S.data(), w.data(), hh.data());
+        return;
+    }
+    f.close();
+    requireDevicePath("load");
+    vsom::Checkpoint c;
+    c.width = width;
+    c.height = height;
+    c.depth = depth;
+    c.resize();
+    getState(c.map.data(), c.sigma.data(), nullptr, c.weight.data(), c.hits.data());   // sections absent from the file keep their values
+    c.U = uMatrix;
+    c.U.resize(width * height, 0.0);
+    if (!vsom::read_octave(fileName, c)) {
+        std::cout << "Could not open file " << fileName << " for reading. Quitting...\n";
         std::exit(EXIT_FAILURE);
     }
-    uint64_t hdr[6];
-    f.read((char *)hdr, sizeof(hdr));
-    if (!f || hdr[0] != 0x314d4f5356ull)
-        throw std::runtime_error("not a VSOM1 checkpoint");
-    if (ctx)
-        vsom_destroy(ctx);
-    ctx = nullptr;
-    width = hdr[1];
-    height = hdr[2];
-    depth = hdr[3];
-    inLen = hdr[4];
-    transform = hdr[5] == vsom::Median ? Transformation::StandardMedianEstimator({})
-                : hdr[5] == vsom::Clr  ? Transformation::CombinatorialLinearRegression({})
-                                       : Transformation::Standard({});
-    uMatrix.assign(width * height, 0.0);
-    createContext();
-    const size_t N = width * height;
-    std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
-    std::vector<uint64_t> hh(N);
-    f.read((char *)m.data(), m.size() * 4);
-    f.read((char *)s.data(), s.size() * 4);
-    f.read((char *)S.data(), S.size() * 4);
-    f.read((char *)w.data(), w.size() * 4);
-    f.read((char *)hh.data(), hh.size() * 8);
-    if (!f)
-        throw std::runtime_error("truncated VSOM1 checkpoint");
-    setState(m.data(), s.data(), S.data(), w.data(), hh.data());
+    if (c.width * c.height != width * height)
+        throw std::runtime_error("checkpoint does not match the map size");
+    width = c.width;      // "# rows" / "# columns" of the last 2-D section (:1470-1483)
+    height = c.height;
+    uMatrix = c.U;
+    setState(c.map.data(), c.sigma.data(), nullptr, c.weight.data(), c.hits.data());
 }

@@ -99,9 +99,23 @@ int main(int argc, char **argv)
         // a copy carries the state (copy constructor, SOM.hpp:90-105)
         Som copy{som};
         dump(out + "/single_copy.bin", copy, {});
-        som.save((out + "/ckpt.vsom").c_str());
+        som.saveBinary((out + "/ckpt.vsom").c_str());             // lossless (incl. SMap)
         Som loaded{(out + "/ckpt.vsom").c_str()};
         dump(out + "/single_loaded.bin", loaded, {});
+        som.addBmu(SomIndex(3, 4));
+        som.addBmu(SomIndex(3, 4));
+        som.updateUMatrix(ones);
+        dump(out + "/single_text_src.bin", som, {});
+        som.save((out + "/ckpt.txt").c_str());                    // the reference's Octave text format
+        Som fromText{(out + "/ckpt.txt").c_str()};                // Som(const char*) sizes the map from the file
+        dump(out + "/single_text_loaded.bin", fromText, {});
+        fromText.save((out + "/ckpt2.txt").c_str());              // load -> save is idempotent
+        {
+            std::ofstream u(out + "/umatrix.txt");
+            const UMatrix um = som.getUMatrix();   // keep the temporary alive for the loop
+            for (double x : um.getData())
+                u << std::hexfloat << x << "\n";
+        }
     }
     // ---- consumers of the search: restricted BMU / BMD, U-matrix, evaluate, measureSimilarity ----
     {

@@ -4,9 +4,11 @@
 //   host_loader_test mnist  <folder> <maxLoadCount|0>
 //   host_loader_test sqlite <db> <table> <maxLoadCount|0> <col,col,...>
 //   host_loader_test spec   <db> <specfile> <maxLoadCount|0>
+//   host_loader_test octave <in.txt> <out.txt>      (reference checkpoint text: read dims, load, save)
 #include "DataSet.hpp"
 #include "MnistDataLoader.hpp"
 #include "SqliteDataLoader.hpp"
+#include "vsom_checkpoint.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -39,6 +41,16 @@ int main(int argc, char **argv)
     if (argc < 4)
         return 2;
     const std::string mode = argv[1];
+    if (mode == "octave") {
+        vsom::Checkpoint c;
+        if (!vsom::read_octave_dims(argv[2], c.width, c.height, c.depth))
+            return 3;
+        std::printf("DIMS %zu %zu %zu\n", c.width, c.height, c.depth);
+        c.resize();
+        if (!vsom::read_octave(argv[2], c))
+            return 3;
+        return vsom::write_octave(argv[3], c) ? 0 : 4;
+    }
     auto count = [](const char *s) -> std::optional<size_t> {
         const long v = std::atol(s);
         return v > 0 ? std::optional<size_t>((size_t)v) : std::nullopt;
