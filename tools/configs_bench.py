@@ -72,11 +72,17 @@ def online_case(name, W, J, tr, B, sigma, X, init, decay):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"c2", "c3local", "c4", "c5", "online"}
+    which = set(sys.argv[1:]) or {"c2", "c2median", "c3local", "c4", "c5", "online"}
     if "c2" in which:
         X = gen.mnist_like(4096, 3, 784)
         init = gen.random_map(64 * 64, 784, 42) * np.float32(100) + np.float32(100)
         batch_case("C2 64x64x784 std first", 64, 784, capi.STANDARD, 4096, 16.0, X, init)
+    if "c2median" in which:
+        X = gen.mnist_like(4096, 3, 784)
+        init = gen.random_map(64 * 64, 784, 42) * np.float32(100) + np.float32(100)
+        batch_case("C2m 64x64x784 median first", 64, 784, capi.MEDIAN, 4096, 16.0, X, init)
+        init = gen.random_map(128 * 128, 784, 42) * np.float32(100) + np.float32(100)
+        batch_case("C3m 128x128x784 median first", 128, 784, capi.MEDIAN, 4096, 32.0, X, init, steps=5)
     if "c3local" in which:
         X = gen.mnist_like(4096, 3, 784)
         init = gen.random_map(128 * 128, 784, 42) * np.float32(100) + np.float32(100)

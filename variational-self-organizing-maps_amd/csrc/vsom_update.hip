@@ -329,15 +329,16 @@ __global__ __launch_bounds__(CWP_THREADS) void cwp_kernel(const int2 *__restrict
         weight[n0 + nl] = run;                   // :875
 }
 
-// Eigen scalar_sign_op<float>: NaN -> NaN, else (a>0)-(a<0) as float (Transformation.cpp:50)
+// Eigen scalar_sign_op<float> (Transformation.cpp:50) as the chains need it: +-1 for a nonzero
+// number, NaN for NaN, and the argument itself for +-0.  The reference yields +0 for -0; inside the
+// chains the difference cannot surface: t = c*s is -0 instead of +0 (or NaN either way when c is
+// NaN/inf), M + (-0) == M + (+0) because M is never -0 (it starts at +0 and x + y is -0 only for
+// -0 + -0), and (w*s)*s is +0 either way.  Three VALU ops (v_bfi, v_cmp_lg, v_cndmask) instead of
+// five -- the sign is what the Median kernels spend their time on.
 __device__ __forceinline__ float vsom_sign(float a)
 {
-    // straight-line selects (v_cmp + v_cndmask, no exec-mask branches): a + 0.f is +0 for +-0 and
-    // NaN for NaN (not foldable under strict IEEE semantics), then the two signs override it
-    float s = a + 0.f;
-    s = a > 0.f ? 1.f : s;
-    s = a < 0.f ? -1.f : s;
-    return s;
+    const float one = __builtin_copysignf(1.f, a);
+    return (a < 0.f || a > 0.f) ? one : a;
 }
 
 // Standard / Median: lane = node, RD dims per lane, 4 waves per workgroup = 4 dim slices
