@@ -151,6 +151,10 @@ int vsom_get_sqres(vsom_ctx *ctx, float *out_host);
  * Som::findBmu for every sample of the chunk (Som.cpp:291-309, distance :124-141);
  * writes lastBMU / sqres on the device; optional host copies.                             */
 int vsom_bmu_batch(vsom_ctx *ctx, uint64_t *idx_out_host, float *dist_out_host);
+/* Som::findBmu(v) for one host vector (Som.cpp:283-309; the perf harness calls it 1000 times,
+ * tests/performance/perf_tests.cpp:181-199): one copy, one scan launch, 32 bytes back.  Does not
+ * touch the staged chunk.  dist_out = euclidianWeightedDist(bmu, v) (NaN when node 0 is NaN). */
+int vsom_find_bmu(vsom_ctx *ctx, const float *v_host, uint64_t *bmu_out, float *dist_out);
 /* Som::findLocalBmu from the current lastBMU of every sample (Som.cpp:335-454) */
 int vsom_bmu_local_batch(vsom_ctx *ctx, uint64_t *idx_out_host, float *dist_out_host);
 /* Som::euclidianWeightedDist(pos, v, ...) for `count` (node, sample-row) pairs of the chunk */

@@ -76,3 +76,38 @@ def test_train_single_api(tr, fn, sigma):
         assert beq(st[k], getattr(o, k)), k
     assert (st["hits"] == 0).all()      # trainSingle itself does not count hits (addBmu is the driver's)
     ctx.close()
+
+
+@pytest.mark.parametrize("tr,W,H,J", [(po.STANDARD, 100, 100, 100), (po.STANDARD, 7, 5, 13), (po.MEDIAN, 12, 12, 9),
+                                      (po.CLR, 8, 8, 6)])
+def test_find_bmu_single_vector(tr, W, H, J):
+    """vsom_find_bmu (Som::findBmu of one host vector, the perf harness's findBmu x1000 scenario):
+    index and distance bit-identical to the oracle; the staged chunk is left alone."""
+    D = po.length(tr, J)
+    init = gen.random_map(W * H, D, seed=42)
+    X = gen.correlated(40, J, seed=5) if tr == po.CLR else gen.blobs(40, J, 4, 1, 2)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    orc = po.OracleSom(W, H, J, tr)
+    ctx.set_state(map=init)
+    orc.set_state(map=init)
+    ctx.upload_chunk(X[:7])
+    for i in range(len(X)):
+        idx, dist = ctx.find_bmu(X[i])
+        want = orc.find_bmu(X[i])
+        assert idx == want, i
+        assert np.float32(dist).view(np.uint32) == np.float32(orc.dist(want, X[i])).view(np.uint32), i
+    assert ctx.chunk_size == 7
+    # NaN at node 0 pins the BMU to node 0 (Som.cpp:293-299); NaN elsewhere never wins
+    bad = init.copy()
+    bad[0, 0] = np.nan
+    bad[min(5, W * H - 1), 1] = np.nan
+    ctx.set_state(map=bad)
+    orc.set_state(map=bad)
+    idx, dist = ctx.find_bmu(X[0])
+    assert idx == orc.find_bmu(X[0]) == 0 and np.isnan(dist)
+    bad[0, 0] = init[0, 0]
+    ctx.set_state(map=bad)
+    orc.set_state(map=bad)
+    for i in range(10):
+        assert ctx.find_bmu(X[i])[0] == orc.find_bmu(X[i])
+    ctx.close()

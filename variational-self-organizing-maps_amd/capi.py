@@ -27,7 +27,7 @@ SYMBOLS = [
     "vsom_synchronize", "vsom_set_bmu_mode", "vsom_set_update_mode", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
     "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_host_alloc", "vsom_host_free",
     "vsom_prefetch_chunk", "vsom_prefetch_wait", "vsom_commit_chunk", "vsom_get_last_bmu",
-    "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_bmu_local_batch",
+    "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_find_bmu", "vsom_bmu_local_batch",
     "vsom_distances", "vsom_bmu_restricted_batch", "vsom_distances_row", "vsom_distances_raw", "vsom_batch_phase1_async", "vsom_batch_finish_async",
     "vsom_batch_phase2_async", "vsom_batch_epoch_async", "vsom_batch_epoch", "vsom_get_mse",
     "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk",
@@ -92,6 +92,7 @@ def lib():
     L.vsom_set_last_bmu.argtypes = [vp, u64p]
     L.vsom_get_sqres.argtypes = [vp, fp]
     L.vsom_bmu_batch.argtypes = [vp, u64p, fp]
+    L.vsom_find_bmu.argtypes = [vp, fp, u64p, fp]
     L.vsom_bmu_local_batch.argtypes = [vp, u64p, fp]
     L.vsom_distances.argtypes = [vp, u64p, u64p, C.c_size_t, fp]
     L.vsom_bmu_restricted_batch.argtypes = [vp, C.c_uint64, u64p, fp]
@@ -283,6 +284,14 @@ class Context:
         idx, dist = np.empty(B, np.uint64), np.empty(B, np.float32)
         check(lib().vsom_bmu_batch(self._h, _u(idx), _f(dist)))
         return idx, dist
+
+    def find_bmu(self, v):
+        """Som::findBmu of one host vector (does not disturb the staged chunk)."""
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        assert v.size == self.in_len
+        idx, dist = C.c_uint64(), C.c_float()
+        check(lib().vsom_find_bmu(self._h, _f(v), C.byref(idx), C.byref(dist)))
+        return int(idx.value), np.float32(dist.value)
 
     def bmu_local_batch(self):
         B = self.chunk_size

@@ -83,6 +83,8 @@ static int free_all(vsom_ctx *c)
             (void)hipFree(p);
     if (c->lut_host)
         (void)hipHostFree(c->lut_host);
+    if (c->v_pinned)
+        (void)hipHostFree(c->v_pinned);
     if (c->sl_fb)
         (void)hipHostFree(c->sl_fb);
     for (auto &e : c->ev_live) {

@@ -91,6 +91,7 @@ struct vsom_ctx {
 
     // online path scratch
     float *v_dev = nullptr;         // one sample, padded
+    float *v_pinned = nullptr;      // its pinned host staging (+ 16 floats for results)
     float *res_dev = nullptr;       // residual
     u64 *onl_state = nullptr;       // [4]: bmu, lastbmu, ...
     float *onl_f = nullptr;         // [4]: dist, mse

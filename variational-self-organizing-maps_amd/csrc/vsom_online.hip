@@ -18,6 +18,7 @@
 #include "vsom_device.hpp"
 #include <cmath>
 #include <algorithm>
+#include <cstring>
 
 // onl_state: [0],[1] argmin key of even / odd samples, [2],[3] their node-0-NaN flags ;
 // onl_f: [0] dist, [1] mse sum
@@ -368,7 +369,8 @@ static int ensure_lutd(vsom_ctx *c, double sigma, const double **out, int *lutw)
 // enqueue one trainSingle on sample rows (xs / xp / yp), lastBMU in/out at `lastbmu_dev`
 static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const float *yp,
                           double eta, double sigma, int decay_fn, u64 *lastbmu_dev,
-                          float *residual_dev, float fB, int add_hit, const double *lutd, int lutw, int par)
+                          float *residual_dev, float fB, int add_hit, const double *lutd, int lutw, int par,
+                          float *fstate = nullptr)
 {
     OnlineArgs a;
     a.par = par & 1;
@@ -381,7 +383,7 @@ static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const f
     a.d.ldm = (int)c->pitch;
     a.d.L = (int)c->part_len;
     a.state = c->onl_state;
-    a.fstate = c->onl_f;
+    a.fstate = fstate ? fstate : c->onl_f;   // {distance of the BMU, MSE running sum}
     a.N = (int)c->N;
     a.W = (int)c->W;
     a.H = (int)c->H;
@@ -429,7 +431,91 @@ static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const f
     return VSOM_OK;
 }
 
+// one host vector -> the single-sample device rows [xs | xp | yp | residual] (v_dev), through a pinned
+// host buffer; CLR expands x'/y' (Transformation.cpp:94-101).  The copy is enqueued on the stream.
+static int stage_single(vsom_ctx *c, const float *v_host)
+{
+    const size_t xs_n = c->xpitch, pp = c->part_pitch;
+    const size_t nstage = xs_n + 2 * pp;
+    if (!c->v_dev) {
+        // device: [xs | xp | yp | residual(pp) | tail(16)]; tail = {u64 lastBMU/bmu, float dist, float mse}
+        VSOM_HIP_CHECK(hipMalloc(&c->v_dev, (xs_n + 3 * pp + 16) * sizeof(float)));
+        VSOM_HIP_CHECK(hipMalloc(&c->res_dev, 64));
+        VSOM_HIP_CHECK(hipHostMalloc(&c->v_pinned, (xs_n + 3 * pp + 32) * sizeof(float)));
+    } else {
+        // the previous call's copy out of the pinned buffer has been waited for (every caller
+        // synchronises the stream before returning)
+    }
+    float *host = c->v_pinned;
+    std::fill(host, host + nstage, 0.f);
+    for (uint32_t d = 0; d < c->J; ++d)
+        host[d] = v_host[d];
+    if (c->transform == VSOM_CLR) {
+        size_t p = 0;
+        for (uint32_t i = 0; i < c->J; ++i)
+            for (uint32_t j = i + 1; j < c->J; ++j) {
+                host[xs_n + p] = v_host[i];
+                host[xs_n + pp + p] = v_host[j];
+                ++p;
+            }
+    }
+    VSOM_HIP_CHECK(hipMemcpyAsync(c->v_dev, host, nstage * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    return VSOM_OK;
+}
+
 extern "C" {
+
+// Som::findBmu(v) for ONE host vector (Som.cpp:283-309) without touching the staged chunk: copy,
+// one scan launch (8 lanes per node, atomicMin on the (distance, index) key), 32 bytes back.
+int vsom_find_bmu(vsom_ctx *c, const float *v_host, uint64_t *bmu_out, float *dist_out)
+{
+    if (!c)
+        return vsom_fail(VSOM_ERR_INVALID, "null context");
+    VSOM_HIP_CHECK(hipSetDevice(c->device));
+    if (int jrc = vsom_join_aux(c))
+        return jrc;
+    if (!v_host)
+        return vsom_fail(VSOM_ERR_INVALID, "null argument");
+    int rc = stage_single(c, v_host);
+    if (rc)
+        return rc;
+    const bool clr = c->transform == VSOM_CLR;
+    const size_t xs_n = c->xpitch, pp = c->part_pitch;
+    float *xs = c->v_dev, *xp = c->v_dev + xs_n, *yp = xp + pp;
+    OnlineArgs a;
+    a.par = 0;
+    a.d.xa = clr ? xp : xs;
+    a.d.xb = clr ? yp : xs;
+    a.d.ldx = 0;
+    a.d.ma = c->map;
+    a.d.mb = clr ? c->map + c->part_pitch : c->map;
+    a.d.ldm = (int)c->pitch;
+    a.d.L = (int)c->part_len;
+    a.state = c->onl_state;
+    a.fstate = c->onl_f;
+    a.N = (int)c->N;
+    a.W = (int)c->W;
+    a.H = (int)c->H;
+    VSOM_HIP_CHECK(hipMemsetAsync(c->onl_state, 0xFF, 8, c->stream));   // arm the key of parity 0
+    dim3 grid((unsigned)(((size_t)c->N * 8 + 255) / 256));
+    if (clr)
+        hipLaunchKernelGGL(online_scan_kernel<true>, grid, dim3(256), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL(online_scan_kernel<false>, grid, dim3(256), 0, c->stream, a);
+    VSOM_HIP_CHECK(hipGetLastError());
+    u64 *st = reinterpret_cast<u64 *>(c->v_pinned + xs_n + 2 * pp);      // 16 spare floats behind the rows
+    VSOM_HIP_CHECK(hipMemcpyAsync(st, c->onl_state, 32, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const bool nan0 = st[2] != 0;     // a NaN distance at node 0 pins the BMU to 0 (Som.cpp:293-299)
+    const uint64_t bmu = nan0 ? 0ull : (st[0] & 0xFFFFFFFFull);
+    if (bmu_out)
+        *bmu_out = bmu;
+    if (dist_out) {
+        const uint32_t bits = nan0 ? 0x7FC00000u : (uint32_t)(st[0] >> 32);
+        std::memcpy(dist_out, &bits, 4);
+    }
+    return VSOM_OK;
+}
 
 int vsom_train_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn, float *mse_out)
 {
@@ -485,48 +571,41 @@ int vsom_train_single(vsom_ctx *c, const float *v_host, double eta, double sigma
         return vsom_fail(VSOM_ERR_INVALID, "online training needs Exponential or InverseProportional");
     if (*last_bmu >= c->N)
         return vsom_fail(VSOM_ERR_INVALID, "lastBMU out of range");
-    // single-sample staging buffers: [xs | xp | yp | residual] + lastBMU
-    const size_t xs_n = c->xpitch, pp = c->part_pitch;
-    if (!c->v_dev) {
-        VSOM_HIP_CHECK(hipMalloc(&c->v_dev, (xs_n + 3 * pp) * sizeof(float)));
-        VSOM_HIP_CHECK(hipMalloc(&c->res_dev, 64));
-    }
-    std::vector<float> host(xs_n + 2 * pp, 0.f);
-    for (uint32_t d = 0; d < c->J; ++d)
-        host[d] = v_host[d];
-    if (c->transform == VSOM_CLR) {
-        size_t p = 0;
-        for (uint32_t i = 0; i < c->J; ++i)
-            for (uint32_t j = i + 1; j < c->J; ++j) {   // Transformation.cpp:94-101
-                host[xs_n + p] = v_host[i];
-                host[xs_n + pp + p] = v_host[j];
-                ++p;
-            }
-    }
-    const double *lutd = nullptr;
-    int lutw = 0;
-    int rc = ensure_lutd(c, sigma, &lutd, &lutw);
+    int rc = stage_single(c, v_host);
     if (rc)
         return rc;
-    float *xs = c->v_dev, *xp = c->v_dev + xs_n, *yp = xp + pp, *res = yp + pp;
-    u64 *lb = reinterpret_cast<u64 *>(c->res_dev);
-    VSOM_HIP_CHECK(hipMemcpyAsync(xs, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    VSOM_HIP_CHECK(hipMemcpyAsync(lb, last_bmu, 8, hipMemcpyHostToDevice, c->stream));
+    const size_t xs_n = c->xpitch, pp = c->part_pitch;
+    const double *lutd = nullptr;
+    int lutw = 0;
+    rc = ensure_lutd(c, sigma, &lutd, &lutw);
+    if (rc)
+        return rc;
+    float *xs = c->v_dev, *xp = c->v_dev + xs_n, *yp = xp + pp, *res = yp + pp, *tail = res + pp;
+    u64 *lb = reinterpret_cast<u64 *>(tail);
+    // inputs and outputs travel through the pinned buffer: rows (stage_single), a 16-byte tail in,
+    // residual + tail out -- three small asynchronous copies and one synchronisation per call
+    float *ptail_in = c->v_pinned + xs_n + 3 * pp + 16;      // host image of the tail going in
+    float *pout = c->v_pinned + xs_n + 2 * pp;               // host image of [residual | tail] coming out
+    std::memcpy(ptail_in, last_bmu, 8);
+    ptail_in[2] = 0.f;
+    ptail_in[3] = 0.f;
+    VSOM_HIP_CHECK(hipMemcpyAsync(tail, ptail_in, 16, hipMemcpyHostToDevice, c->stream));
     {
         TimerScope ts(c, VSOM_T_ONLINE);
         hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f);
-        rc = enqueue_single(c, xs, xp, yp, eta, sigma, decay_fn, lb, res, 1.0f, 0, lutd, lutw, 0);
+        rc = enqueue_single(c, xs, xp, yp, eta, sigma, decay_fn, lb, res, 1.0f, 0, lutd, lutw, 0, tail + 2);
         if (rc)
             return rc;
         VSOM_HIP_CHECK(hipGetLastError());
     }
-    uint64_t bmu = 0;
-    VSOM_HIP_CHECK(hipMemcpyAsync(&bmu, lb, 8, hipMemcpyDeviceToHost, c->stream));
-    if (residual_out)
-        VSOM_HIP_CHECK(hipMemcpyAsync(residual_out, res, (size_t)c->part_len * 4, hipMemcpyDeviceToHost, c->stream));
-    if (dist_out)
-        VSOM_HIP_CHECK(hipMemcpyAsync(dist_out, c->onl_f, 4, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipMemcpyAsync(pout, res, (pp + 4) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    uint64_t bmu = 0;
+    std::memcpy(&bmu, pout + pp, 8);
+    if (residual_out)
+        std::memcpy(residual_out, pout, (size_t)c->part_len * 4);
+    if (dist_out)
+        *dist_out = pout[pp + 2];
     *last_bmu = bmu;
     if (bmu_out)
         *bmu_out = bmu;

@@ -713,9 +713,11 @@ SomIndex Som::findBmu(const Eigen::VectorXf &v) const
 
 SomIndex Som::findBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &, const Eigen::VectorXf &) const
 {
-    stageOne(v);
+    requireDevicePath("findBmu");
+    if ((size_t)v.size() != inLen)
+        throw std::invalid_argument("sample length does not match the map");
     uint64_t idx = 0;
-    check(vsom_bmu_batch(ctx, &idx, nullptr), "vsom_bmu_batch");
+    check(vsom_find_bmu(ctx, v.data(), &idx, nullptr), "vsom_find_bmu");
     return SomIndex((size_t)idx % width, (size_t)idx / width);   // Som.cpp:306
 }
 

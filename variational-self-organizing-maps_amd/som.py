@@ -233,9 +233,8 @@ class Som:
         self.ctx.upload_chunk(v)
 
     def findBmu(self, v, valid=None, weights=None):
-        self._stage_one(v)
-        idx, _ = self.ctx.bmu_batch()
-        return SomIndex(int(idx[0]) % self.width, int(idx[0]) // self.width)
+        idx, _ = self.ctx.find_bmu(v)
+        return SomIndex(idx % self.width, idx // self.width)
 
     def findLocalBmu(self, v, valid, lastBMUref, weights=None):
         self._stage_one(v)
