@@ -54,6 +54,10 @@ CASES = [
     ("median_ragged", 9, 9, 11, po.MEDIAN, 50, 4.0),
     ("c5_clr_J8", 8, 8, 8, po.CLR, 128, 4.0),
     ("clr_J5_ragged", 6, 7, 5, po.CLR, 45, 3.0),
+    # node counts that select the 32- and 64-node role-split neighbourhood kernels, ragged chunks
+    ("cw32_96x96x6", 96, 96, 6, po.STANDARD, 333, 20.0),
+    ("cw64_128x128x4", 128, 128, 4, po.STANDARD, 77, 30.0),
+    ("cw64_130x127x3_median", 130, 127, 3, po.MEDIAN, 130, 25.0),
 ]
 
 
