@@ -369,8 +369,11 @@ static int ensure_chunk_capacity(vsom_ctx *c, size_t B)
     VSOM_HIP_CHECK(hipMalloc(&c->Xs, (cap + 8) * c->xpitch * 4));
     VSOM_HIP_CHECK(hipMemset(c->Xs, 0, (cap + 8) * c->xpitch * 4));
     if (c->transform == VSOM_CLR) {
-        VSOM_HIP_CHECK(hipMalloc(&c->XP, cap * c->part_pitch * 4));
-        VSOM_HIP_CHECK(hipMalloc(&c->YP, cap * c->part_pitch * 4));
+        // like Xs: the pipelined update kernels read one sample pair past the chunk
+        VSOM_HIP_CHECK(hipMalloc(&c->XP, (cap + 8) * c->part_pitch * 4));
+        VSOM_HIP_CHECK(hipMalloc(&c->YP, (cap + 8) * c->part_pitch * 4));
+        VSOM_HIP_CHECK(hipMemset(c->XP, 0, (cap + 8) * c->part_pitch * 4));
+        VSOM_HIP_CHECK(hipMemset(c->YP, 0, (cap + 8) * c->part_pitch * 4));
     }
     VSOM_HIP_CHECK(hipMalloc(&c->lastbmu, cap * 8));
     VSOM_HIP_CHECK(hipMalloc(&c->sqres, cap * 4));

@@ -367,13 +367,24 @@ __global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ X
         S[k] = 0.f;   // currentModelSigma.setZero()  :844
     }
     vsom_cfp xr = (vsom_cfp)(Xs + d0);
-    for (int j = 0; j < B; ++j) {
-        const float2 v = cw[cw2_index(j, ldn, nlc)];
-        const float c = v.x, w = v.y;
+    const float4 *cp = (const float4 *)cw + nlc;     // {c_j, w_j, c_j+1, w_j+1} of pair row r at cp[r * ldn]
+    // Sample pairs, software-pipelined: the scalar loads of x and the (c,w) load of pair r+1 are
+    // issued before pair r is consumed (two register sets used alternately).  Reads one pair past
+    // the chunk at most: Xs has B+8 rows, cw ceil(B/2)+8 pair rows.
+    auto load = [&](float (&xa)[RD], float (&xb)[RD], float4 &cv, int r) {
+        vsom_cfp p0 = xr + (size_t)(2 * r) * ldx;
+        vsom_cfp p1 = p0 + ldx;
 #pragma unroll
         for (int k = 0; k < RD; ++k) {
-            float x = xr[k];
-            float dl = x - M[k];            // Stepper: value - model        (Transformation.cpp:12)
+            xa[k] = p0[k];
+            xb[k] = p1[k];
+        }
+        cv = cp[(size_t)r * ldn];
+    };
+    auto step = [&](const float (&x)[RD], float c, float w) {
+#pragma unroll
+        for (int k = 0; k < RD; ++k) {
+            float dl = x[k] - M[k];         // Stepper: value - model        (Transformation.cpp:12)
             if (MEDIAN)
                 dl = vsom_sign(dl);         //          sign(value - model)  (Transformation.cpp:50)
             float t = c * dl;
@@ -382,7 +393,28 @@ __global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ X
             u = u * dl;
             S[k] = S[k] + u;                // :867
         }
-        xr += ldx;
+    };
+    const int npair = B >> 1;
+    float xa0[RD], xa1[RD], xb0[RD], xb1[RD];
+    float4 ca, cb;
+    load(xa0, xa1, ca, 0);
+    int r = 0;
+    for (; r + 2 <= npair; r += 2) {
+        load(xb0, xb1, cb, r + 1);
+        step(xa0, ca.x, ca.y);
+        step(xa1, ca.z, ca.w);
+        load(xa0, xa1, ca, r + 2);
+        step(xb0, cb.x, cb.y);
+        step(xb1, cb.z, cb.w);
+    }
+    if (r < npair) {                       // one more full pair (set a holds it)
+        load(xb0, xb1, cb, r + 1);
+        step(xa0, ca.x, ca.y);
+        step(xa1, ca.z, ca.w);
+        if (B & 1)
+            step(xb0, cb.x, cb.y);         // odd tail sample = first half of the next pair row
+    } else if (B & 1) {
+        step(xa0, ca.x, ca.y);
     }
     if (valid) {
         const size_t node = (size_t)(n0 + nl);
@@ -525,12 +557,24 @@ __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict
     }
     vsom_cfp xr = (vsom_cfp)(XP + p0);
     vsom_cfp yr = (vsom_cfp)(YP + p0);
-    for (int j = 0; j < B; ++j) {
-        const float2 v = cw[cw2_index(j, ldn, nlc)];
-        const float c = v.x, w = v.y;
+    const float4 *cp = (const float4 *)cw + nlc;
+    // same software pipeline as update_kernel: loads of sample pair r+1 in flight while pair r is used
+    auto load = [&](float (&xa)[RP], float (&ya)[RP], float (&xb)[RP], float (&yb)[RP], float4 &cv, int r) {
+        vsom_cfp px0 = xr + (size_t)(2 * r) * ldx, py0 = yr + (size_t)(2 * r) * ldx;
+        vsom_cfp px1 = px0 + ldx, py1 = py0 + ldx;
 #pragma unroll
         for (int k = 0; k < RP; ++k) {
-            float xp = xr[k], yp = yr[k];
+            xa[k] = px0[k];
+            ya[k] = py0[k];
+            xb[k] = px1[k];
+            yb[k] = py1[k];
+        }
+        cv = cp[(size_t)r * ldn];
+    };
+    auto step = [&](const float (&x)[RP], const float (&y)[RP], float c, float w) {
+#pragma unroll
+        for (int k = 0; k < RP; ++k) {
+            const float xp = x[k], yp = y[k];
             float inner = A[k] * xp;       // A.*x' + B - y'   (Transformation.cpp:129)
             inner = inner + Bv[k];
             inner = inner - yp;
@@ -547,8 +591,28 @@ __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict
             SA[k] = SA[k] + uA;            // Som.cpp:867
             SB[k] = SB[k] + uB;
         }
-        xr += ldx;
-        yr += ldx;
+    };
+    const int npair = B >> 1;
+    float xa0[RP], ya0[RP], xa1[RP], ya1[RP], xb0[RP], yb0[RP], xb1[RP], yb1[RP];
+    float4 ca, cb;
+    load(xa0, ya0, xa1, ya1, ca, 0);
+    int r = 0;
+    for (; r + 2 <= npair; r += 2) {
+        load(xb0, yb0, xb1, yb1, cb, r + 1);
+        step(xa0, ya0, ca.x, ca.y);
+        step(xa1, ya1, ca.z, ca.w);
+        load(xa0, ya0, xa1, ya1, ca, r + 2);
+        step(xb0, yb0, cb.x, cb.y);
+        step(xb1, yb1, cb.z, cb.w);
+    }
+    if (r < npair) {
+        load(xb0, yb0, xb1, yb1, cb, r + 1);
+        step(xa0, ya0, ca.x, ca.y);
+        step(xa1, ya1, ca.z, ca.w);
+        if (B & 1)
+            step(xb0, yb0, cb.x, cb.y);
+    } else if (B & 1) {
+        step(xa0, ya0, ca.x, ca.y);
     }
     if (valid) {
         const size_t node = (size_t)(n0 + nl);
