@@ -83,7 +83,8 @@ struct vsom_ctx {
     double *lutd = nullptr; size_t lutd_cap = 0; double lutd_sigma = -1.0;   // online path (double)
 
     // hand-scheduled update kernel (code object loaded with hipModuleLoadData)
-    void *upd_module = nullptr, *upd_fn16 = nullptr, *upd_fn14 = nullptr, *upd_fma16 = nullptr, *upd_fma14 = nullptr;
+    void *upd_module = nullptr, *upd_fn16 = nullptr, *upd_fn14 = nullptr, *upd_fma16 = nullptr, *upd_fma14 = nullptr,
+         *upd_clr8 = nullptr;
     int update_mode = VSOM_UPDATE_STRICT;
     bool use_asm = true;
     bool use_chain = true;

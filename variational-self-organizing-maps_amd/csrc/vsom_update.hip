@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict
                                                          const float *__restrict__ YP, int ldx,
                                                          const float2 *__restrict__ cw, int ldn,
                                                          int B, int n0, int nloc, int P, int ppitch,
-                                                         int nslices, float *__restrict__ map,
+                                                         int nslices, int pbase, float *__restrict__ map,
                                                          float *__restrict__ sigma, int pitch,
                                                          const float *__restrict__ weight)
 {
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict
     const int slice = blockIdx.y * 4 + wave;
     if (slice >= nslices)
         return;
-    const int p0 = slice * RP;
+    const int p0 = pbase + slice * RP;   // pbase: first pair not covered by the assembly kernel
     const int nl = blockIdx.x * 64 + lane;
     const bool valid = nl < nloc;
     const int nlc = valid ? nl : nloc - 1;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict
 }
 
 // sigmaMap[i] = sqrt(S / W)  (Som.cpp:873) for the columns the assembly kernel left as raw S
-__global__ void sigma_finalize_kernel(float *__restrict__ sigma, int pitch, int ncols, int n0, int nloc,
+__global__ void sigma_finalize_kernel(float *__restrict__ sigma, int pitch, int col0, int ncols, int n0, int nloc,
                                       const float *__restrict__ weight)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -640,7 +640,7 @@ __global__ void sigma_finalize_kernel(float *__restrict__ sigma, int pitch, int 
     const int nl = (int)(i / ncols), d = (int)(i % ncols);
     const size_t node = (size_t)n0 + nl;
     const float Wf = weight[node];
-    float *p = sigma + node * pitch + d;
+    float *p = sigma + node * pitch + col0 + d;
     *p = sqrtf(*p / Wf);
 }
 
@@ -655,7 +655,8 @@ struct UpdAsmArgs {
     const void *cw2;
     void *map;
     void *sbuf;
-    unsigned ldx_bytes, ldn_bytes, B, nloc, nslices, pitch_bytes, n0, pad;
+    unsigned ldx_bytes, ldn_bytes, B, nloc, nslices, pitch_bytes, n0, ppitch_bytes;   // ppitch: CLR only
+    const void *yp;                                                                   // CLR only (kernarg 72 B)
 };
 
 int vsom_load_asm_module(vsom_ctx *c)
@@ -664,16 +665,18 @@ int vsom_load_asm_module(vsom_ctx *c)
         return VSOM_OK;
     hipModule_t mod;
     VSOM_HIP_CHECK(hipModuleLoadData(&mod, vsom_update_hsaco));
-    hipFunction_t f16, f14, m16, m14;
+    hipFunction_t f16, f14, m16, m14, fclr;
     VSOM_HIP_CHECK(hipModuleGetFunction(&f16, mod, "vsom_update_std_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&f14, mod, "vsom_update_std_rd14_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&m16, mod, "vsom_update_fma_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&m14, mod, "vsom_update_fma_rd14_gfx950"));
+    VSOM_HIP_CHECK(hipModuleGetFunction(&fclr, mod, "vsom_update_clr_rp8_gfx950"));
     c->upd_module = mod;
     c->upd_fn16 = f16;
     c->upd_fn14 = f14;
     c->upd_fma16 = m16;
     c->upd_fma14 = m14;
+    c->upd_clr8 = fclr;
     return VSOM_OK;
 }
 
@@ -795,12 +798,45 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         const unsigned gx = (unsigned)((nloc + 63) / 64);
         if (c->transform == VSOM_CLR) {
             constexpr int RP = 8;
-            const int nsl = (int)((c->part_len + RP - 1) / RP);
-            dim3 grid(gx, (unsigned)((nsl + 3) / 4));
-            hipLaunchKernelGGL(update_clr_kernel<RP>, grid, dim3(256), 0, c->stream, c->XP, c->YP,
-                               (int)c->part_pitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
-                               (int)c->part_len, (int)c->part_pitch, nsl, c->map, c->sigma,
-                               (int)c->pitch, c->weight);
+            int pbase = 0;
+            if (c->use_asm) {
+                // hand-scheduled kernel for the full 8-pair slices (gen_update_asm.py, KC)
+                if ((rc = vsom_load_asm_module(c)))
+                    return rc;
+                const unsigned nfull = c->part_len / RP;
+                if (nfull > 0) {
+                    UpdAsmArgs a;
+                    a.xs = c->XP;
+                    a.cw2 = c->cw;
+                    a.map = c->map;
+                    a.sbuf = c->sigma;
+                    a.ldx_bytes = c->part_pitch * 4u;
+                    a.ldn_bytes = (unsigned)(ldn * 16u);
+                    a.B = (unsigned)c->B;
+                    a.nloc = (unsigned)nloc;
+                    a.nslices = nfull;
+                    a.pitch_bytes = c->pitch * 4u;
+                    a.n0 = (unsigned)n0;
+                    a.ppitch_bytes = c->part_pitch * 4u;
+                    a.yp = c->YP;
+                    size_t sz = sizeof(a);
+                    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
+                                     HIP_LAUNCH_PARAM_END};
+                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)c->upd_clr8, 8 * ((nfull + 3) / 4), (gx + 7) / 8, 1,
+                                                         256, 1, 1, 0, c->stream, nullptr, extra));
+                    pbase = (int)(nfull * RP);
+                    sig_cols = pbase;
+                }
+            }
+            const int rest = (int)c->part_len - pbase;
+            if (rest > 0) {
+                const int nsl = (rest + RP - 1) / RP;
+                dim3 grid(gx, (unsigned)((nsl + 3) / 4));
+                hipLaunchKernelGGL(update_clr_kernel<RP>, grid, dim3(256), 0, c->stream, c->XP, c->YP,
+                                   (int)c->part_pitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
+                                   (int)c->part_len, (int)c->part_pitch, nsl, pbase, c->map, c->sigma,
+                                   (int)c->pitch, c->weight);
+            }
         } else if ((size_t)gx * ((c->D + 15) / 16) <= VSOM_CHAIN_MAX_WAVES && c->use_chain) {
             // lane = node would leave most SIMDs idle: one lane per (node, dim) chain instead
             int dl_log2 = 0;
@@ -838,8 +874,9 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     a.nslices = nfull;
                     a.pitch_bytes = c->pitch * 4u;
                     a.n0 = (unsigned)n0;
-                    a.pad = 0;
-                    size_t sz = sizeof(a);
+                    a.ppitch_bytes = 0;
+                    a.yp = nullptr;
+                    size_t sz = 64;   // kernarg segment of the Standard kernels (the CLR one takes all 72 bytes)
                     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
                                      HIP_LAUNCH_PARAM_END};
                     // XCD-aware grid: x = 8 * slice quads, y = node groups / 8 (see gen_update_asm.py)
@@ -871,8 +908,11 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
     if (sig_cols > 0) {
         TimerScope ts(c, VSOM_T_SIGMA);
         const size_t tot = nloc * (size_t)sig_cols;
-        hipLaunchKernelGGL(sigma_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
-                           c->sigma, (int)c->pitch, sig_cols, (int)n0, (int)nloc, c->weight);
+        // the assembly kernels left raw S in those columns (CLR: in the A part and in the B part)
+        for (uint32_t part = 0; part < c->nparts; ++part)
+            hipLaunchKernelGGL(sigma_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                               c->sigma, (int)c->pitch, (int)(part * c->part_pitch), sig_cols, (int)n0, (int)nloc,
+                               c->weight);
         VSOM_HIP_CHECK(hipGetLastError());
     }
     return vsom_join_aux(c);   // the MSE sum forked by launch_finish ran beside the kernels above
