@@ -1,0 +1,86 @@
+"""GPU: seeded random sweep over map shapes, chunk lengths, transformations and sigmas -- two batch
+epochs (full search, then local search) and a short online chunk per case, every output compared
+bit for bit (NaN == NaN) with the oracle.  Small sigmas on wide maps make the float neighbourhood
+weight underflow, so rows with W = 0 -> c = 0/0 = NaN are part of the sweep."""
+import numpy as np
+import pytest
+
+import gen
+import vsom_amd
+from vsom_amd import capi
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind == "f":
+        return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+    return bool((a == b).all())
+
+
+def _cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        tr = [po.STANDARD, po.MEDIAN, po.CLR][i % 3]
+        W, H = int(rs.randint(2, 40)), int(rs.randint(2, 40))
+        J = int(rs.randint(2, 9)) if tr == po.CLR else int(rs.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 33, 64, 100]))
+        B = int(rs.choice([1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 200, 257]))
+        sigma = float(rs.choice([1.5, 2.0, 3.7, 8.0, 20.0]))
+        out.append((f"{i}_{['std', 'med', 'clr'][tr]}_{W}x{H}x{J}_B{B}_s{sigma}", tr, W, H, J, B, sigma, int(rs.randint(1, 1 << 30))))
+    return out
+
+
+CASES = _cases(36, 20240611) + [
+    # shapes that reach the hand-scheduled kernels (enough wavefronts) with ragged chunks / dims
+    ("asm_rd14_40x33x784_B65", po.STANDARD, 40, 33, 784, 65, 12.0, 11),
+    ("asm_rd16_tail_37x35x794_B33", po.STANDARD, 37, 35, 794, 33, 9.0, 12),
+    ("asm_rd14_50x50x112_B77", po.STANDARD, 50, 50, 112, 77, 6.0, 13),
+    ("asm_rd16_64x64x100_B130", po.STANDARD, 64, 64, 100, 130, 25.0, 14),
+    ("lane_node_median_48x48x200_B70", po.MEDIAN, 48, 48, 200, 70, 14.0, 15),
+    ("asm_clr_J9_30x30_B55", po.CLR, 30, 30, 9, 55, 9.0, 16),
+    ("asm_clr_J12_20x21_B129", po.CLR, 20, 21, 12, 129, 2.5, 17),
+]
+
+
+@pytest.mark.parametrize("name,tr,W,H,J,B,sigma,seed", CASES, ids=[c[0] for c in CASES])
+def test_random_shape(name, tr, W, H, J, B, sigma, seed):
+    D = po.length(tr, J)
+    rs = np.random.RandomState(seed)
+    X = (rs.randn(B, J) * rs.choice([0.1, 1.0, 50.0])).astype(np.float32)
+    X[rs.rand(B, J) < 0.1] = 0.0                       # exact zeros (sign(0), -0 paths)
+    init = gen.random_map(W * H, D, seed=seed % 1000)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    orc = po.OracleSom(W, H, J, tr)
+    ctx.set_state(map=init)
+    orc.set_state(map=init)
+    for first in (True, False):
+        lb = np.zeros(B, np.uint64)
+        mse_o = orc.batch_epoch(X, lb, sigma, first)
+        ctx.upload_chunk(X)
+        mse_g = ctx.batch_epoch(sigma, first)
+        assert _same(ctx.get_last_bmu(), lb), (name, first, "lastBMU")
+        assert _same(np.float32(mse_g), np.float32(mse_o)), (name, first, "mse")
+        st = ctx.get_state()
+        for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("weight", orc.weight), ("hits", orc.hits)):
+            assert _same(st[k], ref), (name, first, k)
+    # a few online steps on top (window + post fused launch; sigma <= 1 single launch)
+    clean = gen.random_map(W * H, D, seed=7)          # the batch result may hold NaN rows: restart clean
+    ctx.set_state(map=clean, sigma=np.zeros_like(clean), S=np.zeros_like(clean), weight=np.zeros(W * H, np.float32),
+                  hits=np.zeros(W * H, np.uint64))
+    orc.set_state(map=clean, sigma=np.zeros_like(clean), S=np.zeros_like(clean), weight=np.zeros(W * H, np.float32),
+                  hits=np.zeros(W * H, np.uint64))
+    nb = min(B, 12)
+    for sg, fn in ((max(sigma, 1.2), capi.EXPONENTIAL), (1.0, capi.INVERSE_PROPORTIONAL)):
+        lb = np.zeros(nb, np.uint64)
+        mse_o = orc.train_online_chunk(X[:nb], lb, 0.05, sg, fn)
+        ctx.upload_chunk(X[:nb])
+        mse_g = ctx.train_online_chunk(0.05, sg, fn)
+        assert _same(ctx.get_last_bmu(), lb), (name, sg, "online lastBMU")
+        assert _same(np.float32(mse_g), np.float32(mse_o)), (name, sg, "online mse")
+        st = ctx.get_state()
+        for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("S", orc.S), ("weight", orc.weight), ("hits", orc.hits)):
+            assert _same(st[k], ref), (name, sg, "online " + k)
+    ctx.close()
