@@ -20,8 +20,10 @@ import vsom_amd  # noqa: E402
 from vsom_amd import capi  # noqa: E402
 
 
-def batch_case(name, W, J, tr, B, sigma, X, init, steps=10, is_first=True, flops_upd=6.0):
+def batch_case(name, W, J, tr, B, sigma, X, init, steps=10, is_first=True, flops_upd=6.0, bmu_mode=None):
     ctx = vsom_amd.Context(W, W, J, tr)
+    if bmu_mode is not None:
+        ctx.set_bmu_mode(bmu_mode)
     ctx.set_state(map=init)
     ctx.upload_chunk(X)
     for _ in range(2):
@@ -83,6 +85,11 @@ def main():
         batch_case("C2m 64x64x784 median first", 64, 784, capi.MEDIAN, 4096, 16.0, X, init)
         init = gen.random_map(128 * 128, 784, 42) * np.float32(100) + np.float32(100)
         batch_case("C3m 128x128x784 median first", 128, 784, capi.MEDIAN, 4096, 32.0, X, init, steps=5)
+    if "c3exact" in which:
+        X = gen.mnist_like(4096, 3, 784)
+        init = gen.random_map(128 * 128, 784, 42) * np.float32(100) + np.float32(100)
+        batch_case("C3 128x128x784 std, exact-order search kernel", 128, 784, capi.STANDARD, 4096, 32.0, X, init, steps=5,
+                   bmu_mode=capi.BMU_EXACT)
     if "c3local" in which:
         X = gen.mnist_like(4096, 3, 784)
         init = gen.random_map(128 * 128, 784, 42) * np.float32(100) + np.float32(100)
