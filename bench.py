@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--nchunks", type=int, default=4, help="distinct resident chunks cycled over")
+    ap.add_argument("--host-chunks", choices=["off", "sync", "overlap"], default="off",
+                    help="PCIe-inclusive variants (N=1, not the contract number): chunks start in pinned host "
+                         "memory every step; 'sync' = vsom_upload_chunk, 'overlap' = prefetch of chunk i+1 "
+                         "beside the epoch of chunk i (vsom_prefetch_chunk / vsom_commit_chunk)")
     return ap.parse_args()
 
 
@@ -137,10 +141,29 @@ def main():
     trainer = vdist.ShardedBatchTrainer(eng, rank, world)
     is_first = not args.local
 
+    pinned = None
+    if args.host_chunks != "off":
+        if world != 1:
+            raise SystemExit("--host-chunks is a single-GPU measurement")
+        pinned = [capi.PinnedBuffer(c.shape) for c in chunks_host]
+        for pb, c in zip(pinned, chunks_host):
+            pb.array[...] = c
+        if args.host_chunks == "overlap":
+            ctx.prefetch_chunk(pinned[0].array)
+
     def step(i):
         with torch.cuda.stream(stream):
-            eng.load_chunk_device(chunks[i % len(chunks)])   # staging + lastBMU reset (DataSet.cpp:118-160)
+            if args.host_chunks == "sync":
+                ctx.upload_chunk(pinned[i % len(pinned)].array)      # blocking H2D + staging
+                eng._bind_chunk()
+            elif args.host_chunks == "overlap":
+                ctx.commit_chunk()                                   # chunk i (copied during step i-1)
+                eng._bind_chunk()
+            else:
+                eng.load_chunk_device(chunks[i % len(chunks)])   # staging + lastBMU reset (DataSet.cpp:118-160)
             trainer.epoch(args.sigma, is_first)
+            if args.host_chunks == "overlap":
+                ctx.prefetch_chunk(pinned[(i + 1) % len(pinned)].array)   # H2D of chunk i+1 beside this epoch
 
     for i in range(args.warmup):
         step(i)
@@ -232,7 +255,7 @@ def main():
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if args.host_chunks == "off" else f"synthetic, chunks in pinned host memory ({args.host_chunks})",
             "update_arithmetic": "fma (opt-in, 1e-5 relative)" if args.fma else "strict (bit-identical to the CPU oracle)",
             "config": {"workload": (f"{W}x{H} map, {D}-dim MNIST-like synthetic, standard transformation, "
                                     f"trainBatchSomEpoch({'findBmu' if is_first else 'findLocalBmu'} + update), "
