@@ -58,6 +58,8 @@ CASES = [
     ("cw32_96x96x6", 96, 96, 6, po.STANDARD, 333, 20.0),
     ("cw64_128x128x4", 128, 128, 4, po.STANDARD, 77, 30.0),
     ("cw64_130x127x3_median", 130, 127, 3, po.MEDIAN, 130, 25.0),
+    # neighbourhood table larger than the LDS budget (200x200x4 B = 160 KB): read from global memory
+    ("cw64_lut_global_200x200x3", 200, 200, 3, po.STANDARD, 41, 40.0),
 ]
 
 
