@@ -100,6 +100,13 @@ def main():
         batch_case("C4 64x64x32 median first", 64, 32, capi.MEDIAN, 16384, 16.0, X, init, flops_upd=6.0)
         batch_case("C4 64x64x32 median local", 64, 32, capi.MEDIAN, 16384, 16.0, X, init, is_first=False)
         batch_case("C4' 64x64x32 std first", 64, 32, capi.STANDARD, 16384, 16.0, X, init)
+        batch_case("C4 64x64x32 median first, exact-order search kernel", 64, 32, capi.MEDIAN, 16384, 16.0, X, init,
+                   bmu_mode=capi.BMU_EXACT)
+        for dd in (64, 128):
+            Xd = gen.blobs(16384, dd, 8, 1, 4, sigma=1.0)
+            initd = gen.random_map(64 * 64, dd, 42)
+            batch_case(f"64x64x{dd} std first (auto)", 64, dd, capi.STANDARD, 16384, 16.0, Xd, initd)
+            batch_case(f"64x64x{dd} std first (exact)", 64, dd, capi.STANDARD, 16384, 16.0, Xd, initd, bmu_mode=capi.BMU_EXACT)
     if "c5" in which:
         X = gen.correlated(8192, 64, 5)
         D = 64 * 63

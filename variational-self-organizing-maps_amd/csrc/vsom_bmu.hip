@@ -353,10 +353,13 @@ int launch_bmu_full(vsom_ctx *c, size_t s0, size_t s1)
 {
     TimerScope ts(c, VSOM_T_BMU);
     // the MFMA shortlist covers the plain squared-distance comparer (Standard / Median);
-    // it pays once the map is large enough to fill the matrix pipes
+    // it pays once the map is large enough to fill the matrix pipes and the vectors are long enough
+    // for the contraction to outweigh writing and re-reading the B x N approximation matrix
+    // (measured on 64x64 maps, B = 16384: D = 32 exact 0.22 vs 0.36 ms, D = 64 0.34 vs 0.39, D = 128
+    // 0.61 vs 0.47)
     const bool can = c->transform != VSOM_CLR;
     bool want = c->bmu_mode == VSOM_BMU_SHORTLIST;
-    if (c->bmu_mode == VSOM_BMU_AUTO && c->N >= 1024 && (s1 - s0) >= 64) {
+    if (c->bmu_mode == VSOM_BMU_AUTO && c->N >= 1024 && (s1 - s0) >= 64 && c->D > 64) {
         want = true;
         // feedback of the previous shortlist call (pinned host words written by the device, read
         // without synchronising: possibly one call stale): when more than a quarter of the samples
