@@ -192,11 +192,12 @@ protected:
         std::vector<int> *valid;
         size_t *lastBMU;
     };
-    std::vector<DataRow> allData;
-    std::vector<Eigen::VectorXf> data;
-    std::vector<std::vector<int>> valid;
+    // [MI355X build] built lazily by ensureRows() (hence mutable): see vsom_host.cpp
+    mutable std::vector<DataRow> allData;
+    mutable std::vector<Eigen::VectorXf> data;
+    mutable std::vector<std::vector<int>> valid;
     std::vector<size_t> index;
-    std::vector<size_t> lastBMU;
+    mutable std::vector<size_t> lastBMU;
     IDataLoader &_loader;
     size_t depth, n, loadedNumberOfChunks;
     bool _verbose;
@@ -247,6 +248,8 @@ private:
     };
     Pinned m_flat[2];
     int m_cur = 0;
+    mutable bool m_rowsBuilt = true;
+    void ensureRows() const;
 };
 
 // ===== SomIndex ==============================================================================

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -195,8 +196,7 @@ size_t ArrayDataLoader::load()
     for (size_t r = m_currentIndex; r < end; ++r) {
         RowData row;
         row.values = Eigen::VectorXf((Eigen::Index)m_depth);
-        for (size_t d = 0; d < m_depth; ++d)
-            row.values[(Eigen::Index)d] = m_rows[r * m_depth + d];
+        std::memcpy(row.values.data(), &m_rows[r * m_depth], m_depth * sizeof(float));
         row.valid.assign(m_depth, 1);
         data.push_back(std::move(row));
     }
@@ -237,8 +237,41 @@ const std::vector<ColumnSpec> ArrayDataLoader::getColumnSpec() noexcept
     return out;
 }
 
-const std::vector<DataSet::DataRow> DataSet::getAll() const { return allData; }
-std::vector<DataSet::DataRow> DataSet::getAll() { return allData; }
+// The per-row containers of the reference (vector<VectorXf> data, vector<vector<int>> valid, the
+// DataRow views) are built on first use: the training drivers only need the contiguous staging copy,
+// and materialising three heap objects per row costs more host time per chunk than the device step.
+void DataSet::ensureRows() const
+{
+    if (m_rowsBuilt)
+        return;
+    data.clear();
+    valid.clear();
+    allData.clear();
+    data.reserve(n);
+    valid.reserve(n);
+    allData.reserve(n);
+    size_t cur = 0;
+    for (auto &row : _loader.data) {
+        if (cur >= n)
+            break;
+        data.push_back(row.values);
+        valid.push_back(row.valid);
+        allData.push_back(DataRow{&data.back(), &valid.back(), &lastBMU[cur]});
+        ++cur;
+    }
+    m_rowsBuilt = true;
+}
+
+const std::vector<DataSet::DataRow> DataSet::getAll() const
+{
+    ensureRows();
+    return allData;
+}
+std::vector<DataSet::DataRow> DataSet::getAll()
+{
+    ensureRows();
+    return allData;
+}
 
 std::vector<Eigen::VectorXf> DataSet::getPreviewData(size_t count) const
 {
@@ -250,15 +283,17 @@ std::vector<Eigen::VectorXf> DataSet::getPreviewData(size_t count) const
 
 Eigen::VectorXf DataSet::getData(size_t i) const
 {
-    if (_loader.data.size() > i)
+    ensureRows();
+    if (_loader.data.size() > i && data.size() > i)
         return data[i];
     return Eigen::VectorXf::Zero((Eigen::Index)_loader.getDepth());
 }
 
 const Eigen::VectorXi DataSet::getValidity(size_t i) const
 {
+    ensureRows();
     Eigen::VectorXi v = Eigen::VectorXi::Zero((Eigen::Index)_loader.getDepth());
-    if (n > i)
+    if (n > i && valid.size() > i)
         for (size_t d = 0; d < valid[i].size(); ++d)
             v[(Eigen::Index)d] = valid[i][d];
     return v;
@@ -298,6 +333,7 @@ size_t DataSet::size() const { return n; }
 void DataSet::addVector(Eigen::VectorXf v)
 {
     if ((size_t)v.rows() == _loader.getDepth()) {
+        ensureRows();
         depth = _loader.getDepth();
         m_flat[m_cur].reserve((data.size() + 1) * depth);
         for (size_t d = 0; d < depth; ++d)
@@ -350,12 +386,14 @@ void DataSet::Pinned::reserve(size_t nfloats)
 // the reference passes DataSet by value (SOM.hpp:78-82); the copy owns its row views and staging
 DataSet::DataSet(const DataSet &o)
     : data{o.data}, valid{o.valid}, index{o.index}, lastBMU{o.lastBMU}, _loader{o._loader}, depth{o.depth}, n{o.n},
-      loadedNumberOfChunks{o.loadedNumberOfChunks}, _verbose{o._verbose}
+      loadedNumberOfChunks{o.loadedNumberOfChunks}, _verbose{o._verbose}, m_rowsBuilt{o.m_rowsBuilt}
 {
-    allData.reserve(o.allData.size());
-    for (size_t k = 0; k < o.allData.size() && k < data.size(); ++k)
-        allData.push_back(DataRow{&data[k], &valid[k], &lastBMU[k]});
-    const size_t nf = data.size() * depth;
+    if (m_rowsBuilt) {
+        allData.reserve(o.allData.size());
+        for (size_t k = 0; k < o.allData.size() && k < data.size(); ++k)
+            allData.push_back(DataRow{&data[k], &valid[k], &lastBMU[k]});
+    }
+    const size_t nf = std::max(n, data.size()) * depth;
     if (nf && o.m_flat[o.m_cur].p) {
         m_flat[0].reserve(nf);
         std::copy(o.m_flat[o.m_cur].p, o.m_flat[o.m_cur].p + nf, m_flat[0].p);
@@ -370,13 +408,8 @@ void DataSet::loadNextDataFromStream()
     const size_t numberOfRows = _loader.load();
     n = numberOfRows;
     depth = _loader.getDepth();
-    valid.clear();
-    valid.reserve(numberOfRows);
-    data.clear();
-    data.reserve(numberOfRows);
     lastBMU.assign(numberOfRows, 0);
-    allData.clear();
-    allData.reserve(numberOfRows);
+    m_rowsBuilt = false;          // data / valid / allData are rebuilt from the loader on first use
     index.resize(numberOfRows);
     for (size_t k = 0; k < index.size(); ++k)
         index[k] = k;
@@ -387,11 +420,12 @@ void DataSet::loadNextDataFromStream()
     float *flat = m_flat[m_cur].p;
     size_t cur = 0;
     for (auto &row : _loader.data) {
-        data.push_back(row.values);
-        valid.push_back(row.valid);
-        for (size_t d = 0; d < depth; ++d)
-            flat[cur * depth + d] = row.values[(Eigen::Index)d];
-        allData.push_back(DataRow{&data.back(), &valid.back(), &lastBMU[cur]});
+        if (cur >= numberOfRows)
+            break;
+        const size_t have = std::min<size_t>((size_t)row.values.size(), depth);
+        std::memcpy(flat + cur * depth, row.values.data(), have * sizeof(float));
+        for (size_t d = have; d < depth; ++d)
+            flat[cur * depth + d] = 0.f;
         ++cur;
     }
     ++loadedNumberOfChunks;
@@ -778,21 +812,24 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
 {
     requireDevicePath("trainBatchSom");
     metrics = Som::Metrics(numberOfEpochs);   // Som.cpp:719
+    auto sigmaOf = [&](size_t e) { return sigma0 * std::exp(-sigmaDecay * static_cast<double>(e)); };   // :727
+    bool have = false;                // a loaded chunk is waiting in `data`, its copy is in flight
+    size_t B = 0;
     for (size_t i = 0; i < numberOfEpochs; ++i) {
         std::cout << "Training VSOM epoch " << i << "/" << numberOfEpochs << '\n';
-        auto sigma = sigma0 * std::exp(-sigmaDecay * static_cast<double>(i));   // :727
+        const auto sigma = sigmaOf(i);
         if (sigma < 1.0)
             return;   // :729-730
         auto meanSquareError = float{0.0f};
         auto countDataChunks = size_t{0};
-        bool have = false;            // a loaded chunk is waiting in `data`, its copy is in flight
-        size_t B = 0;
-        if (!data.hasReadWholeDataStream()) {   // :735
+        if (!have && !data.hasReadWholeDataStream()) {   // :735 (the first chunk may already be in flight)
             data.loadNextDataFromStream();
             B = data.size();
             check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
             have = true;
         }
+        // the next epoch will run (and therefore reload the stream from its start, :737,749)?
+        const bool another = i + 1 < numberOfEpochs && sigmaOf(i + 1) >= 1.0;
         while (have) {
             const size_t Bcur = B;
             if (Bcur > 0) {
@@ -801,23 +838,34 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
             }
             have = false;
             const bool last = data.hasReadWholeDataStream();
-            if (last && Bcur > 0) {
-                // the chunk still held by `data` after the loop keeps its BMUs (Som.cpp:777,800)
-                std::vector<uint64_t> lb(Bcur);
-                check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
-                for (size_t s = 0; s < Bcur; ++s)
-                    data.getLastBMU(s) = (size_t)lb[s];
-            } else if (!last) {
+            if (!last) {
                 data.loadNextDataFromStream();   // host work beside the device epoch
                 B = data.size();
                 check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
                 have = true;
+            } else if (another) {
+                // last chunk of this epoch: load the next epoch's first chunk beside it (the BMUs of
+                // this chunk would be wiped by that reload in the reference too, DataSet.cpp:136-137)
+                data.resetStreamLoadPosition();   // :749
+                data.loadNextDataFromStream();
+                B = data.size();
+                check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+            } else if (Bcur > 0) {
+                // the chunk still held by `data` when training ends keeps its BMUs (Som.cpp:777,800)
+                std::vector<uint64_t> lb(Bcur);
+                check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
+                for (size_t s = 0; s < Bcur; ++s)
+                    data.getLastBMU(s) = (size_t)lb[s];
             }
             float mse = 0.f;
             if (Bcur > 0)
                 check(vsom_get_mse(ctx, &mse), "vsom_get_mse");
             meanSquareError += mse;
             ++countDataChunks;
+            if (last) {
+                have = false;
+                break;
+            }
         }
         hostStale = true;
         meanSquareError /= static_cast<float>(countDataChunks);   // :743
@@ -825,7 +873,10 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
             const std::lock_guard<std::mutex> lock(metricsMutex);
             metrics.MeanSquaredError[i] = meanSquareError;
         }
-        data.resetStreamLoadPosition();
+        if (another)
+            have = true;              // chunk 0 of epoch i+1 is already loaded and on its way
+        else
+            data.resetStreamLoadPosition();   // :749
     }
 }
 

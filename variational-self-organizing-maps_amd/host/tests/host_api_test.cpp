@@ -7,6 +7,7 @@
 #include "DataSet.hpp"
 #include "Transformation.hpp"
 
+#include <chrono>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -42,8 +43,31 @@ static std::vector<float> make_rows(size_t n, size_t d, unsigned seed)
     return r;
 }
 
+// `host_api_test perf`: the whole C++ path (loader -> DataSet -> pipelined Som::train) at BASELINE's size
+static int perf()
+{
+    const size_t W = 128, H = 128, J = 784, NROWS = 16384, CHUNK = 4096;
+    auto rows = make_rows(NROWS, J, 777u);
+    ArrayDataLoader loader(rows.data(), NROWS, J, CHUNK);
+    DataSet ds(loader);
+    Som som{W, H, J};
+    som.randomInitialize(42, 1);
+    std::cout.setstate(std::ios_base::failbit);                      // the drivers print per epoch
+    som.train(ds, 1, 0.0, 0.0, 40.0, 0.1, Som::WeigthDecayFunction::BatchMap);   // warm-up (first epoch: full search)
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t epochs = 4;
+    som.train(ds, epochs, 0.0, 0.0, 40.0, 0.1, Som::WeigthDecayFunction::BatchMap);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout.clear();
+    std::printf("{\"host_cpp_train\": \"128x128x784, %zu rows in chunks of %zu, %zu epochs (epoch 0 full search, later local)\", "
+                "\"s_per_epoch\": %.4f, \"samples_per_s\": %.0f}\n", NROWS, CHUNK, epochs, dt / epochs, NROWS * epochs / dt);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && std::string(argv[1]) == "perf")
+        return perf();
     const std::string out = argc > 1 ? argv[1] : ".";
     const size_t W = 10, H = 10, J = 9, NROWS = 50, CHUNK = 20;
     auto rows = make_rows(NROWS, J, 12345u);
