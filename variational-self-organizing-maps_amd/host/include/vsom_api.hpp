@@ -125,6 +125,7 @@ protected:
     std::vector<std::string> _names;
     std::string _filePath;
     bool _verbose;
+    mutable std::vector<unsigned char> _img, _lab;   // file bytes, kept between loads
     std::vector<RowData> readRows(size_t skip, size_t limit) const;
 };
 

@@ -41,6 +41,8 @@ MnistDataLoader::MnistDataLoader(std::optional<size_t> maxLoadCount, bool verbos
 bool MnistDataLoader::open(const char *path)
 {
     _filePath = path;   // MnistDataLoader.cpp:9-14: remembers the folder, nothing is read yet
+    _img.clear();
+    _lab.clear();
     return true;
 }
 
@@ -106,8 +108,14 @@ size_t amount_to_read(size_t limit, size_t skip, size_t count)
 std::vector<RowData> MnistDataLoader::readRows(size_t skip, size_t limit) const
 {
     std::vector<RowData> out;
-    const auto img = read_idx(_filePath + "/train-images-idx3-ubyte", 0x803);
-    const auto lab = read_idx(_filePath + "/train-labels-idx1-ubyte", 0x801);
+    // the reference re-reads both files on every load(); the bytes are kept after the first read here
+    // (open() drops them), which changes nothing unless the files are rewritten during training
+    if (_img.empty() || _lab.empty()) {
+        _img = read_idx(_filePath + "/train-images-idx3-ubyte", 0x803);
+        _lab = read_idx(_filePath + "/train-labels-idx1-ubyte", 0x801);
+    }
+    const auto &img = _img;
+    const auto &lab = _lab;
     if (img.empty() || lab.empty())
         return out;
     const size_t icount = be32(img.data() + 4), rows = be32(img.data() + 8), cols = be32(img.data() + 12);
