@@ -192,7 +192,10 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict
     }
 }
 
-// one wavefront per sample.  stats: [0] samples sent to the exact redo list, [1] total candidates
+// one workgroup (4 wavefronts) per sample: the tile scan and the exact-order evaluations of the
+// shortlist are spread over the wavefronts (the evaluations are chains of dependent row reads, so
+// more wavefronts per sample is what shortens them).  stats: [0] samples sent to the exact redo
+// list, [1] total candidates
 __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int s1, int N, int D,
                                                         const float *__restrict__ G, int ldg,
                                                         const float *__restrict__ tmin, int ntm,
@@ -201,14 +204,21 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
                                                         unsigned *__restrict__ redo_count, int *__restrict__ redo_list,
                                                         unsigned *__restrict__ stats)
 {
-    __shared__ unsigned cand[4][SL_CMAX];
+    __shared__ unsigned cand[SL_CMAX];
+    __shared__ unsigned s_cnt;
+    __shared__ u64 s_best[4];
+    __shared__ int s_nan0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = s0 + blockIdx.x * 4 + wave;
+    const int s = s0 + blockIdx.x;
     if (s >= s1)
-        return;   // wave-uniform
+        return;   // block-uniform
+    if (threadIdx.x == 0)
+        s_cnt = 0u;
     const float *xr = a.xa + (size_t)s * a.ldx;
     const float *g = G + (size_t)(s - s0) * ldg;
-    // |x|^2
+    const float *tm = tmin + (size_t)(s - s0) * ntm;
+    // |x|^2 and the row minimum of the approximations: every wavefront computes both, in the same
+    // order, so all of them hold identical values (a NaN never replaces the incumbent minimum)
     float nx = 0.f;
     for (int d = lane; d < D; d += 64) {
         float v = xr[d];
@@ -219,20 +229,16 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         nx = nx + __shfl_xor(nx, off);
     const float nmax = __uint_as_float(scal[0]);
     bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f);
-    // pass 1: minimum of the approximations (a NaN never replaces the incumbent)
     float m = __uint_as_float(0x7F800000u);
-    {
-        const float *tm = tmin + (size_t)(s - s0) * ntm;
-        for (int i = lane; i < ntm; i += 64) {
-            float v = tm[i];
-            m = v < m ? v : m;
-        }
+    for (int i = lane; i < ntm; i += 64) {
+        float v = tm[i];
+        m = v < m ? v : m;
     }
     for (int off = 32; off > 0; off >>= 1) {
         float o = __shfl_xor(m, off);
         m = o < m ? o : m;
     }
-    unsigned cnt = 0;
+    __syncthreads();   // s_cnt = 0 visible
     if (!bad) {
         // T_s = 4*g1*(nMmax+nx) + 2.1*g2*(m + nx + 2*g1*(nMmax+nx)), inflated by 1.05 (header)
         const float ea = c_g1 * (nmax + nx);                 // c_g1 = 2*g1
@@ -243,12 +249,11 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         const float thr = m + T;
         if (!(thr < 3.0e38f))
             bad = true;                                      // nothing finite to compare with
-        // pass 2: collect candidates (order irrelevant: the key min decides).  tmin[t] is the exact
-        // minimum of the non-NaN entries of columns [64t, 64t+64), so only tiles with tmin <= thr
-        // can hold a candidate: one coalesced 256-byte read per such tile instead of the whole row.
-        const float *tm = tmin + (size_t)(s - s0) * ntm;
+        // collect candidates (order irrelevant: the key min decides).  tmin[t] is the exact minimum of
+        // the non-NaN entries of columns [64t, 64t+64), so only tiles with tmin <= thr can hold a
+        // candidate: one coalesced 256-byte read per such tile; wavefront w takes tiles 64w + 256k + lane
         const u64 below = (1ull << lane) - 1ull;
-        for (int t0 = 0; t0 < ntm && !bad; t0 += 64) {
+        for (int t0 = wave * 64; t0 < ntm && !bad; t0 += 256) {
             const int t = t0 + lane;
             u64 hm = __ballot(t < ntm && tm[t] <= thr);
             while (hm) {
@@ -257,32 +262,44 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
                 const int i = (t0 + tl) * 64 + lane;
                 const bool c = i < N && g[i] <= thr;
                 const u64 mask = __ballot(c);
-                const unsigned before = (unsigned)__popcll(mask & below);
-                if (c && cnt + before < SL_CMAX)
-                    cand[wave][cnt + before] = (unsigned)i;
-                cnt += (unsigned)__popcll(mask);
+                if (mask) {
+                    unsigned base = 0;
+                    if (lane == 0)
+                        base = atomicAdd(&s_cnt, (unsigned)__popcll(mask));
+                    base = __shfl(base, 0);
+                    const unsigned slot = base + (unsigned)__popcll(mask & below);
+                    if (c && slot < SL_CMAX)
+                        cand[slot] = (unsigned)i;
+                }
             }
         }
-        if (cnt > SL_CMAX)
-            bad = true;
     }
-    if (bad) {
-        if (lane == 0) {
+    __syncthreads();
+    const unsigned cnt = s_cnt;
+    if (cnt > SL_CMAX)
+        bad = true;
+    if (bad) {   // block-uniform
+        if (threadIdx.x == 0) {
             unsigned slot = atomicAdd(redo_count, 1u);
             redo_list[slot] = s;
             atomicAdd(&stats[0], 1u);
         }
         return;
     }
-    // exact-order evaluation: 8 lanes per candidate, node 0 always included
+    // exact-order evaluation: 8 lanes per candidate, 32 candidates per pass over the workgroup;
+    // node 0 always included (wavefront 0)
     const int grp = lane >> 3, k = lane & 7;
-    float d0 = vsom_group_dist<false>(xr, xr, a.ma, a.ma, a.L, k);
-    d0 = __shfl(d0, 0);
-    u64 best = vsom_key(d0, 0u);
-    const bool nan0 = d0 != d0;
-    for (unsigned c0 = 0; c0 < cnt; c0 += 8) {
-        unsigned ci = c0 + grp;
-        unsigned node = cand[wave][ci < cnt ? ci : cnt - 1];
+    u64 best = ~0ull;
+    if (wave == 0) {
+        float d0 = vsom_group_dist<false>(xr, xr, a.ma, a.ma, a.L, k);
+        d0 = __shfl(d0, 0);
+        best = vsom_key(d0, 0u);
+        if (lane == 0)
+            s_nan0 = d0 != d0;
+    }
+    for (unsigned c0 = 0; c0 < cnt; c0 += 32) {
+        const unsigned ci = c0 + (unsigned)(wave * 8 + grp);
+        const unsigned node = cand[ci < cnt ? ci : cnt - 1];
         float d = vsom_group_dist<false>(xr, xr, a.ma + (size_t)node * a.ldm, a.ma, a.L, k);
         u64 key = ci < cnt ? vsom_key(d, node) : ~0ull;
         best = key < best ? key : best;
@@ -291,14 +308,20 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         u64 o = __shfl_xor(best, off);
         best = o < best ? o : best;
     }
-    if (lane == 0) {
+    if (lane == 0)
+        s_best[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
         atomicAdd(&stats[1], cnt);
-        if (nan0) {
+        u64 b = s_best[0];
+        for (int i = 1; i < 4; ++i)
+            b = s_best[i] < b ? s_best[i] : b;
+        if (s_nan0) {
             lastbmu[s] = 0;
             sqres[s] = __uint_as_float(0x7FC00000u);
         } else {
-            lastbmu[s] = best & 0xFFFFFFFFull;
-            sqres[s] = __uint_as_float((uint32_t)(best >> 32));
+            lastbmu[s] = b & 0xFFFFFFFFull;
+            sqres[s] = __uint_as_float((uint32_t)(b >> 32));
         }
     }
 }
@@ -376,7 +399,7 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     const double u = 5.9604644775390625e-08;   // 2^-24
     const double K = (double)c->xpitch;
     const double g1 = ((double)GK + K / GK + 3.0) * u, g2 = ((double)c->D / 8.0 + 10.0) * u;
-    hipLaunchKernelGGL(sl_select_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, a, (int)s0,
+    hipLaunchKernelGGL(sl_select_kernel, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0,
                        (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(2.0 * g1), (float)(2.1 * g2),
                        c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4);
     hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows);
