@@ -18,6 +18,7 @@
 //                  result is bit-identical to the reference's SSE2 build.
 #include "vsom_device.hpp"
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 
 // (c,w) layout: pair-interleaved, float2 at ((j>>1)*ldn + node)*2 + (j&1), i.e. one float4
@@ -757,8 +758,16 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         bool piped = false;
         if (c->cw_mode == 0) {
             // role-split kernel: NW nodes per workgroup so that the grid still covers the CUs
-            const bool lds = lut_bytes <= 96 * 1024;
-            const int nw = nloc >= 16384 ? 64 : (nloc >= 8192 ? 32 : 16);
+            // 16 nodes per workgroup and the table in LDS only while it is small: what counts is how
+            // many workgroups (worker wavefronts) a CU holds -- 40 KB of tiles each; a 64-KB table
+            // (128x128 map) would leave one per CU.  Measured at C3: 64 nodes + LDS table 0.153 ms,
+            // 32 + global 0.142, 16 + global 0.121, 16 + LDS 0.20.
+            bool lds = lut_bytes <= 24 * 1024;
+            int nw = 16;
+            if (const char *e = std::getenv("VSOM_CW_NW"))      // development knobs
+                nw = std::atoi(e) == 64 ? 64 : (std::atoi(e) == 32 ? 32 : 16);
+            if (const char *e = std::getenv("VSOM_CW_LUT_GLOBAL"))
+                lds = e[0] == '1' ? false : (e[0] == '0' ? lut_bytes <= 96 * 1024 : lds);
             const int T = 2048 / nw;
             const size_t smem = (size_t)5 * 2048 * sizeof(float) + (size_t)3 * T * sizeof(int2) + (lds ? lut_bytes : 0);
             const void *fn = nw == 64 ? (lds ? (const void *)cwp_kernel<64, 32, true> : (const void *)cwp_kernel<64, 32, false>)
