@@ -8,14 +8,23 @@
 //
 // Split into
 //   bxy_kernel   : SomIndex(*this, lastBMU[j]) once per sample               (:847-849)
-//   cw_kernel    : one thread per node walks the samples: LUT lookup of w (the double exp is
-//                  tabulated on the host over (|dx|,|dy|), bit-identical), the fp32 prefix sum
-//                  W and c = w/W -> cw[j][i] = (c, w).  N chains of length B.
-//   update_*     : the N*D chains.  Lane = node, RD consecutive dims in registers (M,S);
-//                  x_j[d] is wave-uniform and arrives through scalar loads (SGPR operands of
-//                  v_pk_* VALU ops), (c,w) is one coalesced 8-byte load per lane per sample.
-//                  Every fp32 operation is rounded separately (-ffp-contract=off), so the
-//                  result is bit-identical to the reference's SSE2 build.
+//   cwp_kernel   : the neighbourhood chain per node: LUT lookup of w (the double exp is tabulated on
+//                  the host over (|dx|,|dy|), bit-identical), the serial fp32 prefix sum W and
+//                  c = w/W -> cw[j][i] = (c, w).  Role-split workgroups: one wavefront only adds,
+//                  eight look up / divide / store (cw_kernel / cw16_kernel are the earlier
+//                  redundant-chain versions, kept behind VSOM_CW_MODE for comparison).
+//   update_*     : the N*D chains.
+//                  - vsom_update_{std,fma}_rd{14,16}_gfx950, vsom_update_clr_rp8_gfx950: hand-scheduled
+//                    code object (gen_update_asm.py): lane = node, RD dims (8 CLR pairs) per lane in
+//                    VGPRs, x rows through scalar loads (SGPR operands of v_pk_* ops), a ring of
+//                    (c,w) loads always in flight.
+//                  - update_kernel (Median, ragged tails), update_clr_kernel (ragged tail): the same
+//                    decomposition in HIP, sample pairs software-pipelined.
+//                  - update_chain_kernel: one lane per (node, dim) chain for maps too small to fill
+//                    the chip with lane = node.
+//                  Every fp32 operation is rounded separately (-ffp-contract=off), so the result is
+//                  bit-identical to the reference's SSE2 build (VSOM_UPDATE_FMA opts out, 1e-5).
+//   sigma_finalize_kernel : sigmaMap = sqrt(S / W) for the columns the assembly kernels left as S.
 #include "vsom_device.hpp"
 #include <cmath>
 #include <cstdlib>
