@@ -7,7 +7,9 @@
 //   samples      : Bcap x xpitch fp32 (xpitch = roundup(J,32), zero padded)
 //   CLR samples  : XP/YP Bcap x part_pitch (x'_p = x[i(p)], y'_p = x[j(p)], pairs i<j
 //                  lexicographic, Transformation.cpp:94-101)
-//   cw           : B x ldn float2 (c = w/W prefix, w) per (sample, node)
+//   cw           : (c = w/W prefix, w) per (sample, node), pair-interleaved: one float4
+//                  {c_j, w_j, c_j+1, w_j+1} at [(j>>1)][node], ceil(B/2)+8 pair rows of ldn nodes
+//   Xnext[2]     : raw B x J chunks landing on the copy stream (double-buffered ingest)
 #pragma once
 
 #include <hip/hip_runtime.h>
