@@ -182,3 +182,31 @@ def test_sharded_phases_equal_whole_epoch():
     _same(ctx.get_last_bmu(), lb, "lastBMU")
     _check_state(ctx, orc, "sharded")
     ctx.close()
+
+
+def test_empty_chunk_epoch_rewrites_every_neuron():
+    """trainBatchSomEpoch over a chunk of zero rows: no BMUs, MSE 0, and phase 2 still runs -- model
+    vectors become zero, sigmaMap sqrt(0/0) = NaN, weightMap 0 (Som.cpp:840-875); bmuHits untouched."""
+    W, H, J = 9, 7, 13
+    init = gen.random_map(W * H, J, seed=42)
+    X = gen.blobs(50, J, 4, 1, 2)
+    for tr in (po.STANDARD, po.CLR):
+        Jt = 5 if tr == po.CLR else J
+        D = po.length(tr, Jt)
+        init = gen.random_map(W * H, D, seed=42)
+        Xt = X[:, :Jt].copy()
+        ctx, orc = _mk(W, H, Jt, tr, init)
+        lb = np.zeros(50, np.uint64)
+        orc.batch_epoch(Xt, lb, 4.0, True)
+        ctx.upload_chunk(Xt)
+        ctx.batch_epoch(4.0, True)
+        empty = np.zeros((0, Jt), np.float32)
+        mse_o = orc.batch_epoch(empty, np.zeros(0, np.uint64), 4.0, False)
+        ctx.upload_chunk(empty)
+        mse_g = ctx.batch_epoch(4.0, False)
+        assert np.float32(mse_g) == np.float32(mse_o) == 0
+        assert ctx.chunk_size == 0
+        _check_state(ctx, orc, "empty chunk")
+        st = ctx.get_state()
+        assert (st["map"] == 0).all() and np.isnan(st["sigma"]).all() and (st["weight"] == 0).all()
+        ctx.close()

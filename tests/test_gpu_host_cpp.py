@@ -133,6 +133,34 @@ def test_octave_text_checkpoint(dumps):
     assert (got["S"] == 0).all()                            # not part of the format (Som.cpp:51-83 zeroes it)
 
 
+def test_mnist_loader_to_batch_training_end_to_end(tmp_path):
+    """BASELINE configuration 2's plumbing (IDX -> MnistDataLoader -> DataSet -> Som::train BatchMap)
+    against the oracle on the same rows and chunk boundaries.  A chunked MnistDataLoader pass ends
+    with a zero-row load (MnistDataLoader.cpp:49-55) and the reference's epoch over that empty chunk
+    rewrites every neuron (zero vector, NaN sigma, zero weight, Som.cpp:840-875) -- reproduced."""
+    import struct
+    rs = np.random.RandomState(11)
+    n = 600
+    images = (rs.randint(0, 256, size=(n, 28, 28)) * (rs.rand(n, 28, 28) < 0.2)).astype(np.uint8)
+    labels = rs.randint(0, 10, size=n).astype(np.uint8)
+    folder = str(tmp_path)
+    with open(os.path.join(folder, "train-images-idx3-ubyte"), "wb") as f:
+        f.write(struct.pack(">IIII", 0x803, n, 28, 28) + images.tobytes())
+    with open(os.path.join(folder, "train-labels-idx1-ubyte"), "wb") as f:
+        f.write(struct.pack(">II", 0x801, n) + labels.tobytes())
+    exe = os.path.join(HOST, "host_api_test")
+    res = subprocess.run([exe, "mnist", folder, folder], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-400:] + res.stderr[-400:]
+    rows = np.concatenate([images.reshape(n, 784), np.eye(10)[labels]], axis=1).astype(np.float32)
+    o = po.OracleSom(12, 12, 794, po.STANDARD)
+    o.random_initialize(5, 1.0)
+    done, mse = o.train_batch(rows, [0, 256, 512, 600, 600], 3, 6.0, 0.2, nthreads=4)   # 256, 256, 88, 0 rows
+    dump = read_dump(os.path.join(folder, "mnist_batch.bin"))
+    check_state(dump, o)
+    assert done == 3 and beq(dump["mse"], mse)
+    assert (dump["map"] == 0).all() and np.isnan(dump["sigma"]).all()    # the empty chunk's doing
+
+
 def test_custom_transformation_is_rejected_not_emulated(dumps):
     _, out, err = dumps
     assert "custom_transformation_rejected=1 kind=-1" in out

@@ -671,8 +671,9 @@ int launch_finish(vsom_ctx *c)
 {
     {
         TimerScope ts(c, VSOM_T_FINISH);
-        hipLaunchKernelGGL(hits_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, c->stream, c->lastbmu,
-                           (int)c->B, c->hits);
+        if (c->B > 0)
+            hipLaunchKernelGGL(hits_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, c->stream, c->lastbmu,
+                               (int)c->B, c->hits);
         VSOM_HIP_CHECK(hipGetLastError());
     }
     // the serial MSE sum (~5 ns per sample) reads sqres and writes mse only: it runs on the side

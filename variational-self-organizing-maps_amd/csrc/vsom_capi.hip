@@ -397,6 +397,7 @@ int vsom_set_chunk_device(vsom_ctx *c, const float *x_dev, size_t B)
     if (rc)
         return rc;
     c->B = B;
+    c->chunk_loaded = true;
     return launch_stage_chunk(c, x_dev, B);
 }
 
@@ -677,7 +678,7 @@ int vsom_batch_phase1_async(vsom_ctx *c, size_t s0, size_t s1, int is_first)
 int vsom_batch_finish_async(vsom_ctx *c)
 {
     CHECK_CTX(c);
-    if (c->B == 0)
+    if (!c->chunk_loaded)   // an EMPTY chunk is legal: the reference's epoch then zeroes the map
         return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
     return launch_finish(c);
 }
@@ -687,7 +688,7 @@ int vsom_batch_phase2_async(vsom_ctx *c, double sigma, size_t n0, size_t n1)
     CHECK_CTX_NOJOIN(c);
     if (n0 > n1 || n1 > c->N)
         return vsom_fail(VSOM_ERR_INVALID, "node range out of bounds");
-    if (c->B == 0)
+    if (!c->chunk_loaded)   // an EMPTY chunk is legal: the reference's epoch then zeroes the map
         return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
     return launch_phase2(c, sigma, n0, n1);
 }
@@ -695,7 +696,7 @@ int vsom_batch_phase2_async(vsom_ctx *c, double sigma, size_t n0, size_t n1)
 int vsom_batch_epoch_async(vsom_ctx *c, double sigma, int is_first)
 {
     CHECK_CTX(c);
-    if (c->B == 0)
+    if (!c->chunk_loaded)   // an EMPTY chunk is legal: the reference's epoch then zeroes the map
         return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
     int rc = vsom_batch_phase1_async(c, 0, c->B, is_first);
     if (rc)

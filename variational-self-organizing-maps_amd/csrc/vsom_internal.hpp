@@ -48,6 +48,7 @@ struct vsom_ctx {
 
     // chunk
     size_t B = 0, Bcap = 0;
+    bool chunk_loaded = false;      // a chunk (possibly of 0 rows) has been staged
     float *Xs = nullptr, *XP = nullptr, *YP = nullptr;
     float *Xraw = nullptr;          // staging for host uploads (B x J, unpadded)
     size_t Xraw_cap = 0;

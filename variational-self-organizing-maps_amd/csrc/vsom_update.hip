@@ -738,10 +738,43 @@ int ensure_lut(vsom_ctx *c, double sigma)
     return VSOM_OK;
 }
 
+// trainBatchSomEpoch on an EMPTY chunk (the trailing zero-row load of a chunked MnistDataLoader pass,
+// MnistDataLoader.cpp:49-55): phase 2 still runs over every node with no samples -- the model vector
+// becomes the zero it started from (:843,870), sigmaMap = sqrt(0/0) = NaN (:873), weightMap = 0 (:875)
+__global__ void empty_epoch_kernel(float *__restrict__ map, float *__restrict__ sigma, float *__restrict__ weight,
+                                   int pitch, int part_pitch, int part_len, int n0, int nloc)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)nloc * pitch)
+        return;
+    const int nl = (int)(i / pitch), col = (int)(i % pitch);
+    const size_t at = (size_t)(n0 + nl) * pitch + col;
+    const float zero = weight[n0 + nl] * 0.f;          // keeps the division below out of the constant folder
+    map[at] = 0.f;
+    sigma[at] = (col % part_pitch) < part_len ? sqrtf(0.f / (zero * 0.f + 0.f)) : 0.f;   // pad columns stay zero
+}
+
+__global__ void zero_weight_kernel(float *__restrict__ weight, int n0, int nloc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nloc)
+        weight[n0 + i] = 0.f;
+}
+
 int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
 {
-    if (n1 <= n0 || c->B == 0)
+    if (n1 <= n0)
         return vsom_join_aux(c);
+    if (c->B == 0) {
+        TimerScope ts(c, VSOM_T_UPDATE);
+        const size_t nloc = n1 - n0, tot = nloc * c->pitch;
+        hipLaunchKernelGGL(empty_epoch_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->map,
+                           c->sigma, c->weight, (int)c->pitch, (int)c->part_pitch, (int)c->part_len, (int)n0, (int)nloc);
+        hipLaunchKernelGGL(zero_weight_kernel, dim3((unsigned)((nloc + 255) / 256)), dim3(256), 0, c->stream, c->weight,
+                           (int)n0, (int)nloc);
+        VSOM_HIP_CHECK(hipGetLastError());
+        return vsom_join_aux(c);
+    }
     int rc = ensure_lut(c, sigma);
     if (rc)
         return rc;

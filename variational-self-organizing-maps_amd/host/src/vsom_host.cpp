@@ -786,8 +786,9 @@ float Som::trainBatchSomEpoch(DataSet &dataset, double currentSigma, bool isFirs
 {
     requireDevicePath("trainBatchSomEpoch");
     const size_t B = dataset.size();
-    if (B == 0)
-        return 0.f;
+    // B == 0 is not skipped: the reference's epoch over an empty chunk still rewrites every neuron
+    // (zero model vector, NaN sigma, zero weight -- Som.cpp:840-875), e.g. after the zero-row load that
+    // ends every chunked MnistDataLoader pass
     check(vsom_upload_chunk(ctx, dataset.contiguous(), B), "vsom_upload_chunk");
     std::vector<uint64_t> lb(B);
     if (!isFirst) {
@@ -832,10 +833,9 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
         const bool another = i + 1 < numberOfEpochs && sigmaOf(i + 1) >= 1.0;
         while (have) {
             const size_t Bcur = B;
-            if (Bcur > 0) {
-                check(vsom_commit_chunk(ctx), "vsom_commit_chunk");   // lastBMU := 0 (DataSet.cpp:136-137)
-                check(vsom_batch_epoch_async(ctx, sigma, i == 0 ? 1 : 0), "vsom_batch_epoch_async");
-            }
+            // (also for an empty chunk: the reference's epoch then zeroes the map, see trainBatchSomEpoch)
+            check(vsom_commit_chunk(ctx), "vsom_commit_chunk");   // lastBMU := 0 (DataSet.cpp:136-137)
+            check(vsom_batch_epoch_async(ctx, sigma, i == 0 ? 1 : 0), "vsom_batch_epoch_async");
             have = false;
             const bool last = data.hasReadWholeDataStream();
             if (!last) {
@@ -858,8 +858,7 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
                     data.getLastBMU(s) = (size_t)lb[s];
             }
             float mse = 0.f;
-            if (Bcur > 0)
-                check(vsom_get_mse(ctx, &mse), "vsom_get_mse");
+            check(vsom_get_mse(ctx, &mse), "vsom_get_mse");
             meanSquareError += mse;
             ++countDataChunks;
             if (last) {

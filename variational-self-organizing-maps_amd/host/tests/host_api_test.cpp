@@ -6,6 +6,7 @@
 #include "SOM.hpp"
 #include "DataSet.hpp"
 #include "Transformation.hpp"
+#include "MnistDataLoader.hpp"
 
 #include <chrono>
 #include <cstdio>
@@ -64,10 +65,27 @@ static int perf()
     return 0;
 }
 
+// `host_api_test mnist <folder> <outdir>`: BASELINE configuration 2's plumbing at test size -- IDX files
+// -> MnistDataLoader (chunked) -> DataSet -> Som::train(BatchMap); the dump is compared with the oracle
+// run on the same rows and chunk boundaries (tests/test_gpu_host_cpp.py)
+static int mnist(const std::string &folder, const std::string &out)
+{
+    MnistDataLoader loader(256);
+    loader.open(folder.c_str());
+    DataSet ds(loader);
+    Som som{12, 12, ds, Transformation::Standard(loader.getNames())};   // depth 794 from the loader
+    som.randomInitialize(5, 1);
+    som.train(ds, 3, 0.0, 0.0, 6.0, 0.2, Som::WeigthDecayFunction::BatchMap);
+    dump(out + "/mnist_batch.bin", som, som.getMetrics().MeanSquaredError);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc > 1 && std::string(argv[1]) == "perf")
         return perf();
+    if (argc > 3 && std::string(argv[1]) == "mnist")
+        return mnist(argv[2], argv[3]);
     const std::string out = argc > 1 ? argv[1] : ".";
     const size_t W = 10, H = 10, J = 9, NROWS = 50, CHUNK = 20;
     auto rows = make_rows(NROWS, J, 12345u);
