@@ -200,6 +200,13 @@ int vsom_train_single(vsom_ctx *ctx, const float *v_host, double eta, double sig
  * NULL the call only enqueues (asynchronous); vsom_get_mse then returns the chunk's MSE.     */
 int vsom_train_online_chunk(vsom_ctx *ctx, double eta, double sigma, int decay_fn,
                             float *mse_out);
+/* The same with the epoch's MSE accumulator carried over: the reference keeps ONE running float over
+ * all chunks of an epoch (declared before the chunk loop, Som.cpp:1153; every sample adds its
+ * squaredNorm/epochSize, :1167).  first_chunk != 0 starts it at 0, otherwise it continues from the
+ * previous chunk; mse_out / vsom_get_mse give the running value after this chunk.
+ * vsom_train_online_chunk = first_chunk 1. */
+int vsom_train_online_chunk_acc(vsom_ctx *ctx, double eta, double sigma, int decay_fn, int first_chunk,
+                                float *mse_out);
 
 /* ---- static helper: Som::calculateNeighbourhoodWeight (Som.cpp:949-975) ---------------- */
 double vsom_neighbourhood_weight(size_t cx, size_t cy, size_t bx, size_t by, double sigma);

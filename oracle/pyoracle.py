@@ -86,6 +86,8 @@ def lib():
     L.vso_train_single.argtypes = [sp, fp, C.c_double, C.c_double, u64p, C.c_int, fp, fp]
     L.vso_train_online_chunk.restype = C.c_float
     L.vso_train_online_chunk.argtypes = [sp, fp, C.c_size_t, u64p, C.c_double, C.c_double, C.c_int]
+    L.vso_train_online_chunk_from.restype = C.c_float
+    L.vso_train_online_chunk_from.argtypes = [sp, fp, C.c_size_t, u64p, C.c_double, C.c_double, C.c_int, C.c_float]
     L.vso_train_online.argtypes = [sp, fp, szp, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
                                    C.c_double, C.c_double, C.c_int, fp]
     L.vso_find_restricted_bmu.restype = C.c_size_t
@@ -276,10 +278,13 @@ class OracleSom:
                                      int(decay_fn), _f(res), C.byref(dist))
         return int(bmu), res, np.float32(dist.value), int(lb.value)
 
-    def train_online_chunk(self, X, lastbmu, eta, sigma, decay_fn):
+    def train_online_chunk(self, X, lastbmu, eta, sigma, decay_fn, mse_start=0.0):
+        """One chunk of trainBasicSom's sample loop; returns the epoch's running MSE accumulator after
+        it (mse_start = its value before: the reference keeps one accumulator per epoch)."""
         X = self._chk(X)
-        return np.float32(lib().vso_train_online_chunk(self._p, _f(X), X.shape[0], _u(lastbmu),
-                                                       float(eta), float(sigma), int(decay_fn)))
+        return np.float32(lib().vso_train_online_chunk_from(self._p, _f(X), X.shape[0], _u(lastbmu),
+                                                            float(eta), float(sigma), int(decay_fn),
+                                                            float(np.float32(mse_start))))
 
     def train_online(self, X, chunk_off, epochs, eta0, eta_decay, sigma0, sigma_decay, decay_fn):
         X = self._chk(X)

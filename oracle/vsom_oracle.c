@@ -626,12 +626,16 @@ size_t vso_train_single(vso_som *som, const float *v, double eta, double sigma,
 }
 
 /* ---- inner loop of trainBasicSom: Som.cpp:1159-1171 ---- */
-float vso_train_online_chunk(vso_som *som, const float *X, size_t B,
-                             uint64_t *lastbmu, double eta, double sigma, int decay_fn)
+/* One chunk of the sample loop.  The reference keeps ONE running float over all chunks of an epoch
+ * (meanSquareError is declared before the chunk loop, Som.cpp:1153, and every sample adds
+ * squaredNorm/epochSize of ITS chunk, :1167); mse_start is that running value on entry and the
+ * return value is the running value after this chunk. */
+float vso_train_online_chunk_from(vso_som *som, const float *X, size_t B, uint64_t *lastbmu,
+                                  double eta, double sigma, int decay_fn, float mse_start)
 {
     const size_t L = vso_comparer_len(som->transform, som->depth);
     float *res = (float *)malloc((L ? L : 1) * sizeof(float));
-    float mse = 0.0f, fB = (float)B;
+    float mse = mse_start, fB = (float)B;
     for (size_t j = 0; j < B; ++j) {
         size_t pos = vso_train_single(som, X + j * som->in_len, eta, sigma, &lastbmu[j],
                                       decay_fn, res, NULL);
@@ -641,6 +645,12 @@ float vso_train_online_chunk(vso_som *som, const float *X, size_t B,
     }
     free(res);
     return mse;
+}
+
+float vso_train_online_chunk(vso_som *som, const float *X, size_t B,
+                             uint64_t *lastbmu, double eta, double sigma, int decay_fn)
+{
+    return vso_train_online_chunk_from(som, X, B, lastbmu, eta, sigma, decay_fn, 0.0f);
 }
 
 /* ---- Som::trainBasicSom: Som.cpp:1135-1187 ---- */
@@ -662,8 +672,8 @@ void vso_train_online(vso_som *som, const float *X, const size_t *chunk_off,
         for (size_t c = 0; c < nchunks; ++c) {
             size_t B = chunk_off[c + 1] - chunk_off[c];
             memset(lastbmu, 0, B * sizeof(uint64_t)); /* DataSet.cpp:136-137 */
-            mse += vso_train_online_chunk(som, X + chunk_off[c] * som->in_len, B, lastbmu,
-                                          eta, sigma, decay_fn);
+            mse = vso_train_online_chunk_from(som, X + chunk_off[c] * som->in_len, B, lastbmu,
+                                              eta, sigma, decay_fn, mse); /* one accumulator :1153,1167 */
             ++count;
         }
         mse /= (float)count; /* :1175 */

@@ -118,6 +118,9 @@ size_t vso_train_single(vso_som *som, const float *v, double eta, double sigma,
                         float *residual_out, float *dist_out);
 /* Inner loop of Som::trainBasicSom over one chunk (Som.cpp:1159-1171): returns the
  * chunk's fp32 MSE contribution; lastbmu[B] in/out; bmuHits updated (addBmu). */
+/* running-sum form: returns mse_start + the chunk's terms, added in sample order (Som.cpp:1153,1167) */
+float vso_train_online_chunk_from(vso_som *som, const float *X, size_t B, uint64_t *lastbmu,
+                                  double eta, double sigma, int decay_fn, float mse_start);
 float vso_train_online_chunk(vso_som *som, const float *X, size_t B,
                              uint64_t *lastbmu, double eta, double sigma, int decay_fn);
 /* Som::trainBasicSom (Som.cpp:1135-1187). */

@@ -6,6 +6,7 @@ import pytest
 
 import gen
 import vsom_amd
+from vsom_amd import capi
 from oracle import pyoracle as po
 
 pytestmark = pytest.mark.gpu
@@ -110,4 +111,30 @@ def test_find_bmu_single_vector(tr, W, H, J):
     orc.set_state(map=bad)
     for i in range(10):
         assert ctx.find_bmu(X[i])[0] == orc.find_bmu(X[i])
+    ctx.close()
+
+
+def test_online_epoch_mse_is_one_running_accumulator():
+    """trainBasicSom adds every sample's squaredNorm/epochSize to ONE float declared before the chunk
+    loop (Som.cpp:1153,1167): the device keeps that accumulator across chunks."""
+    W = H = 9
+    J = 11
+    X = gen.blobs(90, J, 3, 1, 2)
+    init = gen.random_map(W * H, J, seed=42)
+    off = [0, 37, 64, 90]
+    o = po.OracleSom(W, H, J)
+    o.set_state(map=init)
+    want = o.train_online(X, off, 1, 0.07, 0.0, 2.5, 0.0, po.EXPONENTIAL)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_state(map=init)
+    run = np.float32(0)
+    sums = []
+    for c in range(3):
+        ctx.upload_chunk(X[off[c]:off[c + 1]])
+        run = ctx.train_online_chunk(0.07, 2.5, capi.EXPONENTIAL, first_chunk=(c == 0))
+        sums.append(run)
+    got = np.float32(run / np.float32(3))
+    assert got.view(np.uint32) == np.float32(want[0]).view(np.uint32)
+    # and it is NOT the sum of per-chunk sums in general (different rounding) -- at least it is monotone
+    assert sums[0] <= sums[1] <= sums[2]
     ctx.close()

@@ -30,7 +30,7 @@ SYMBOLS = [
     "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_find_bmu", "vsom_bmu_local_batch",
     "vsom_distances", "vsom_bmu_restricted_batch", "vsom_distances_row", "vsom_distances_raw", "vsom_batch_phase1_async", "vsom_batch_finish_async",
     "vsom_batch_phase2_async", "vsom_batch_epoch_async", "vsom_batch_epoch", "vsom_get_mse",
-    "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk",
+    "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk", "vsom_train_online_chunk_acc",
     "vsom_neighbourhood_weight", "vsom_device_ptr", "vsom_chunk_size", "vsom_pitch",
     "vsom_chunk_pitch", "vsom_enable_timing", "vsom_get_timing",
 ]
@@ -106,6 +106,7 @@ def lib():
     L.vsom_get_mse.argtypes = [vp, fp]
     L.vsom_train_single.argtypes = [vp, fp, C.c_double, C.c_double, u64p, C.c_int, fp, fp, u64p]
     L.vsom_train_online_chunk.argtypes = [vp, C.c_double, C.c_double, C.c_int, fp]
+    L.vsom_train_online_chunk_acc.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int, fp]
     L.vsom_neighbourhood_weight.argtypes = [C.c_size_t] * 4 + [C.c_double]
     L.vsom_neighbourhood_weight.restype = C.c_double
     L.vsom_device_ptr.argtypes = [vp, C.c_int]
@@ -358,10 +359,12 @@ class Context:
                                       int(decay_fn), _f(res), C.byref(dist), C.byref(bmu)))
         return int(bmu.value), res, np.float32(dist.value), int(lb.value)
 
-    def train_online_chunk(self, eta, sigma, decay_fn):
+    def train_online_chunk(self, eta, sigma, decay_fn, first_chunk=True):
+        """B sequential trainSingle steps on the staged chunk; returns the epoch's running MSE
+        accumulator after it (first_chunk=False continues the previous chunk's value)."""
         mse = C.c_float()
-        check(lib().vsom_train_online_chunk(self._h, float(eta), float(sigma), int(decay_fn),
-                                            C.byref(mse)))
+        check(lib().vsom_train_online_chunk_acc(self._h, float(eta), float(sigma), int(decay_fn),
+                                                int(bool(first_chunk)), C.byref(mse)))
         return np.float32(mse.value)
 
     # ---- measurement ---------------------------------------------------

@@ -324,14 +324,15 @@ __global__ __launch_bounds__(256) void online_small_kernel(
         online_post<CLR>(a, bmu, lane, hits, lastbmu_io, residual, fB, add_hit);
 }
 
-__global__ void online_init_kernel(u64 *state, float *fstate)
+__global__ void online_init_kernel(u64 *state, float *fstate, int keep_mse)
 {
     state[0] = ~0ull;
     state[1] = ~0ull;
     state[2] = 0ull;
     state[3] = 0ull;
     fstate[0] = 0.f;
-    fstate[1] = 0.f;
+    if (!keep_mse)
+        fstate[1] = 0.f;   // else: the epoch's running MSE continues across chunks (Som.cpp:1153,1167)
 }
 
 // double-precision table of calculateNeighbourhoodWeight for the online path (the batch path
@@ -517,7 +518,8 @@ int vsom_find_bmu(vsom_ctx *c, const float *v_host, uint64_t *bmu_out, float *di
     return VSOM_OK;
 }
 
-int vsom_train_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn, float *mse_out)
+int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay_fn, int first_chunk,
+                                float *mse_out)
 {
     if (!c)
         return vsom_fail(VSOM_ERR_INVALID, "null context");
@@ -526,7 +528,7 @@ int vsom_train_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn,
         return jrc;
     if (decay_fn != VSOM_EXPONENTIAL && decay_fn != VSOM_INVERSE_PROPORTIONAL)
         return vsom_fail(VSOM_ERR_INVALID, "online training needs Exponential or InverseProportional");
-    if (c->B == 0)
+    if (!c->chunk_loaded)   // an empty chunk is a no-op for the sample loop (Som.cpp:1161)
         return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
     const double *lutd = nullptr;
     int lutw = 0;
@@ -535,7 +537,8 @@ int vsom_train_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn,
         return rc;
     {
         TimerScope ts(c, VSOM_T_ONLINE);
-        hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f);
+        hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f,
+                           first_chunk ? 0 : 1);
         const float fB = (float)c->B;
         for (size_t j = 0; j < c->B; ++j) {
             const float *xs = c->Xs + j * c->xpitch;
@@ -555,6 +558,11 @@ int vsom_train_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn,
         VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     return VSOM_OK;
+}
+
+int vsom_train_online_chunk(vsom_ctx *c, double eta, double sigma, int decay_fn, float *mse_out)
+{
+    return vsom_train_online_chunk_acc(c, eta, sigma, decay_fn, 1, mse_out);
 }
 
 int vsom_train_single(vsom_ctx *c, const float *v_host, double eta, double sigma, uint64_t *last_bmu,
@@ -592,7 +600,7 @@ int vsom_train_single(vsom_ctx *c, const float *v_host, double eta, double sigma
     VSOM_HIP_CHECK(hipMemcpyAsync(tail, ptail_in, 16, hipMemcpyHostToDevice, c->stream));
     {
         TimerScope ts(c, VSOM_T_ONLINE);
-        hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f);
+        hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f, 1);
         rc = enqueue_single(c, xs, xp, yp, eta, sigma, decay_fn, lb, res, 1.0f, 0, lutd, lutw, 0, tail + 2);
         if (rc)
             return rc;

@@ -809,7 +809,8 @@ float Som::trainBatchSomEpoch(DataSet &dataset, double currentSigma, bool isFirs
 // on chunk k (asynchronous epoch), the host loads chunk k+1 from the loader and starts its
 // host->device copy (vsom_prefetch_chunk from the DataSet's pinned staging buffer).  The reference
 // reloads every chunk every epoch (:737), so this overlap recurs for the whole run.
-void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, double sigmaDecay, bool)
+void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, double sigmaDecay,
+                        bool updateUMatrixAfterEpoch)
 {
     requireDevicePath("trainBatchSom");
     metrics = Som::Metrics(numberOfEpochs);   // Som.cpp:719
@@ -876,6 +877,8 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
             have = true;              // chunk 0 of epoch i+1 is already loaded and on its way
         else
             data.resetStreamLoadPosition();   // :749
+        if (updateUMatrixAfterEpoch)
+            updateUMatrix(data.getWeights());   // :751-752
     }
 }
 
@@ -904,7 +907,7 @@ Som::TrainingReturnValue Som::trainSingle(const Eigen::VectorXf &v, const Eigen:
 }
 
 void Som::trainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, double etaDecay, double sigma0,
-                        double sigmaDecay, WeigthDecayFunction weightDecayFunction, bool)
+                        double sigmaDecay, WeigthDecayFunction weightDecayFunction, bool updateUMatrixAfterEpoch)
 {
     requireDevicePath("trainBasicSom");
     metrics = Som::Metrics(numberOfEpochs);   // Som.cpp:1139
@@ -928,11 +931,12 @@ void Som::trainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, doubl
         }
         while (have) {
             const size_t Bcur = B;
-            if (Bcur > 0) {
-                check(vsom_commit_chunk(ctx), "vsom_commit_chunk");
-                check(vsom_train_online_chunk(ctx, eta, sigma, decay_code(weightDecayFunction), nullptr),
-                      "vsom_train_online_chunk");
-            }
+            // meanSquareError is ONE running float over all chunks of the epoch (:1153,1167): the device
+            // keeps it across chunks (first chunk starts at 0); an empty chunk adds nothing
+            check(vsom_commit_chunk(ctx), "vsom_commit_chunk");
+            check(vsom_train_online_chunk_acc(ctx, eta, sigma, decay_code(weightDecayFunction), countDataChunks == 0 ? 1 : 0,
+                                              nullptr),
+                  "vsom_train_online_chunk_acc");
             have = false;
             const bool last = data.hasReadWholeDataStream();
             if (last && Bcur > 0) {
@@ -946,10 +950,7 @@ void Som::trainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, doubl
                 check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
                 have = true;
             }
-            float mse = 0.f;
-            if (Bcur > 0)
-                check(vsom_get_mse(ctx, &mse), "vsom_get_mse");
-            meanSquareError += mse;
+            check(vsom_get_mse(ctx, &meanSquareError), "vsom_get_mse");   // the running value so far
             ++countDataChunks;
         }
         meanSquareError /= static_cast<float>(countDataChunks);   // :1175
@@ -959,6 +960,8 @@ void Som::trainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, doubl
         }
         data.resetStreamLoadPosition();
         hostStale = true;
+        if (updateUMatrixAfterEpoch)
+            updateUMatrix(data.getWeights());   // :1183-1184
     }
     std::cout << "\rTraining SOM:100%\n";
 }

@@ -291,7 +291,8 @@ class Som:
             while not data.hasReadWholeDataStream():
                 data.loadNextDataFromStream()
                 self.ctx.upload_chunk(data.data)                  # lastBMU zeroed by the load
-                mse = np.float32(mse + self.ctx.train_online_chunk(eta, sigma, int(weightDecayFunction)))
+                # ONE running accumulator over the epoch's chunks (Som.cpp:1153,1167)
+                mse = self.ctx.train_online_chunk(eta, sigma, int(weightDecayFunction), first_chunk=(count == 0))
                 data.lastBMU[...] = self.ctx.get_last_bmu()
                 count += 1
             mse = np.float32(mse / np.float32(count))             # :1175
