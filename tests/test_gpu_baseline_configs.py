@@ -1,0 +1,83 @@
+"""GPU: the BASELINE.json configurations at (or near) their quoted sizes, whole state compared bit
+for bit with the oracle (NaN == NaN).  C3 (128x128x784, B=4096) has its own file
+(test_gpu_fullsize_properties.py: properties + oracle spot checks, the full oracle epoch would take
+minutes on a few cores); here every configuration at its quoted size, the oracle using all host cores
+(about two seconds per 128x128x784 epoch on the GPU box's 128)."""
+import numpy as np
+import pytest
+
+import gen
+import vsom_amd
+from vsom_amd import capi
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+THREADS = max(1, min(128, po.max_threads()))
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype.kind == "f":
+        return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+    return bool((a == b).all())
+
+
+def _epochs(W, J, tr, X, init, sigmas):
+    ctx = vsom_amd.Context(W, W, J, tr)
+    orc = po.OracleSom(W, W, J, tr)
+    ctx.set_state(map=init)
+    orc.set_state(map=init)
+    for e, sigma in enumerate(sigmas):
+        lb = np.zeros(X.shape[0], np.uint64)
+        mse_o = orc.batch_epoch(X, lb, sigma, e == 0, nthreads=THREADS)
+        ctx.upload_chunk(X)
+        mse_g = ctx.batch_epoch(sigma, e == 0)
+        assert _same(ctx.get_last_bmu(), lb), (e, "lastBMU")
+        assert _same(np.float32(mse_g), np.float32(mse_o)), (e, "mse", mse_g, mse_o)
+        st = ctx.get_state()
+        for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("weight", orc.weight), ("hits", orc.hits)):
+            assert _same(st[k], ref), (e, k)
+    ctx.close()
+
+
+def test_c1_10x10x16_batch_schedule_and_online():
+    X = gen.blobs(1024, 16, 4, 1, 2)
+    init = gen.random_map(100, 16, seed=42)
+    _epochs(10, 16, po.STANDARD, X, init, [5.0 * np.exp(-0.05 * i) for i in range(10)])
+    ctx = vsom_amd.Context(10, 10, 16)
+    orc = po.OracleSom(10, 10, 16)
+    ctx.set_state(map=init)
+    orc.set_state(map=init)
+    lb = np.zeros(1024, np.uint64)
+    mse_o = orc.train_online_chunk(X, lb, 0.1, 3.0, po.EXPONENTIAL)
+    ctx.upload_chunk(X)
+    mse_g = ctx.train_online_chunk(0.1, 3.0, capi.EXPONENTIAL)
+    assert _same(np.float32(mse_g), np.float32(mse_o)) and _same(ctx.get_last_bmu(), lb)
+    st = ctx.get_state()
+    for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("S", orc.S), ("weight", orc.weight), ("hits", orc.hits)):
+        assert _same(st[k], ref), k
+    ctx.close()
+
+
+def test_c2_64x64x784_mnist_like():
+    X = gen.mnist_like(4096, seed=3, dim=784)
+    init = gen.random_map(64 * 64, 784, seed=42) * np.float32(100) + np.float32(100)
+    _epochs(64, 784, po.STANDARD, X, init, [16.0, 14.5])
+
+
+def test_c3_128x128x784_full_chunk():
+    X = gen.mnist_like(4096, seed=3, dim=784)
+    init = gen.random_map(128 * 128, 784, seed=42) * np.float32(100) + np.float32(100)
+    _epochs(128, 784, po.STANDARD, X, init, [32.0, 29.0])
+
+
+def test_c4_64x64x32_median_full_chunk():
+    X = gen.blobs(16384, 32, 8, 1, 4, sigma=1.0)
+    init = gen.random_map(64 * 64, 32, seed=42)
+    _epochs(64, 32, po.MEDIAN, X, init, [16.0, 14.0])
+
+
+def test_c5_32x32_clr_J64():
+    X = gen.correlated(8192, 64, seed=5)
+    init = gen.random_map(32 * 32, 64 * 63, seed=42)
+    _epochs(32, 64, po.CLR, X, init, [8.0, 7.0])
