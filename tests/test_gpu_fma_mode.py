@@ -20,14 +20,15 @@ def rel_err(a, b):
 
 
 @pytest.mark.parametrize("W,H,J,B,sigma,kind", [(24, 24, 784, 512, 8.0, "mnist"), (32, 32, 28, 1500, 10.0, "blobs"),
-                                                (16, 16, 48, 4096, 6.0, "blobs")])
+                                                (16, 16, 48, 4096, 6.0, "blobs"),
+                                                (128, 128, 784, 4096, 32.0, "mnist")])
 def test_fma_mode_within_tolerance(W, H, J, B, sigma, kind):
     X = gen.mnist_like(B, 3, J) if kind == "mnist" else gen.blobs(B, J, 5, 1, 2, sigma=0.4)
     init = gen.random_map(W * H, J, 42) * (np.float32(100) if kind == "mnist" else np.float32(1))
     o = po.OracleSom(W, H, J)
     o.set_state(map=init)
     lb = np.zeros(B, np.uint64)
-    mse_o = o.batch_epoch(X, lb, sigma, True, nthreads=16)
+    mse_o = o.batch_epoch(X, lb, sigma, True, nthreads=max(16, min(128, po.max_threads())))
     ctx = vsom_amd.Context(W, H, J)
     ctx.set_state(map=init)
     ctx.set_update_mode(capi.UPDATE_FMA)
