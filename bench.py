@@ -278,7 +278,8 @@ def main():
             dtf, upd_f_ms = fma_extra
             ach_f = flops_launch / (upd_f_ms / 1e3) / 1e12 if upd_f_ms > 0 else 0.0
             out["fma_mode"] = {"note": "opt-in VSOM_UPDATE_FMA arithmetic (tests/test_gpu_fma_mode.py: map/sigma within "
-                                       "1e-5 relative, BMU indices / bmuHits / MSE / weightMap bit-exact); not the headline",
+                                       "1e-5 relative -- measured 3.4e-7 at this size, tools/fma_error_report.py -- BMU "
+                                       "indices / bmuHits / MSE / weightMap bit-exact); not the headline",
                                "value": round(args.steps * Bglob / dtf, 3), "ms_per_step": round(dtf / args.steps * 1e3, 4),
                                "update_avg_launch_ms": round(upd_f_ms, 4), "update_achieved_tflops": round(ach_f, 3),
                                "update_frac_of_peak": round(ach_f / FP32_PEAK_TFLOPS, 4)}
