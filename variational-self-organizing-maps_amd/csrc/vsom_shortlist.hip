@@ -47,8 +47,23 @@ __global__ __launch_bounds__(256) void sl_norm_kernel(const float *__restrict__ 
     const float4 *row = reinterpret_cast<const float4 *>(map + (size_t)nc * ldm);
     const int n4 = Dp >> 2;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll 4
-    for (int q = sub; q < n4; q += 16) {
+    // 8 independent 16-byte loads in flight per lane (the kernel is a single pass over the map and
+    // was latency-bound at 4)
+    int q = sub;
+    for (; q + 7 * 16 < n4; q += 8 * 16) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = row[q + 16 * u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s0 = s0 + v[u].x * v[u].x;
+            s1 = s1 + v[u].y * v[u].y;
+            s2 = s2 + v[u].z * v[u].z;
+            s3 = s3 + v[u].w * v[u].w;
+        }
+    }
+    for (; q < n4; q += 16) {
         float4 v = row[q];
         s0 = s0 + v.x * v.x;
         s1 = s1 + v.y * v.y;
@@ -58,14 +73,32 @@ __global__ __launch_bounds__(256) void sl_norm_kernel(const float *__restrict__ 
     float s = (s0 + s1) + (s2 + s3);
     for (int off = 8; off > 0; off >>= 1)
         s = s + __shfl_xor(s, off);
+    // one atomic per workgroup: 16384 same-address atomics serialise in L2 (they were most of this
+    // kernel's 55 us)
+    __shared__ unsigned smax[4];
+    unsigned bits = 0u;
     if (sub == 0 && node < N) {
         nrm[node] = s;
         if (s == s) {   // NaN rows are legal (excluded from every search)
             if (s > 3.0e38f)
                 atomicOr(&scal[1], 1u);
             else
-                atomicMax(&scal[0], __float_as_uint(s));
+                bits = __float_as_uint(s);   // s >= 0: the bit pattern orders like the value
         }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned o = (unsigned)__shfl_xor((int)bits, off);
+        bits = o > bits ? o : bits;
+    }
+    if ((threadIdx.x & 63) == 0)
+        smax[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = smax[0];
+        for (int i = 1; i < 4; ++i)
+            m = smax[i] > m ? smax[i] : m;
+        if (m)
+            atomicMax(&scal[0], m);
     }
 }
 

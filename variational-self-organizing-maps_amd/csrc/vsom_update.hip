@@ -639,19 +639,23 @@ __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict
     }
 }
 
-// sigmaMap[i] = sqrt(S / W)  (Som.cpp:873) for the columns the assembly kernel left as raw S
-__global__ void sigma_finalize_kernel(float *__restrict__ sigma, int pitch, int col0, int ncols, int n0, int nloc,
-                                      const float *__restrict__ weight)
+// sigmaMap[i] = sqrt(S / W)  (Som.cpp:873) for the columns the assembly kernels left as raw S.
+// One workgroup per node row, 8-byte accesses (ncols is even: 14/16 dims or 8 pairs per slice).
+__global__ __launch_bounds__(256) void sigma_finalize_kernel(float *__restrict__ sigma, int pitch, int col0, int ncols,
+                                                             int n0, int nloc, const float *__restrict__ weight)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)nloc * ncols;
-    if (i >= total)
+    const int nl = blockIdx.x;
+    if (nl >= nloc)
         return;
-    const int nl = (int)(i / ncols), d = (int)(i % ncols);
     const size_t node = (size_t)n0 + nl;
     const float Wf = weight[node];
-    float *p = sigma + node * pitch + col0 + d;
-    *p = sqrtf(*p / Wf);
+    float2 *p = reinterpret_cast<float2 *>(sigma + node * pitch + col0);
+    for (int i = threadIdx.x; i < (ncols >> 1); i += 256) {
+        float2 v = p[i];
+        v.x = sqrtf(v.x / Wf);
+        v.y = sqrtf(v.y / Wf);
+        p[i] = v;
+    }
 }
 
 // hand-scheduled gfx950 code object (gen_update_asm.py -> vsom_update_gfx950.s -> .hsaco),
@@ -958,10 +962,9 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
     }
     if (sig_cols > 0) {
         TimerScope ts(c, VSOM_T_SIGMA);
-        const size_t tot = nloc * (size_t)sig_cols;
         // the assembly kernels left raw S in those columns (CLR: in the A part and in the B part)
         for (uint32_t part = 0; part < c->nparts; ++part)
-            hipLaunchKernelGGL(sigma_finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(sigma_finalize_kernel, dim3((unsigned)nloc), dim3(256), 0, c->stream,
                                c->sigma, (int)c->pitch, (int)(part * c->part_pitch), sig_cols, (int)n0, (int)nloc,
                                c->weight);
         VSOM_HIP_CHECK(hipGetLastError());
