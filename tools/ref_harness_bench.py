@@ -55,6 +55,19 @@ for fn, label in ((som.WeigthDecayFunction.BatchMap, "train BatchMap 10x10x9, 20
         done = 300
     c = time.perf_counter() - t0
     report(label + f" ({done} epochs)", g / done, c / done, "us_per_epoch")
+    if fn == som.WeigthDecayFunction.BatchMap:
+        # the oracle's `faithful` mode keeps the reference's per-call temporaries and copies (what its
+        # Eigen / std::function code does): closer to what the reference itself costs per epoch
+        o2 = po.OracleSom(10, 10, 9)
+        o2.set_state(map=init)
+        lbf = np.zeros(20, np.uint64)
+        t0 = time.perf_counter()
+        for e in range(done):
+            lbf[:] = 0
+            o2.batch_epoch(rows, lbf, 10.0 * np.exp(-0.01 * e), e == 0, nthreads=1, faithful=True)
+        cf = time.perf_counter() - t0
+        report(label + " -- CPU side in the oracle's faithful (reference-allocation-pattern) mode", g / done, cf / done,
+               "us_per_epoch")
     s.close()
 
 # 3: trainSingle x1000 (perf_tests.cpp:114-140)

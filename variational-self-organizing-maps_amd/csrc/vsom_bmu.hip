@@ -391,76 +391,15 @@ __global__ __launch_bounds__(256) void bmu_local_kernel(DistArgs a, int s0, int 
                                                         float *__restrict__ sqres)
 {
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const int lane = threadIdx.x & 63, g = lane >> 3, k = lane & 7;
+    const int lane = threadIdx.x & 63;
     const int s = s0 + wave;
     if (s >= s1)
         return;   // wave-uniform
     const float *xa = a.xa + (size_t)s * a.ldx;
     const float *xb = a.xb + (size_t)s * a.ldx;
-    const u64 m1 = ~0ull;   // -1uz
-    // firstSearchX / firstSearchY (Som.cpp:341-342)
-    const u64 fsx = (g == 0 || g >= 6) ? m1 : ((g == 1 || g == 5) ? 0ull : 1ull);
-    const u64 fsy = (g <= 2) ? 1ull : ((g == 3 || g == 7) ? 0ull : m1);
-
-    u64 lastBMU = lastbmu[s];
-    float minDist = vsom_group_dist<CLR>(xa, xb, a.ma + (size_t)lastBMU * a.ldm,
-                                         a.mb + (size_t)lastBMU * a.ldm, a.L, k);
-    minDist = __shfl(minDist, 0);
-    u64 minIndex = lastBMU;
-    u64 lastMeasured = lastBMU;
-
-    for (;;) {
-        const u64 lmX = lastMeasured % width, lmY = lastMeasured / width;
-        const u64 lbX = lastBMU % width, lbY = lastBMU / width;
-        if (lastMeasured == lastBMU) {   // first try: 8 neighbours, wrap-then-clamp (Som.cpp:362-385)
-            u64 cx = lmX + fsx;
-            cx = cx < width - 1 ? cx : width - 1;
-            u64 cy = lmY + fsy;
-            cy = cy < height - 1 ? cy : height - 1;
-            u64 node = cy * width + cx;
-            float d = vsom_group_dist<CLR>(xa, xb, a.ma + (size_t)node * a.ldm,
-                                           a.mb + (size_t)node * a.ldm, a.L, k);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float di = __shfl(d, i * 8);
-                u64 ni = __shfl(node, i * 8);
-                if (di < minDist) {
-                    minDist = di;
-                    minIndex = ni;
-                }
-            }
-            if (minIndex == lastBMU)
-                break;
-            lastMeasured = minIndex;
-        } else {
-            if (lmX - lbX) {   // moving in X: 3 nodes ahead (Som.cpp:390-403)
-                u64 cx = lmX + lmX - lbX;
-                cx = cx < width - 1 ? cx : width - 1;
-                u64 off = (u64)(long long)((g < 3 ? g : 0) - 1);   // i = -1,0,1
-                u64 cy = lmY + off;
-                cy = cy < height - 1 ? cy : height - 1;
-                u64 node = cy * width + cx;
-                float d = vsom_group_dist<CLR>(xa, xb, a.ma + (size_t)node * a.ldm,
-                                               a.mb + (size_t)node * a.ldm, a.L, k);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    float di = __shfl(d, i * 8);
-                    u64 ni = __shfl(node, i * 8);
-                    if (di < minDist) {
-                        minDist = di;
-                        minIndex = ni;
-                    }
-                }
-            }
-            // moving in Y (Som.cpp:406-437): the reference's loop starts at SIZE_MAX and its
-            // condition `i < endX + 1` is false at once, so no node is evaluated.
-            (void)lbY;
-            if (minIndex == lastMeasured)
-                break;
-            lastBMU = lastMeasured;
-            lastMeasured = minIndex;
-        }
-    }
+    u64 minIndex;
+    float minDist;
+    vsom_local_walk<CLR>(a, xa, xb, width, height, lastbmu[s], lane, minIndex, minDist);
     if (lane == 0) {
         lastbmu[s] = minIndex;
         sqres[s] = minDist;   // == ||Comparer(x, M[minIndex])||^2 (same reduction order)

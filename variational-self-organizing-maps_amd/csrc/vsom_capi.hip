@@ -83,6 +83,9 @@ static int free_all(vsom_ctx *c)
             (void)hipFree(p);
     if (c->lut_host)
         (void)hipHostFree(c->lut_host);
+    for (int i = 0; i < 2; ++i)
+        if (c->lut_ev[i])
+            (void)hipEventDestroy(c->lut_ev[i]);
     if (c->v_pinned)
         (void)hipHostFree(c->v_pinned);
     if (c->sl_fb)
@@ -169,6 +172,8 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
         c->use_asm = !(e[0] == '1');   // debugging aid: HIP update kernel instead of the hand-scheduled one
     if (const char *e = std::getenv("VSOM_CW_MODE"))
         c->cw_mode = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);
+    if (const char *e = std::getenv("VSOM_NO_TINY"))
+        c->use_tiny = !(e[0] == '1');
     if (const char *e = std::getenv("VSOM_NO_CHAIN"))
         c->use_chain = !(e[0] == '1');  // debugging aid: lane = node update kernel on small maps too
 
@@ -698,6 +703,8 @@ int vsom_batch_epoch_async(vsom_ctx *c, double sigma, int is_first)
     CHECK_CTX(c);
     if (!c->chunk_loaded)   // an EMPTY chunk is legal: the reference's epoch then zeroes the map
         return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
+    if (vsom_tiny_applies(c))
+        return launch_tiny_epoch(c, sigma, is_first);   // tiny map: the whole epoch in one launch
     int rc = vsom_batch_phase1_async(c, 0, c->B, is_first);
     if (rc)
         return rc;

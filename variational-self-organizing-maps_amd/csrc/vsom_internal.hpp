@@ -81,7 +81,8 @@ struct vsom_ctx {
 
     // neighbourhood
     float2 *cw = nullptr; size_t cw_cap = 0;
-    float *lut = nullptr; size_t lut_cap = 0; float *lut_host = nullptr;
+    float *lut = nullptr; size_t lut_cap = 0; float *lut_host = nullptr;   // lut_host: 2 x lut_cap, pinned
+    hipEvent_t lut_ev[2] = {nullptr, nullptr}; bool lut_ev_valid[2] = {false, false}; int lut_slot = 0;
     double lut_sigma = -1.0; uint32_t lut_w = 0, lut_h = 0;
     double *lutd = nullptr; size_t lutd_cap = 0; double lutd_sigma = -1.0;   // online path (double)
 
@@ -91,6 +92,7 @@ struct vsom_ctx {
     int update_mode = VSOM_UPDATE_STRICT;
     bool use_asm = true;
     bool use_chain = true;
+    bool use_tiny = true;           // one-launch epoch for tiny maps (VSOM_NO_TINY=1 disables, debugging)
     int cw_mode = 0;                // 0 role-split kernel, 1 quad kernel, 2 16-lane kernel (VSOM_CW_MODE, debugging)
 
     // online path scratch
@@ -139,3 +141,5 @@ int launch_raw_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *vrows_dev, siz
                     float *out_dev);
 int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1);
 int ensure_lut(vsom_ctx *c, double sigma);
+bool vsom_tiny_applies(const vsom_ctx *c);                        // vsom_tiny.hip
+int launch_tiny_epoch(vsom_ctx *c, double sigma, int is_first);   // whole batch epoch, one workgroup

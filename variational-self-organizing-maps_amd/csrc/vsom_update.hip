@@ -718,6 +718,7 @@ int ensure_lut(vsom_ctx *c, double sigma)
     uint32_t lh = ymax + 1, lw = c->W;
     size_t need = (size_t)lh * lw;
     if (need > c->lut_cap) {
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
         if (c->lut)
             VSOM_HIP_CHECK(hipFree(c->lut));
         if (c->lut_host)
@@ -725,17 +726,25 @@ int ensure_lut(vsom_ctx *c, double sigma)
         c->lut = nullptr;
         c->lut_host = nullptr;
         VSOM_HIP_CHECK(hipMalloc(&c->lut, need * sizeof(float)));
-        VSOM_HIP_CHECK(hipHostMalloc(&c->lut_host, need * sizeof(float)));
+        VSOM_HIP_CHECK(hipHostMalloc(&c->lut_host, 2 * need * sizeof(float)));   // two halves used alternately
         c->lut_cap = need;
-    } else {
-        // the previous async copy may still read lut_host
-        VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        c->lut_ev_valid[0] = c->lut_ev_valid[1] = false;
     }
+    // the table changes with every epoch's sigma: stage it through the half of the pinned buffer whose
+    // previous copy (two tables ago) has certainly left it -- no stream synchronisation on this path
+    const int k = c->lut_slot;
+    c->lut_slot ^= 1;
+    if (!c->lut_ev[k])
+        VSOM_HIP_CHECK(hipEventCreateWithFlags(&c->lut_ev[k], hipEventDisableTiming));
+    if (c->lut_ev_valid[k])
+        VSOM_HIP_CHECK(hipEventSynchronize(c->lut_ev[k]));
+    float *host = c->lut_host + (size_t)k * c->lut_cap;
     for (uint32_t dy = 0; dy < lh; ++dy)
         for (uint32_t dx = 0; dx < lw; ++dx)
-            c->lut_host[(size_t)dy * lw + dx] = (float)vsom_neighbourhood_weight(dx, dy, 0, 0, sigma);
-    VSOM_HIP_CHECK(hipMemcpyAsync(c->lut, c->lut_host, need * sizeof(float), hipMemcpyHostToDevice,
-                                  c->stream));
+            host[(size_t)dy * lw + dx] = (float)vsom_neighbourhood_weight(dx, dy, 0, 0, sigma);
+    VSOM_HIP_CHECK(hipMemcpyAsync(c->lut, host, need * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    VSOM_HIP_CHECK(hipEventRecord(c->lut_ev[k], c->stream));
+    c->lut_ev_valid[k] = true;
     c->lut_sigma = sigma;
     c->lut_w = lw;
     c->lut_h = lh;

@@ -65,6 +65,35 @@ static int perf()
     return 0;
 }
 
+// `host_api_test perf_tiny`: the reference's perf-harness scenario shape (perf_tests.cpp:74-112): 10x10 map,
+// 20 nine-dimensional rows, 300 epochs, sigma0 10 / decay 0.01, eta0 0.001 / decay 0.01
+static int perf_tiny()
+{
+    const size_t W = 10, H = 10, J = 9, NROWS = 20;
+    auto rows = make_rows(NROWS, J, 99u);
+    std::cout.setstate(std::ios_base::failbit);
+    for (int mode = 0; mode < 2; ++mode) {
+        ArrayDataLoader loader(rows.data(), NROWS, J);
+        DataSet ds(loader);
+        Som som{W, H, J};
+        som.randomInitialize(1, 1);
+        const auto fn = mode == 0 ? Som::WeigthDecayFunction::BatchMap : Som::WeigthDecayFunction::Exponential;
+        som.train(ds, 5, 0.001, 0.01, 10.0, 0.01, fn);
+        som.randomInitialize(1, 1);
+        const auto t0 = std::chrono::steady_clock::now();
+        som.train(ds, 300, 0.001, 0.01, 10.0, 0.01, fn);
+        (void)som.getNeuron(size_t{0});
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const int epochs = mode == 0 ? 231 : 300;     // batch training stops when sigma < 1 (Som.cpp:729-730)
+        std::cout.clear();
+        std::printf("{\"host_cpp_tiny\": \"%s 10x10x9, 20 rows\", \"us_per_epoch\": %.1f}\n", mode == 0 ? "BatchMap" : "Exponential",
+                    dt / epochs * 1e6);
+        std::cout.setstate(std::ios_base::failbit);
+    }
+    std::cout.clear();
+    return 0;
+}
+
 // `host_api_test mnist <folder> <outdir>`: BASELINE configuration 2's plumbing at test size -- IDX files
 // -> MnistDataLoader (chunked) -> DataSet -> Som::train(BatchMap); the dump is compared with the oracle
 // run on the same rows and chunk boundaries (tests/test_gpu_host_cpp.py)
@@ -84,6 +113,8 @@ int main(int argc, char **argv)
 {
     if (argc > 1 && std::string(argv[1]) == "perf")
         return perf();
+    if (argc > 1 && std::string(argv[1]) == "perf_tiny")
+        return perf_tiny();
     if (argc > 3 && std::string(argv[1]) == "mnist")
         return mnist(argv[2], argv[3]);
     const std::string out = argc > 1 ? argv[1] : ".";
