@@ -19,6 +19,8 @@ struct TinyArgs {
     const float *lut;
     int lutw;
     int N, W, H, Dc, pitch, ppitch, B, is_first;   // Dc: chains per node (D, or P for CLR)
+    int stage_x;                                    // samples fit into LDS
+    int luth;                                       // table rows (the table is copied into LDS)
 };
 
 __device__ __forceinline__ float tiny_sign(float a)   // as vsom_update.hip's vsom_sign (see there)
@@ -95,6 +97,26 @@ __global__ __launch_bounds__(256) void tiny_batch_epoch_kernel(TinyArgs a)
 
     // ---- phase 2 (Som.cpp:809-876): one thread per chain, the old map is not read ------------------
     const int Dc = a.Dc;
+    // the samples (and y' for CLR) move into LDS when they fit: the chains below are serial in the
+    // samples, and an LDS read per step instead of an L2 round trip is most of this kernel's time
+    float *xl = reinterpret_cast<float *>(nan0 + B);
+    const float *xsrc = a.d.xa, *ysrc = a.d.xb;
+    int xld = a.d.ldx;
+    float *lutl = xl + (a.stage_x ? B * Dc * (CLR ? 2 : 1) : 0);
+    for (int i = tid; i < a.lutw * a.luth; i += 256)
+        lutl[i] = a.lut[i];
+    if (a.stage_x) {
+        for (int i = tid; i < B * Dc; i += 256) {
+            const int s = i / Dc, e = i - s * Dc;
+            xl[i] = a.d.xa[(size_t)s * a.d.ldx + e];
+            if (CLR)
+                xl[B * Dc + i] = a.d.xb[(size_t)s * a.d.ldx + e];
+        }
+        xsrc = xl;
+        ysrc = xl + B * Dc;
+        xld = Dc;
+    }
+    __syncthreads();   // table (and samples) in LDS
     for (int c = tid; c < N * Dc; c += 256) {
         const int node = c / Dc, e = c - node * Dc;
         int cx, cy;
@@ -106,11 +128,11 @@ __global__ __launch_bounds__(256) void tiny_batch_epoch_kernel(TinyArgs a)
             int dx = cx - b.x, dy = cy - b.y;
             dx = dx < 0 ? -dx : dx;
             dy = dy < 0 ? -dy : dy;
-            const float w = a.lut[dy * a.lutw + dx];          // (float)calculateNeighbourhoodWeight :851
+            const float w = lutl[dy * a.lutw + dx];           // (float)calculateNeighbourhoodWeight :851
             Wsum = Wsum + w;                                 // :857
             const float cc = w / Wsum;                       // :864 (0/0 -> NaN)
             if (CLR) {
-                const float xp = a.d.xa[(size_t)s * a.d.ldx + e], yp = a.d.xb[(size_t)s * a.d.ldx + e];
+                const float xp = xsrc[(size_t)s * xld + e], yp = ysrc[(size_t)s * xld + e];
                 float inner = M * xp;                        // Transformation.cpp:129
                 inner = inner + Bv;
                 inner = inner - yp;
@@ -126,7 +148,7 @@ __global__ __launch_bounds__(256) void tiny_batch_epoch_kernel(TinyArgs a)
                 S = S + uA;
                 SB = SB + uB;
             } else {
-                float dl = a.d.xa[(size_t)s * a.d.ldx + e] - M;   // Stepper (Transformation.cpp:12 / :50)
+                float dl = xsrc[(size_t)s * xld + e] - M;         // Stepper (Transformation.cpp:12 / :50)
                 if (KIND == VSOM_MEDIAN)
                     dl = tiny_sign(dl);
                 const float t = cc * dl;
@@ -187,7 +209,13 @@ int launch_tiny_epoch(vsom_ctx *c, double sigma, int is_first)
     a.ppitch = (int)c->part_pitch;
     a.B = (int)c->B;
     a.is_first = is_first;
-    const size_t smem = c->B * (sizeof(u64) + sizeof(int2) + sizeof(float) + sizeof(int));
+    size_t smem = c->B * (sizeof(u64) + sizeof(int2) + sizeof(float) + sizeof(int));
+    const size_t xfloats = c->B * (size_t)c->part_len * (clr ? 2 : 1);
+    a.stage_x = xfloats <= 10240 ? 1 : 0;            // 40 KB on top of the per-sample arrays (< 64 KB in all)
+    if (a.stage_x)
+        smem += xfloats * sizeof(float);
+    a.luth = (int)c->lut_h;
+    smem += (size_t)c->lut_w * c->lut_h * sizeof(float);    // N <= 4096 here: at most 16 KB
     TimerScope ts(c, VSOM_T_UPDATE);
     if (c->transform == VSOM_CLR)
         hipLaunchKernelGGL(tiny_batch_epoch_kernel<VSOM_CLR>, dim3(1), dim3(256), smem, c->stream, a);
