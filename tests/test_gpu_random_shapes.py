@@ -2,6 +2,8 @@
 epochs (full search, then local search) and a short online chunk per case, every output compared
 bit for bit (NaN == NaN) with the oracle.  Small sigmas on wide maps make the float neighbourhood
 weight underflow, so rows with W = 0 -> c = 0/0 = NaN are part of the sweep."""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,15 +27,18 @@ def _cases(n, seed):
     out = []
     for i in range(n):
         tr = [po.STANDARD, po.MEDIAN, po.CLR][i % 3]
-        W, H = int(rs.randint(2, 40)), int(rs.randint(2, 40))
-        J = int(rs.randint(2, 9)) if tr == po.CLR else int(rs.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 33, 64, 100]))
-        B = int(rs.choice([1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 200, 257]))
+        wide = os.environ.get("VSOM_SWEEP_WIDE") == "1"
+        W, H = int(rs.randint(2, 72 if wide else 40)), int(rs.randint(2, 72 if wide else 40))
+        J = int(rs.randint(2, 12 if wide else 9)) if tr == po.CLR else int(rs.choice(
+            [1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 33, 64, 100] + ([65, 128, 200] if wide else [])))
+        B = int(rs.choice([1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 200, 257] + ([300, 511, 600] if wide else [])))
         sigma = float(rs.choice([1.5, 2.0, 3.7, 8.0, 20.0]))
         out.append((f"{i}_{['std', 'med', 'clr'][tr]}_{W}x{H}x{J}_B{B}_s{sigma}", tr, W, H, J, B, sigma, int(rs.randint(1, 1 << 30))))
     return out
 
 
-CASES = _cases(36, 20240611) + [
+# VSOM_SWEEP_N / VSOM_SWEEP_SEED widen the sweep for occasional long runs (default: 36 cases)
+CASES = _cases(int(os.environ.get("VSOM_SWEEP_N", "36")), int(os.environ.get("VSOM_SWEEP_SEED", "20240611"))) + [
     # shapes that reach the hand-scheduled kernels (enough wavefronts) with ragged chunks / dims
     ("asm_rd14_40x33x784_B65", po.STANDARD, 40, 33, 784, 65, 12.0, 11),
     ("asm_rd16_tail_37x35x794_B33", po.STANDARD, 37, 35, 794, 33, 9.0, 12),
