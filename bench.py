@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--nchunks", type=int, default=4, help="distinct resident chunks cycled over")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (gloo only to rehearse the N>1 flow on one GPU)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (RCCL refuses that, so combine with --backend gloo)")
     ap.add_argument("--host-chunks", choices=["off", "sync", "overlap"], default="off",
                     help="PCIe-inclusive variants (N=1, not the contract number): chunks start in pinned host "
                          "memory every step; 'sync' = vsom_upload_chunk, 'overlap' = prefetch of chunk i+1 "
@@ -114,10 +118,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     W = H = args.map
     D = args.dim
