@@ -1,0 +1,17 @@
+#!/bin/bash
+# End-to-end C++ path on an MNIST-sized IDX pair (synthetic pixels): loader + DataSet + pipelined training.
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+D=$(mktemp -d)
+python3 - "$D" <<'PY'
+import struct, sys, numpy as np
+d = sys.argv[1]
+rs = np.random.RandomState(3)
+n = 60000
+img = (rs.randint(1, 256, size=(n, 28, 28)) * (rs.rand(n, 28, 28) < 0.19)).astype(np.uint8)
+lab = rs.randint(0, 10, size=n).astype(np.uint8)
+open(d + "/train-images-idx3-ubyte", "wb").write(struct.pack(">IIII", 0x803, n, 28, 28) + img.tobytes())
+open(d + "/train-labels-idx1-ubyte", "wb").write(struct.pack(">II", 0x801, n) + lab.tobytes())
+PY
+$R/variational-self-organizing-maps_amd/host/host_api_test perf_mnist "$D"
+rm -rf "$D"

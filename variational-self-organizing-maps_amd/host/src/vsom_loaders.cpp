@@ -22,6 +22,7 @@
 #include <iostream>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 
 // ---------------------------------------------------------------------------------------------
 // MnistDataLoader
@@ -126,19 +127,37 @@ std::vector<RowData> MnistDataLoader::readRows(size_t skip, size_t limit) const
     ni = std::min(ni, icount > skip ? icount - skip : 0);
     nl = std::min(nl, lcount > skip ? lcount - skip : 0);
     const size_t nrows = std::min(ni, nl);   // std::transform over images, zipped with labels (:61-64)
-    out.reserve(nrows);
+    out.resize(nrows);
     const size_t depth = px + 10;
-    for (size_t r = 0; r < nrows; ++r) {
-        RowData row;
-        row.values = Eigen::VectorXf((Eigen::Index)depth);
-        const unsigned char *src = img.data() + 16 + (skip + r) * px;
-        for (size_t d = 0; d < px; ++d)
-            row.values[(Eigen::Index)d] = (float)src[d];          // raw 0..255, un-normalised (:73-75)
-        const unsigned label = lab[8 + skip + r];
-        for (size_t k = 0; k < 10; ++k)
-            row.values[(Eigen::Index)(px + k)] = (label == k) ? 1.0f : 0.0f;   // one-hot label (:66-71)
-        row.valid.assign(depth, 1);
-        out.push_back(std::move(row));
+    // rows are independent: a few host threads convert a chunk (4096 x 794 values plus two heap objects
+    // per row is several milliseconds on one core -- as long as the device step it has to hide behind)
+    auto convert = [&](size_t r0, size_t r1) {
+        for (size_t r = r0; r < r1; ++r) {
+            RowData &row = out[r];
+            row.values = Eigen::VectorXf((Eigen::Index)depth);
+            float *dst = row.values.data();
+            const unsigned char *src = img.data() + 16 + (skip + r) * px;
+            for (size_t d = 0; d < px; ++d)
+                dst[d] = (float)src[d];                               // raw 0..255, un-normalised (:73-75)
+            const unsigned label = lab[8 + skip + r];
+            for (size_t k = 0; k < 10; ++k)
+                dst[px + k] = (label == k) ? 1.0f : 0.0f;             // one-hot label (:66-71)
+            row.valid.assign(depth, 1);
+        }
+    };
+    const size_t nthreads = nrows >= 512 ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (nthreads <= 1) {
+        convert(0, nrows);
+    } else {
+        std::vector<std::thread> pool;
+        const size_t per = (nrows + nthreads - 1) / nthreads;
+        for (size_t t = 0; t < nthreads; ++t) {
+            const size_t r0 = t * per, r1 = std::min(nrows, r0 + per);
+            if (r0 < r1)
+                pool.emplace_back(convert, r0, r1);
+        }
+        for (auto &th : pool)
+            th.join();
     }
     return out;
 }

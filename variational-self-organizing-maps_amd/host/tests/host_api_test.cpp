@@ -94,6 +94,27 @@ static int perf_tiny()
     return 0;
 }
 
+// `host_api_test perf_mnist <folder>`: BASELINE configuration 3's data path end to end -- IDX files (60000 x 784,
+// written by the caller) -> MnistDataLoader(4096) -> DataSet -> Som::train(BatchMap) on a 128x128 map
+static int perf_mnist(const std::string &folder)
+{
+    MnistDataLoader loader(4096);
+    loader.open(folder.c_str());
+    DataSet ds(loader);
+    Som som{128, 128, ds, Transformation::Standard(loader.getNames())};
+    som.randomInitialize(42, 1);
+    std::cout.setstate(std::ios_base::failbit);
+    som.train(ds, 1, 0.0, 0.0, 40.0, 0.05, Som::WeigthDecayFunction::BatchMap);
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t epochs = 2;
+    som.train(ds, epochs, 0.0, 0.0, 40.0, 0.05, Som::WeigthDecayFunction::BatchMap);
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout.clear();
+    std::printf("{\"host_cpp_mnist\": \"128x128x794, 60000 rows via MnistDataLoader(4096), %zu epochs\", \"s_per_epoch\": %.4f, "
+                "\"samples_per_s\": %.0f}\n", epochs, dt / epochs, 60000.0 * epochs / dt);
+    return 0;
+}
+
 // `host_api_test mnist <folder> <outdir>`: BASELINE configuration 2's plumbing at test size -- IDX files
 // -> MnistDataLoader (chunked) -> DataSet -> Som::train(BatchMap); the dump is compared with the oracle
 // run on the same rows and chunk boundaries (tests/test_gpu_host_cpp.py)
@@ -115,6 +136,8 @@ int main(int argc, char **argv)
         return perf();
     if (argc > 1 && std::string(argv[1]) == "perf_tiny")
         return perf_tiny();
+    if (argc > 2 && std::string(argv[1]) == "perf_mnist")
+        return perf_mnist(argv[2]);
     if (argc > 3 && std::string(argv[1]) == "mnist")
         return mnist(argv[2], argv[3]);
     const std::string out = argc > 1 ? argv[1] : ".";
