@@ -14,9 +14,18 @@ def blobs(n, dim, n_blobs, seed_centres, seed_samples, sigma=0.1):
 
 def mnist_like(n, seed=3, dim=784):
     """C2/C3 style: uint8-valued floats 0..255, ~19 % non-zero pixels inside a central
-    20x20 window of a 28x28 image (un-normalised, as MnistDataLoader.cpp:73-75 yields)."""
+    20x20 window of a 28x28 image (un-normalised, as MnistDataLoader.cpp:73-75 yields).
+    dim = side^2 + 10 appends the loader's one-hot label columns."""
     rs = np.random.RandomState(seed)
     side = int(round(np.sqrt(dim)))
+    lside = int(round(np.sqrt(max(dim - 10, 0))))
+    if side * side != dim and lside * lside == dim - 10 and dim > 10:
+        # what MnistDataLoader really hands over: the image followed by the one-hot label
+        # (MnistDataLoader.cpp:73-82, depth 784 + 10)
+        img = mnist_like(n, seed, dim - 10)
+        onehot = np.zeros((n, 10), np.float32)
+        onehot[np.arange(n), rs.randint(0, 10, size=n)] = 1.0
+        return np.concatenate([img, onehot], axis=1)
     if side * side != dim:
         x = rs.randint(0, 256, size=(n, dim)) * (rs.rand(n, dim) < 0.19)
         return x.astype(np.float32)

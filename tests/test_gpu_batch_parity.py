@@ -164,6 +164,40 @@ def test_weight_underflow_nan_propagation():
     ctx.close()
 
 
+@pytest.mark.parametrize("tr,J", [(po.STANDARD, 75), (po.STANDARD, 122), (po.MEDIAN, 75), (po.CLR, 6)],
+                         ids=["std_rd16_pad", "std_rd14_pad", "median", "clr_rp8_pad"])
+def test_ragged_last_slice_keeps_row_padding_zero(tr, J):
+    """The assembly update kernels run their last slice over the zero padding of the rows.  With
+    0/0 weights (Q7) that padding would turn NaN; it must be zero again when a fresh map is set
+    over the NaN one and searched by the MFMA shortlist, which reads rows to the padded length."""
+    W = H = 40
+    B = 48
+    X = gen.blobs(B, J, 2, 31, 32, sigma=0.05)
+    orc = po.OracleSom(W, H, J, tr)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    init = gen.random_map(W * H, orc.depth, seed=9)
+    orc.set_state(map=init)
+    ctx.set_state(map=init)
+    lb = np.zeros(B, np.uint64)
+    orc.batch_epoch(X, lb, 1.05, True)
+    ctx.upload_chunk(X)
+    ctx.batch_epoch(1.05, True)
+    assert np.isnan(orc.map).any(), "test input should produce NaN rows"
+    _check_state(ctx, orc, "ragged underflow")
+    fresh = gen.random_map(W * H, orc.depth, seed=10)
+    orc.set_state(map=fresh)
+    ctx.set_state(map=fresh)
+    ctx.set_bmu_mode(vsom_amd.capi.BMU_SHORTLIST)
+    lb2 = np.zeros(B, np.uint64)
+    mse_o = orc.batch_epoch(X, lb2, 6.0, True)
+    ctx.upload_chunk(X)
+    mse_g = ctx.batch_epoch(6.0, True)
+    _same(ctx.get_last_bmu(), lb2, "lastBMU after a fresh map over NaN rows")
+    _same(np.float32(mse_g), np.float32(mse_o), "mse")
+    _check_state(ctx, orc, "fresh map")
+    ctx.close()
+
+
 def test_sharded_phases_equal_whole_epoch():
     """phase1 over sample shards + finish + phase2 over node shards == one whole epoch."""
     W, H, J, B = 12, 12, 20, 150

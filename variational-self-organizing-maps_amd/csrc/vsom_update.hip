@@ -641,8 +641,12 @@ __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict
 
 // sigmaMap[i] = sqrt(S / W)  (Som.cpp:873) for the columns the assembly kernels left as raw S.
 // One workgroup per node row, 8-byte accesses (ncols is even: 14/16 dims or 8 pairs per slice).
-__global__ __launch_bounds__(256) void sigma_finalize_kernel(float *__restrict__ sigma, int pitch, int col0, int ncols,
-                                                             int n0, int nloc, const float *__restrict__ weight)
+// When the last slice ran over the end of the part (ncols > nvalid: it read the zero padding of the
+// sample rows) its padding columns of mean and sigma^2 are put back to zero -- the MFMA search
+// reads model rows to the padded length and the padding could hold NaN (0/0 weights).
+__global__ __launch_bounds__(256) void sigma_finalize_kernel(float *__restrict__ sigma, float *__restrict__ map, int pitch,
+                                                             int col0, int ncols, int nvalid, int n0, int nloc,
+                                                             const float *__restrict__ weight)
 {
     const int nl = blockIdx.x;
     if (nl >= nloc)
@@ -650,10 +654,21 @@ __global__ __launch_bounds__(256) void sigma_finalize_kernel(float *__restrict__
     const size_t node = (size_t)n0 + nl;
     const float Wf = weight[node];
     float2 *p = reinterpret_cast<float2 *>(sigma + node * pitch + col0);
+    float2 *pm = reinterpret_cast<float2 *>(map + node * pitch + col0);
     for (int i = threadIdx.x; i < (ncols >> 1); i += 256) {
         float2 v = p[i];
         v.x = sqrtf(v.x / Wf);
         v.y = sqrtf(v.y / Wf);
+        if (2 * i + 1 >= nvalid) {             // padding columns (at most one slice wide)
+            float2 m = pm[i];
+            if (2 * i >= nvalid) {
+                v.x = 0.f;
+                m.x = 0.f;
+            }
+            v.y = 0.f;
+            m.y = 0.f;
+            pm[i] = m;
+        }
         p[i] = v;
     }
 }
@@ -663,6 +678,52 @@ __global__ __launch_bounds__(256) void sigma_finalize_kernel(float *__restrict__
 static const unsigned char vsom_update_hsaco[] = {
 #include "vsom_update_hsaco.inc"
 };
+
+// Column split of the Standard assembly update: n16 slices of 16 dims followed by n14 slices of 14,
+// covering D (rounded up to even: one padding column) exactly when 16*n16 + 14*n14 has a solution --
+// every even count >= 84 has one -- choosing the fewest idle wavefront slots (workgroups carry 4 slices)
+// and then the most 14-wide slices (the faster kernel: 784 = 56 * 14 tiles the chip with no tail).
+// Otherwise one kernel whose ragged last slice runs into the padding (limit = usable row pitch).
+// VSOM_UPD_SPLIT="n16,n14" overrides (development).
+static void vsom_update_split(unsigned D, unsigned limit, unsigned &n16, unsigned &n14)
+{
+    static int env16 = -2, env14 = -2;
+    if (env16 == -2) {
+        env16 = env14 = -1;
+        if (const char *e = getenv("VSOM_UPD_SPLIT"))
+            if (sscanf(e, "%d,%d", &env16, &env14) != 2)
+                env16 = env14 = -1;
+    }
+    if (env16 >= 0 && env14 >= 0 && (unsigned)(16 * env16 + 14 * env14) >= D &&
+        (unsigned)(16 * env16 + 14 * env14) <= limit) {
+        n16 = (unsigned)env16;
+        n14 = (unsigned)env14;
+        return;
+    }
+    const unsigned De = (D + 1) & ~1u;
+    int best = -1;
+    for (unsigned b = 0; 16 * b <= De; ++b) {
+        const unsigned rem = De - 16 * b;
+        if (rem % 14)
+            continue;
+        const unsigned a = rem / 14;
+        const int idle = (int)((4 - a % 4) % 4 + (4 - b % 4) % 4);
+        const int score = 1000000 - idle * 10000 + (int)a;      // fewest idle slots, then most 14-wide slices
+        if (score > best) {
+            best = score;
+            n16 = b;
+            n14 = a;
+        }
+    }
+    if (best >= 0 && De <= limit)
+        return;
+    const unsigned s14 = (D + 13) / 14, s16 = (D + 15) / 16;
+    n16 = n14 = 0;
+    if (s14 * 14 <= limit && s14 * 14 <= s16 * 16)
+        n14 = s14;
+    else if (s16 * 16 <= limit)
+        n16 = s16;
+}
 
 struct UpdAsmArgs {
     const void *xs;
@@ -867,8 +928,8 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 // hand-scheduled kernel for the full 8-pair slices (gen_update_asm.py, KC)
                 if ((rc = vsom_load_asm_module(c)))
                     return rc;
-                const unsigned nfull = c->part_len / RP;
-                if (nfull > 0) {
+                const unsigned nfull = (c->part_len + RP - 1) / RP;   // a ragged last slice runs over the padding
+                if (nfull * RP <= c->part_pitch) {
                     UpdAsmArgs a;
                     a.xs = c->XP;
                     a.cw2 = c->cw;
@@ -888,8 +949,8 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                                      HIP_LAUNCH_PARAM_END};
                     VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)c->upd_clr8, 8 * ((nfull + 3) / 4), (gx + 7) / 8, 1,
                                                          256, 1, 1, 0, c->stream, nullptr, extra));
-                    pbase = (int)(nfull * RP);
-                    sig_cols = pbase;
+                    pbase = (int)c->part_len;
+                    sig_cols = (int)(nfull * RP);
                 }
             }
             const int rest = (int)c->part_len - pbase;
@@ -919,23 +980,26 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
             constexpr int RD = 16;
             int dbase = 0;
             if (c->transform == VSOM_STANDARD && c->use_asm) {
-                // hand-scheduled kernel for the full slices; RD = 14 when it tiles D exactly
-                // (14 slices per SIMD on 128x128x784: no tail wave), else 16
+                // hand-scheduled kernels, 16 or 14 dims per wavefront: the first n16 slices by the
+                // 16-wide kernel, the following n14 by the 14-wide one on the side stream (the two run
+                // concurrently; vsom_update_split picks the pair).  Columns past D are the zero padding
+                // of the rows; sigma_finalize_kernel re-zeroes them afterwards.
                 if ((rc = vsom_load_asm_module(c)))
                     return rc;
-                const int rd = (c->D % 14 == 0) ? 14 : 16;
-                const unsigned nfull = c->D / rd;
-                if (nfull > 0) {
+                unsigned n16 = 0, n14 = 0;
+                vsom_update_split(c->D, c->pitch < c->xpitch ? c->pitch : c->xpitch, n16, n14);
+                const bool fma = c->update_mode == VSOM_UPDATE_FMA;
+                auto launch = [&](void *fn, unsigned nsl, unsigned col0, hipStream_t st) -> int {
                     UpdAsmArgs a;
-                    a.xs = c->Xs;
+                    a.xs = c->Xs + col0;
                     a.cw2 = c->cw;
-                    a.map = c->map;
-                    a.sbuf = c->sigma;
+                    a.map = c->map + col0;
+                    a.sbuf = c->sigma + col0;
                     a.ldx_bytes = c->xpitch * 4u;
                     a.ldn_bytes = (unsigned)(ldn * 16u);
                     a.B = (unsigned)c->B;
                     a.nloc = (unsigned)nloc;
-                    a.nslices = nfull;
+                    a.nslices = nsl;
                     a.pitch_bytes = c->pitch * 4u;
                     a.n0 = (unsigned)n0;
                     a.ppitch_bytes = 0;
@@ -944,13 +1008,29 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
                                      HIP_LAUNCH_PARAM_END};
                     // XCD-aware grid: x = 8 * slice quads, y = node groups / 8 (see gen_update_asm.py)
-                    const bool fma = c->update_mode == VSOM_UPDATE_FMA;
-                    void *fn = rd == 14 ? (fma ? c->upd_fma14 : c->upd_fn14) : (fma ? c->upd_fma16 : c->upd_fn16);
-                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn,
-                                                         8 * ((nfull + 3) / 4), (gx + 7) / 8, 1, 256, 1, 1, 0, c->stream,
-                                                         nullptr, extra));
-                    dbase = (int)(nfull * rd);
-                    sig_cols = dbase;
+                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, 8 * ((nsl + 3) / 4), (gx + 7) / 8, 1, 256, 1,
+                                                         1, 0, st, nullptr, extra));
+                    return VSOM_OK;
+                };
+                if (n16 + n14 > 0) {
+                    const bool both = n16 > 0 && n14 > 0;
+                    if (both) {   // fork: the 14-wide part beside the 16-wide one
+                        VSOM_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
+                        VSOM_HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+                    }
+                    if (n16 > 0 && (rc = launch(fma ? c->upd_fma16 : c->upd_fn16, n16, 0, c->stream)))
+                        return rc;
+                    if (n14 > 0 &&
+                        (rc = launch(fma ? c->upd_fma14 : c->upd_fn14, n14, n16 * 16, both ? c->aux_stream : c->stream)))
+                        return rc;
+                    if (both) {
+                        VSOM_HIP_CHECK(hipEventRecord(c->ev_join, c->aux_stream));
+                        c->aux_pending = true;
+                        if ((rc = vsom_join_aux(c)))
+                            return rc;
+                    }
+                    dbase = (int)c->D;
+                    sig_cols = (int)(n16 * 16 + n14 * 14);
                 }
             }
             const int rest = (int)c->D - dbase;
@@ -974,8 +1054,8 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         // the assembly kernels left raw S in those columns (CLR: in the A part and in the B part)
         for (uint32_t part = 0; part < c->nparts; ++part)
             hipLaunchKernelGGL(sigma_finalize_kernel, dim3((unsigned)nloc), dim3(256), 0, c->stream,
-                               c->sigma, (int)c->pitch, (int)(part * c->part_pitch), sig_cols, (int)n0, (int)nloc,
-                               c->weight);
+                               c->sigma, c->map, (int)c->pitch, (int)(part * c->part_pitch), sig_cols,
+                               (int)c->part_len, (int)n0, (int)nloc, c->weight);
         VSOM_HIP_CHECK(hipGetLastError());
     }
     return vsom_join_aux(c);   // the MSE sum forked by launch_finish ran beside the kernels above
