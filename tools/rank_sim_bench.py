@@ -25,7 +25,7 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     ctx.set_state(map=init)
     ctx.upload_chunk(X)
     n1 = W * W // world
-    steps = 5
+    steps = int(os.environ.get("VSOM_SIM_STEPS", "5"))
 
     def step():
         ctx.batch_phase1_async(0, 4096, True)

@@ -370,15 +370,16 @@ static int ensure_chunk_capacity(vsom_ctx *c, size_t B)
     c->partial_cap = 0;
     c->Bcap = 0;
     size_t cap = (B + 63) / 64 * 64;
-    // the assembly update kernel prefetches up to 2 sample rows past the chunk
-    VSOM_HIP_CHECK(hipMalloc(&c->Xs, (cap + 8) * c->xpitch * 4));
-    VSOM_HIP_CHECK(hipMemset(c->Xs, 0, (cap + 8) * c->xpitch * 4));
+    // the assembly update kernel reads up to 2 sample rows past the chunk and touches rows up to
+    // PF_ROWS + 3 past it (gen_update_asm.py, load_cw)
+    VSOM_HIP_CHECK(hipMalloc(&c->Xs, (cap + VSOM_ROW_PAD) * c->xpitch * 4));
+    VSOM_HIP_CHECK(hipMemset(c->Xs, 0, (cap + VSOM_ROW_PAD) * c->xpitch * 4));
     if (c->transform == VSOM_CLR) {
         // like Xs: the pipelined update kernels read one sample pair past the chunk
-        VSOM_HIP_CHECK(hipMalloc(&c->XP, (cap + 8) * c->part_pitch * 4));
-        VSOM_HIP_CHECK(hipMalloc(&c->YP, (cap + 8) * c->part_pitch * 4));
-        VSOM_HIP_CHECK(hipMemset(c->XP, 0, (cap + 8) * c->part_pitch * 4));
-        VSOM_HIP_CHECK(hipMemset(c->YP, 0, (cap + 8) * c->part_pitch * 4));
+        VSOM_HIP_CHECK(hipMalloc(&c->XP, (cap + VSOM_ROW_PAD) * c->part_pitch * 4));
+        VSOM_HIP_CHECK(hipMalloc(&c->YP, (cap + VSOM_ROW_PAD) * c->part_pitch * 4));
+        VSOM_HIP_CHECK(hipMemset(c->XP, 0, (cap + VSOM_ROW_PAD) * c->part_pitch * 4));
+        VSOM_HIP_CHECK(hipMemset(c->YP, 0, (cap + VSOM_ROW_PAD) * c->part_pitch * 4));
     }
     VSOM_HIP_CHECK(hipMalloc(&c->lastbmu, cap * 8));
     VSOM_HIP_CHECK(hipMalloc(&c->sqres, cap * 4));

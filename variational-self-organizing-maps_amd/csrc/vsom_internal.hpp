@@ -28,6 +28,9 @@ typedef unsigned long long u64;
 
 #define VSOM_TK 32          // K-chunk of the tile kernels; row pitches are multiples of it
 
+// spare (zeroed) rows behind the staged sample matrices: the pipelined update kernels read ahead
+constexpr size_t VSOM_ROW_PAD = 32;
+
 struct vsom_ctx {
     int device = 0;
     uint32_t W = 0, H = 0, J = 0, D = 0, N = 0;
