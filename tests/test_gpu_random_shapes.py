@@ -89,3 +89,56 @@ def test_random_shape(name, tr, W, H, J, B, sigma, seed):
         for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("S", orc.S), ("weight", orc.weight), ("hits", orc.hits)):
             assert _same(st[k], ref), (name, sg, "online " + k)
     ctx.close()
+
+
+def _asm_cases(n, seed):
+    """Standard-transformation shapes large enough for the hand-scheduled update kernels, with random
+    depths (even, odd, multiples of 14/16 and not: every column plan and the padded last slice), random
+    chunk lengths (all residues mod 8: the ring tail) and sharded second phases."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        W, H = int(rs.randint(34, 90)), int(rs.randint(34, 90))
+        J = int(rs.choice([rs.randint(17, 130), rs.randint(130, 900)]))
+        B = int(rs.choice([rs.randint(1, 40), rs.randint(40, 300)]))
+        sigma = float(rs.choice([2.0, 6.0, 15.0, 40.0]))
+        out.append((f"asm{i}_{W}x{H}x{J}_B{B}_s{sigma}", W, H, J, B, sigma, int(rs.randint(1, 1 << 30))))
+    return out
+
+
+# VSOM_ASM_SWEEP_N widens this one for occasional long runs (default: 8 cases)
+ASM_CASES = _asm_cases(int(os.environ.get("VSOM_ASM_SWEEP_N", "8")), int(os.environ.get("VSOM_SWEEP_SEED", "20240611")))
+
+
+@pytest.mark.parametrize("name,W,H,J,B,sigma,seed", ASM_CASES, ids=[c[0] for c in ASM_CASES])
+def test_random_shape_assembly_update(name, W, H, J, B, sigma, seed):
+    rs = np.random.RandomState(seed)
+    X = (rs.randn(B, J) * rs.choice([0.1, 1.0, 50.0])).astype(np.float32)
+    X[rs.rand(B, J) < 0.1] = 0.0
+    init = gen.random_map(W * H, J, seed=seed % 1000)
+    ctx = vsom_amd.Context(W, H, J, po.STANDARD)
+    orc = po.OracleSom(W, H, J, po.STANDARD)
+    ctx.set_state(map=init)
+    orc.set_state(map=init)
+    lb = np.zeros(B, np.uint64)
+    mse_o = orc.batch_epoch(X, lb, sigma, True)
+    ctx.upload_chunk(X)
+    mse_g = ctx.batch_epoch(sigma, True)
+    assert _same(ctx.get_last_bmu(), lb), (name, "lastBMU")
+    assert _same(np.float32(mse_g), np.float32(mse_o)), (name, "mse")
+    st = ctx.get_state()
+    for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("weight", orc.weight), ("hits", orc.hits)):
+        assert _same(st[k], ref), (name, k)
+    # the same epoch again as a search + two node shards of the second phase (the multi-GPU entry points)
+    ctx.set_state(map=init, hits=np.zeros(W * H, np.uint64))
+    ctx.upload_chunk(X)
+    ctx.batch_phase1_async(0, B, True)
+    ctx.batch_finish_async()
+    cut = int(rs.randint(1, W * H))
+    ctx.batch_phase2_async(sigma, cut, W * H)
+    ctx.batch_phase2_async(sigma, 0, cut)
+    ctx.synchronize()
+    st = ctx.get_state()
+    for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("weight", orc.weight), ("hits", orc.hits)):
+        assert _same(st[k], ref), (name, "sharded " + k)
+    ctx.close()

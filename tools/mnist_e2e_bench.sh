@@ -8,7 +8,9 @@ import struct, sys, numpy as np
 d = sys.argv[1]
 rs = np.random.RandomState(3)
 n = 60000
-img = (rs.randint(1, 256, size=(n, 28, 28)) * (rs.rand(n, 28, 28) < 0.19)).astype(np.uint8)
+# like tests/gen.py mnist_like: ~19 % non-zero pixels, all inside the central 20x20 window
+img = np.zeros((n, 28, 28), np.uint8)
+img[:, 4:24, 4:24] = (rs.randint(1, 256, size=(n, 20, 20)) * (rs.rand(n, 20, 20) < 0.19 * 784 / 400)).astype(np.uint8)
 lab = rs.randint(0, 10, size=n).astype(np.uint8)
 open(d + "/train-images-idx3-ubyte", "wb").write(struct.pack(">IIII", 0x803, n, 28, 28) + img.tobytes())
 open(d + "/train-labels-idx1-ubyte", "wb").write(struct.pack(">II", 0x801, n) + lab.tobytes())
