@@ -196,7 +196,7 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
         if (hipMalloc(&c->map, nd * 4) != hipSuccess || hipMalloc(&c->sigma, nd * 4) != hipSuccess ||
             hipMalloc(&c->S, nd * 4) != hipSuccess || hipMalloc(&c->weight, (size_t)c->N * 4) != hipSuccess ||
             hipMalloc(&c->hits, (size_t)c->N * 8) != hipSuccess || hipMalloc(&c->mse, 16) != hipSuccess ||
-            hipMalloc(&c->onl_state, 64) != hipSuccess || hipMalloc(&c->onl_f, 64) != hipSuccess) {
+            hipMalloc(&c->onl_state, VSOM_ONL_STATE_BYTES) != hipSuccess || hipMalloc(&c->onl_f, 64) != hipSuccess) {
             rc = vsom_fail(VSOM_ERR_NOMEM, "hipMalloc of model state failed");
             break;
         }

@@ -76,6 +76,75 @@ __device__ __forceinline__ float vsom_group_dist(const float *xa, const float *x
 }
 
 
+// The same distance for callers that wait on it alone (the online path's local search and post step:
+// one wavefront, nothing else to hide the memory latency).  vsom_group_dist's unrolled loop leaves a
+// rolled remainder loop with one load in flight -- a whole round trip per element for short rows
+// (D = 32: 4 trips) and for the last < 14 elements of long ones; here the remainder is fetched in
+// blocks of up to 16 / 4 elements before the first is used.  Same operations in the same order per
+// accumulator class as vsom_group_dist, hence the same bits.
+template <bool CLR, int BLK>
+__device__ __forceinline__ float vsom_group_acc_block(float acc, const float *xa, const float *xb, const float *ma,
+                                                      const float *mb, int k, int base, int nb)
+{
+    float xv[BLK], yv[BLK], mv[BLK], bv[BLK];
+#pragma unroll
+    for (int u = 0; u < BLK; ++u) {
+        const int d = k + 8 * (base + (u < nb ? u : nb - 1));   // clamped: always a valid element
+        xv[u] = xa[d];
+        mv[u] = ma[d];
+        yv[u] = CLR ? xb[d] : 0.f;
+        bv[u] = CLR ? mb[d] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < BLK; ++u) {
+        if (u < nb) {                                            // wavefront-uniform
+            const float r = vsom_resid<CLR>(xv[u], yv[u], mv[u], bv[u]);
+            const float p = r * r;
+            acc = acc + p;
+        }
+    }
+    return acc;
+}
+
+template <bool CLR>
+__device__ __forceinline__ float vsom_group_dist_lat(const float *xa, const float *xb,
+                                                     const float *ma, const float *mb, int L, int k)
+{
+    const int L8 = L & ~7;
+    const int ni = L8 >> 3;                      // elements per class
+    float acc = 0.f;
+    for (int base = 0; base < ni;) {
+        const int left = ni - base;
+        if (left > 16) {          // long rows: 14 at a time, like vsom_group_dist (49 at a time measured slower)
+            acc = vsom_group_acc_block<CLR, 14>(acc, xa, xb, ma, mb, k, base, 14);
+            base += 14;
+        } else if (left > 4) {
+            acc = vsom_group_acc_block<CLR, 16>(acc, xa, xb, ma, mb, k, base, left);
+            base += left;
+        } else {
+            acc = vsom_group_acc_block<CLR, 4>(acc, xa, xb, ma, mb, k, base, left);
+            base += left;
+        }
+    }
+    float q = acc + __shfl_xor(acc, 4);
+    const int rem = L - L8;
+    if (rem >= 4) {
+        int d = L8 + (k & 3);
+        float r = vsom_resid<CLR>(xa[d], CLR ? xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
+        float p = r * r;
+        q = q + p;
+    }
+    float t = q + __shfl_xor(q, 2);
+    float res = t + __shfl_xor(t, 1);
+    for (int tt = (rem >= 4 ? 4 : 0); tt < rem; ++tt) {
+        int d = L8 + tt;
+        float r = vsom_resid<CLR>(xa[d], CLR ? xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
+        float p = r * r;
+        res = res + p;
+    }
+    return res;
+}
+
 // Som::findLocalBmu (Som.cpp:335-454) for one sample by one wavefront: 8 candidates x 8 accumulator
 // classes across the 64 lanes, unsigned (size_t) arithmetic kept literal.  Every lane
 // returns the same (minIndex, minDist); minDist == ||Comparer(x, M[minIndex])||^2.

@@ -30,6 +30,8 @@ typedef unsigned long long u64;
 
 // spare (zeroed) rows behind the staged sample matrices: the pipelined update kernels read ahead
 constexpr size_t VSOM_ROW_PAD = 32;
+// bytes of vsom_ctx::onl_state (layout: vsom_online.hip)
+constexpr size_t VSOM_ONL_STATE_BYTES = 4352;
 
 struct vsom_ctx {
     int device = 0;
@@ -102,7 +104,7 @@ struct vsom_ctx {
     float *v_dev = nullptr;         // one sample, padded
     float *v_pinned = nullptr;      // its pinned host staging (+ 16 floats for results)
     float *res_dev = nullptr;       // residual
-    u64 *onl_state = nullptr;       // [4]: bmu, lastbmu, ...
+    u64 *onl_state = nullptr;       // argmin key slots + flags of the online scan (vsom_online.hip)
     float *onl_f = nullptr;         // [4]: dist, mse
 
     // timing

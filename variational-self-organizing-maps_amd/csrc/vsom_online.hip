@@ -20,8 +20,18 @@
 #include <algorithm>
 #include <cstring>
 
-// onl_state: [0],[1] argmin key of even / odd samples, [2],[3] their node-0-NaN flags ;
+// onl_state (u64): the argmin key of a sample lives in ONL_SLOTS slots, one 128-byte line each (slot s
+// of parity p at [(p * ONL_SLOTS + s) * 16]); a workgroup of the scan folds its minimum into slot
+// blockIdx % ONL_SLOTS and the reader takes the minimum over the slots.  With ONE slot the 512
+// same-address device-scope atomics of a 128x128 scan serialise and cost 4.5 of its 13.5 us
+// (tools/exp/scan_bw_bench.hip: 8.9 us without the atomic, 13.5 with one slot, 9.1-9.4 with 8-64).
+// The node-0-NaN flags of the two parities sit at [ONL_FLAG], [ONL_FLAG + 1].
 // onl_f: [0] dist, [1] mse sum
+constexpr int ONL_SLOTS = 16;
+constexpr int ONL_FLAG = 2 * ONL_SLOTS * 16;
+constexpr size_t ONL_STATE_BYTES = (ONL_FLAG + 16) * sizeof(u64);
+static_assert(ONL_STATE_BYTES <= VSOM_ONL_STATE_BYTES, "vsom_create allocates VSOM_ONL_STATE_BYTES");
+__device__ __forceinline__ u64 *online_slot(u64 *state, int par, int s) { return state + (par * ONL_SLOTS + s) * 16; }
 struct OnlineArgs {
     DistArgs d;          // xa/xb point at the sample's row(s)
     u64 *state;
@@ -31,9 +41,16 @@ struct OnlineArgs {
 };
 
 // BMU of the sample from its scan results; a NaN distance at node 0 pins it to 0 (Som.cpp:293-299)
+// (whole wavefronts call this: the slots are read by 16 lanes and folded with shuffles)
 __device__ __forceinline__ u64 online_resolve(const u64 *state, int par)
 {
-    return state[2 + par] ? 0ull : (state[par] & 0xFFFFFFFFull);
+    u64 key = state[(par * ONL_SLOTS + ((int)threadIdx.x & (ONL_SLOTS - 1))) * 16];
+#pragma unroll
+    for (int off = ONL_SLOTS / 2; off >= 1; off >>= 1) {
+        const u64 o = __shfl_xor(key, off);
+        key = o < key ? o : key;
+    }
+    return state[ONL_FLAG + par] ? 0ull : (key & 0xFFFFFFFFull);
 }
 
 #ifndef VSOM_SCAN_UNR
@@ -50,7 +67,7 @@ __global__ __launch_bounds__(256) void online_scan_kernel(OnlineArgs a)
                                                   a.d.mb + (size_t)nc * a.d.ldm, a.d.L, k);
     u64 key = (node < a.N) ? vsom_key(d, (uint32_t)node) : ~0ull;
     if (node == 0 && k == 0)
-        a.state[2 + a.par] = (d != d) ? 1ull : 0ull;
+        a.state[ONL_FLAG + a.par] = (d != d) ? 1ull : 0ull;
     // wave min, then block min, then one atomic per block
     for (int off = 32; off >= 8; off >>= 1) {
         u64 o = __shfl_xor(key, off);
@@ -64,7 +81,7 @@ __global__ __launch_bounds__(256) void online_scan_kernel(OnlineArgs a)
         u64 m = skey[0];
         for (int i = 1; i < 4; ++i)
             m = skey[i] < m ? skey[i] : m;
-        atomicMin(&a.state[a.par], m);
+        atomicMin(online_slot(a.state, a.par, (int)(blockIdx.x % ONL_SLOTS)), m);
     }
 }
 
@@ -79,7 +96,7 @@ __device__ __forceinline__ u64 online_local_search(const OnlineArgs &a, const u6
     const u64 fsy = (g <= 2) ? 1ull : ((g == 3 || g == 7) ? 0ull : m1);
     const float *xa = a.d.xa, *xb = a.d.xb;
     u64 lastBMU = *lastbmu;
-    float minDist = vsom_group_dist<CLR>(xa, xb, a.d.ma + (size_t)lastBMU * a.d.ldm,
+    float minDist = vsom_group_dist_lat<CLR>(xa, xb, a.d.ma + (size_t)lastBMU * a.d.ldm,
                                          a.d.mb + (size_t)lastBMU * a.d.ldm, a.d.L, k);
     minDist = __shfl(minDist, 0);
     u64 minIndex = lastBMU, lastMeasured = lastBMU;
@@ -92,7 +109,7 @@ __device__ __forceinline__ u64 online_local_search(const OnlineArgs &a, const u6
             u64 cy = lmY + fsy;
             cy = cy < height - 1 ? cy : height - 1;
             u64 node = cy * width + cx;
-            float d = vsom_group_dist<CLR>(xa, xb, a.d.ma + (size_t)node * a.d.ldm,
+            float d = vsom_group_dist_lat<CLR>(xa, xb, a.d.ma + (size_t)node * a.d.ldm,
                                            a.d.mb + (size_t)node * a.d.ldm, a.d.L, k);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -114,7 +131,7 @@ __device__ __forceinline__ u64 online_local_search(const OnlineArgs &a, const u6
                 u64 cy = lmY + off;
                 cy = cy < height - 1 ? cy : height - 1;
                 u64 node = cy * width + cx;
-                float d = vsom_group_dist<CLR>(xa, xb, a.d.ma + (size_t)node * a.d.ldm,
+                float d = vsom_group_dist_lat<CLR>(xa, xb, a.d.ma + (size_t)node * a.d.ldm,
                                                a.d.mb + (size_t)node * a.d.ldm, a.d.L, k);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -241,7 +258,7 @@ __device__ __forceinline__ void online_post(const OnlineArgs &a, u64 bmu, int la
         for (int d = lane; d < a.d.L; d += 64)
             residual[d] = vsom_resid<CLR>(a.d.xa[d], CLR ? a.d.xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
     }
-    float dist = vsom_group_dist<CLR>(a.d.xa, a.d.xb, ma, mb, a.d.L, k);
+    float dist = vsom_group_dist_lat<CLR>(a.d.xa, a.d.xb, ma, mb, a.d.L, k);
     if (lane == 0) {
         a.fstate[0] = dist;
         float q = dist / fB;                 // residual.squaredNorm() / epochSize  (:1167)
@@ -281,8 +298,8 @@ __global__ __launch_bounds__(256) void online_window_kernel(
     __syncthreads();             // this workgroup's writes of the BMU row are visible to its wave 0
     if (threadIdx.x < 64) {
         online_post<CLR>(a, bmu, threadIdx.x, hits, lastbmu_out, residual, fB, add_hit);
-        if (threadIdx.x == 0)
-            a.state[a.par ^ 1] = ~0ull;   // arm the next sample's key (nobody reads it during this launch)
+        if (threadIdx.x < ONL_SLOTS)
+            *online_slot(a.state, a.par ^ 1, (int)threadIdx.x) = ~0ull;   // arm the next sample's key (nobody reads it during this launch)
     }
 }
 
@@ -326,10 +343,10 @@ __global__ __launch_bounds__(256) void online_small_kernel(
 
 __global__ void online_init_kernel(u64 *state, float *fstate, int keep_mse)
 {
-    state[0] = ~0ull;
-    state[1] = ~0ull;
-    state[2] = 0ull;
-    state[3] = 0ull;
+    for (int s = 0; s < 2 * ONL_SLOTS; ++s)
+        state[s * 16] = ~0ull;
+    state[ONL_FLAG] = 0ull;
+    state[ONL_FLAG + 1] = 0ull;
     fstate[0] = 0.f;
     if (!keep_mse)
         fstate[1] = 0.f;   // else: the epoch's running MSE continues across chunks (Som.cpp:1153,1167)
@@ -442,7 +459,8 @@ static int stage_single(vsom_ctx *c, const float *v_host)
         // device: [xs | xp | yp | residual(pp) | tail(16)]; tail = {u64 lastBMU/bmu, float dist, float mse}
         VSOM_HIP_CHECK(hipMalloc(&c->v_dev, (xs_n + 3 * pp + 16) * sizeof(float)));
         VSOM_HIP_CHECK(hipMalloc(&c->res_dev, 64));
-        VSOM_HIP_CHECK(hipHostMalloc(&c->v_pinned, (xs_n + 3 * pp + 32) * sizeof(float)));
+        // pinned: the same rows, 32 floats of tails, and an image of onl_state for vsom_find_bmu
+        VSOM_HIP_CHECK(hipHostMalloc(&c->v_pinned, (xs_n + 3 * pp + 32) * sizeof(float) + ONL_STATE_BYTES));
     } else {
         // the previous call's copy out of the pinned buffer has been waited for (every caller
         // synchronises the stream before returning)
@@ -497,22 +515,25 @@ int vsom_find_bmu(vsom_ctx *c, const float *v_host, uint64_t *bmu_out, float *di
     a.N = (int)c->N;
     a.W = (int)c->W;
     a.H = (int)c->H;
-    VSOM_HIP_CHECK(hipMemsetAsync(c->onl_state, 0xFF, 8, c->stream));   // arm the key of parity 0
+    VSOM_HIP_CHECK(hipMemsetAsync(c->onl_state, 0xFF, ONL_SLOTS * 16 * sizeof(u64), c->stream));   // arm the keys of parity 0
     dim3 grid((unsigned)(((size_t)c->N * 8 + 255) / 256));
     if (clr)
         hipLaunchKernelGGL(online_scan_kernel<true>, grid, dim3(256), 0, c->stream, a);
     else
         hipLaunchKernelGGL(online_scan_kernel<false>, grid, dim3(256), 0, c->stream, a);
     VSOM_HIP_CHECK(hipGetLastError());
-    u64 *st = reinterpret_cast<u64 *>(c->v_pinned + xs_n + 2 * pp);      // 16 spare floats behind the rows
-    VSOM_HIP_CHECK(hipMemcpyAsync(st, c->onl_state, 32, hipMemcpyDeviceToHost, c->stream));
+    u64 *st = reinterpret_cast<u64 *>(c->v_pinned + xs_n + 3 * pp + 32);   // image of onl_state (8-byte aligned: pitches are multiples of 32 floats)
+    VSOM_HIP_CHECK(hipMemcpyAsync(st, c->onl_state, ONL_STATE_BYTES, hipMemcpyDeviceToHost, c->stream));
     VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    const bool nan0 = st[2] != 0;     // a NaN distance at node 0 pins the BMU to 0 (Som.cpp:293-299)
-    const uint64_t bmu = nan0 ? 0ull : (st[0] & 0xFFFFFFFFull);
+    uint64_t key = ~0ull;             // minimum over the key slots of parity 0
+    for (int sl = 0; sl < ONL_SLOTS; ++sl)
+        key = std::min<uint64_t>(key, st[sl * 16]);
+    const bool nan0 = st[ONL_FLAG] != 0;     // a NaN distance at node 0 pins the BMU to 0 (Som.cpp:293-299)
+    const uint64_t bmu = nan0 ? 0ull : (key & 0xFFFFFFFFull);
     if (bmu_out)
         *bmu_out = bmu;
     if (dist_out) {
-        const uint32_t bits = nan0 ? 0x7FC00000u : (uint32_t)(st[0] >> 32);
+        const uint32_t bits = nan0 ? 0x7FC00000u : (uint32_t)(key >> 32);
         std::memcpy(dist_out, &bits, 4);
     }
     return VSOM_OK;
