@@ -13,7 +13,9 @@
 //                         The workgroup that owns the BMU node then does the post step: residual
 //                         + distance of the BMU after the update (:946), addBmu (:1189-1192), MSE
 //                         running sum (:1167), lastBMU (:895), re-arming the other parity's key.
-//   online_small_kernel   sigma <= 1: Som::findLocalBmu + <=6x6 window + post in one launch
+//   online_small_kernel   sigma <= 1: Som::findLocalBmu + <=6x6 window + post in one launch of one
+//                         1024-thread workgroup (16 wavefronts share the window's nodes: 15.0 vs 17.9 us
+//                         with 4; staging the walk's candidate rows through LDS was measured slower, 20 us)
 // The bandwidth roofline of one sample is 4*N*D (scan) + 20*k*D (k window nodes) bytes.
 #include "vsom_device.hpp"
 #include <cmath>
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256) void online_window_kernel(
 // the whole trainSingle step in ONE small launch -- wave 0 walks the local search, each wave then
 // updates window nodes round-robin, wave 0 finishes with the residual / bookkeeping.
 template <int KIND>
-__global__ __launch_bounds__(256) void online_small_kernel(
+__global__ __launch_bounds__(1024) void online_small_kernel(
     OnlineArgs a, const float *__restrict__ xs, const float *__restrict__ xp, const float *__restrict__ yp,
     const double *__restrict__ lutd, int lutw, int D, int P, int ppitch, int pitch, double eta, double sigma,
     int decay_fn, float *map, float *Smap, float *sigmap, float *weight, u64 *hits, u64 *lastbmu_io,
@@ -415,7 +417,7 @@ static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const f
     } else {
         // sigma <= 1: one fused launch (local search + <=6x6 window + post)
 #define LAUNCH_SMALL(KIND)                                                                                  \
-    hipLaunchKernelGGL(online_small_kernel<KIND>, dim3(1), dim3(256), 0, c->stream, a, xs, xp, yp, lutd, lutw, \
+    hipLaunchKernelGGL(online_small_kernel<KIND>, dim3(1), dim3(1024), 0, c->stream, a, xs, xp, yp, lutd, lutw, \
                        (int)c->D, (int)c->part_len, (int)c->part_pitch, (int)c->pitch, eta, sigma, decay_fn, \
                        c->map, c->S, c->sigma, c->weight, c->hits, lastbmu_dev, residual_dev, fB, add_hit)
         if (c->transform == VSOM_CLR)
