@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         s_best[wave] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&stats[1], cnt);
+        // statistics only, but 4096 same-address atomics per chunk queue up at the memory side: the
+        // count goes to one of 32 line-sized slots (scal[16 + 32 s]); sl_feedback_kernel adds them up
+        atomicAdd(&stats[12 + 32 * (blockIdx.x & 31)], cnt);
         u64 b = s_best[0];
         for (int i = 1; i < 4; ++i)
             b = s_best[i] < b ? s_best[i] : b;
@@ -363,13 +365,18 @@ __global__ void sl_reset_kernel(unsigned *scal)
 {
     if (threadIdx.x < 8)
         scal[threadIdx.x] = 0u;
+    if (threadIdx.x < 32)
+        scal[16 + 32 * threadIdx.x] = 0u;     // candidate-count slots
 }
 
 // copies {redo samples, candidates} of this call into the host-visible feedback words
 __global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsigned nrows)
 {
+    unsigned cand = 0;
+    for (int sl = 0; sl < 32; ++sl)
+        cand += scal[16 + 32 * sl];
     host_fb[0] = scal[4];
-    host_fb[1] = scal[5];
+    host_fb[1] = cand;
     host_fb[2] = nrows;
     __threadfence_system();
     host_fb[3] = host_fb[3] + 1u;
@@ -409,7 +416,7 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     }
     if (!c->sl_nrm) {
         VSOM_HIP_CHECK(hipMalloc(&c->sl_nrm, (size_t)c->N * sizeof(float)));
-        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 64));
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 8192));   // 16 words + 32 line-sized counter slots
         VSOM_HIP_CHECK(hipHostMalloc(&c->sl_fb, 64));
         std::memset(c->sl_fb, 0, 64);
     }
