@@ -153,8 +153,13 @@ __global__ __launch_bounds__(256) void tiny_batch_epoch_kernel(TinyArgs a)
                     dl = tiny_sign(dl);
                 const float t = cc * dl;
                 M = M + t;                                   // :864
-                float u = w * dl;
-                u = u * dl;
+                float u;
+                if (KIND == VSOM_MEDIAN) {
+                    u = w * __builtin_fabsf(dl);             // = (w * s) * s exactly for s in {-1, +-0, 1, NaN}
+                } else {
+                    u = w * dl;
+                    u = u * dl;
+                }
                 S = S + u;                                   // :867
             }
         }

@@ -351,6 +351,14 @@ __device__ __forceinline__ float vsom_sign(float a)
     return (a < 0.f || a > 0.f) ? one : a;
 }
 
+// (w * s) * s of the sigma^2 accumulation (Som.cpp:867) when s = sign(..) is -1, +-0, +1 or NaN and w a
+// finite weight >= 0: both products are exact, and equal w * |s| -- w for +-1, +0 for +-0 (w*(-0) = -0,
+// (-0)*(-0) = +0), NaN for NaN.  One multiplication with a source modifier instead of two.
+__device__ __forceinline__ float vsom_median_sq(float w, float s)
+{
+    return w * __builtin_fabsf(s);
+}
+
 // Standard / Median: lane = node, RD dims per lane, 4 waves per workgroup = 4 dim slices
 template <int RD, bool MEDIAN>
 __global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ Xs, int ldx,
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ X
                 dl = vsom_sign(dl);         //          sign(value - model)  (Transformation.cpp:50)
             float t = c * dl;
             M[k] = M[k] + t;                // :864
-            float u = w * dl;
+            float u = w * dl;           // (packed: v_pk_mul_f32 has no |x| modifier, so no vsom_median_sq here)
             u = u * dl;
             S[k] = S[k] + u;                // :867
         }
@@ -496,8 +504,13 @@ __global__ __launch_bounds__(256) void update_chain_kernel(const float *__restri
             } else {
                 float t = c * dl;
                 M = M + t;                  // :864
-                float s = w * dl;
-                s = s * dl;
+                float s;
+                if (MEDIAN) {
+                    s = vsom_median_sq(w, dl);
+                } else {
+                    s = w * dl;
+                    s = s * dl;
+                }
                 S = S + s;                  // :867
             }
         }
@@ -524,8 +537,13 @@ __global__ __launch_bounds__(256) void update_chain_kernel(const float *__restri
         } else {
             float t = v.x * dl;
             M = M + t;
-            float s = v.y * dl;
-            s = s * dl;
+            float s;
+            if (MEDIAN) {
+                s = vsom_median_sq(v.y, dl);
+            } else {
+                s = v.y * dl;
+                s = s * dl;
+            }
             S = S + s;
         }
     }
