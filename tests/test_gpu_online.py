@@ -29,6 +29,10 @@ CASES = [
     ("clr_inv", 7, 7, 5, 2, 1, 40, 1.4),
     ("local_sigma1_exp", 10, 10, 8, 0, 0, 60, 1.0),
     ("local_sigma_lt1_inv", 10, 10, 8, 0, 1, 60, 0.7),
+    # 2.5 * sigma < 1: the window truncates to nothing (Som.cpp:899-903), the BMU itself is not updated,
+    # addBmu / MSE / lastBMU still happen
+    ("local_sigma_03_empty_window", 12, 9, 8, 0, 0, 40, 0.3),
+    ("local_sigma_03_empty_window_median", 12, 9, 8, 1, 1, 40, 0.3),
     ("d794", 8, 8, 794, 0, 0, 12, 2.5),
 ]
 

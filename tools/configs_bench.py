@@ -74,7 +74,12 @@ def online_case(name, W, J, tr, B, sigma, X, init, decay):
 
 
 def main():
-    which = set(sys.argv[1:]) or {"c2", "c2median", "c3local", "c4", "c5", "online"}
+    which = set(sys.argv[1:]) or {"c1", "c2", "c2median", "c3local", "c4", "c5", "online"}
+    if "c1" in which:
+        X = gen.blobs(1024, 16, 4, 1, 2, sigma=0.1)
+        init = gen.random_map(100, 16, 42)
+        batch_case("C1 10x10x16 std first", 10, 16, capi.STANDARD, 1024, 5.0, X, init, steps=50)
+        batch_case("C1 10x10x16 std local", 10, 16, capi.STANDARD, 1024, 5.0, X, init, steps=50, is_first=False)
     if "c2" in which:
         X = gen.mnist_like(4096, 3, 784)
         init = gen.random_map(64 * 64, 784, 42) * np.float32(100) + np.float32(100)

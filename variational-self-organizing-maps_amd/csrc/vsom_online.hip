@@ -87,32 +87,54 @@ __global__ __launch_bounds__(256) void online_scan_kernel(OnlineArgs a)
     }
 }
 
-// single-sample Som::findLocalBmu (same walk as bmu_local_kernel in vsom_bmu.hip)
-template <bool CLR>
-__device__ __forceinline__ u64 online_local_search(const OnlineArgs &a, const u64 *lastbmu, int lane)
+// g-th candidate of the walk's first step: the 8 neighbours of `from`, wrap-then-clamp (Som.cpp:362-385)
+__device__ __forceinline__ u64 online_first_try_node(u64 from, int g, u64 width, u64 height)
 {
-    const int g = lane >> 3, k = lane & 7;
-    const u64 width = (u64)a.W, height = (u64)a.H;
     const u64 m1 = ~0ull;
     const u64 fsx = (g == 0 || g >= 6) ? m1 : ((g == 1 || g == 5) ? 0ull : 1ull);
     const u64 fsy = (g <= 2) ? 1ull : ((g == 3 || g == 7) ? 0ull : m1);
+    u64 cx = from % width + fsx;
+    cx = cx < width - 1 ? cx : width - 1;
+    u64 cy = from / width + fsy;
+    cy = cy < height - 1 ? cy : height - 1;
+    return cy * width + cx;
+}
+
+// single-sample Som::findLocalBmu (same walk as bmu_local_kernel in vsom_bmu.hip).  The distance of
+// the starting node (own) and of the first step's 8 neighbours (dfirst, one per lane group) do not
+// depend on each other; the caller may have them evaluated side by side by two wavefronts and pass
+// them in (own != nullptr), which takes one of the walk's latency-bound distance passes off its path.
+template <bool CLR>
+__device__ __forceinline__ u64 online_local_search(const OnlineArgs &a, const u64 *lastbmu, int lane,
+                                                   const float *own = nullptr, float dfirst = 0.f)
+{
+    const int g = lane >> 3, k = lane & 7;
+    const u64 width = (u64)a.W, height = (u64)a.H;
     const float *xa = a.d.xa, *xb = a.d.xb;
     u64 lastBMU = *lastbmu;
-    float minDist = vsom_group_dist_lat<CLR>(xa, xb, a.d.ma + (size_t)lastBMU * a.d.ldm,
-                                         a.d.mb + (size_t)lastBMU * a.d.ldm, a.d.L, k);
-    minDist = __shfl(minDist, 0);
+    float minDist;
+    if (own) {
+        minDist = *own;
+    } else {
+        minDist = vsom_group_dist_lat<CLR>(xa, xb, a.d.ma + (size_t)lastBMU * a.d.ldm,
+                                           a.d.mb + (size_t)lastBMU * a.d.ldm, a.d.L, k);
+        minDist = __shfl(minDist, 0);
+    }
+    bool precomputed = own != nullptr;
     u64 minIndex = lastBMU, lastMeasured = lastBMU;
     for (;;) {
         const u64 lmX = lastMeasured % width, lmY = lastMeasured / width;
         const u64 lbX = lastBMU % width;
         if (lastMeasured == lastBMU) {
-            u64 cx = lmX + fsx;
-            cx = cx < width - 1 ? cx : width - 1;
-            u64 cy = lmY + fsy;
-            cy = cy < height - 1 ? cy : height - 1;
-            u64 node = cy * width + cx;
-            float d = vsom_group_dist_lat<CLR>(xa, xb, a.d.ma + (size_t)node * a.d.ldm,
-                                           a.d.mb + (size_t)node * a.d.ldm, a.d.L, k);
+            const u64 node = online_first_try_node(lastMeasured, g, width, height);
+            float d;
+            if (precomputed) {
+                d = dfirst;
+                precomputed = false;
+            } else {
+                d = vsom_group_dist_lat<CLR>(xa, xb, a.d.ma + (size_t)node * a.d.ldm,
+                                             a.d.mb + (size_t)node * a.d.ldm, a.d.L, k);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float di = __shfl(d, i * 8);
@@ -317,9 +339,23 @@ __global__ __launch_bounds__(1024) void online_small_kernel(
 {
     constexpr bool CLR = KIND == VSOM_CLR;
     __shared__ u64 sbmu;
+    __shared__ float sown;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the walk's starting distance (wavefront 1) beside its first step's 8 neighbours (wavefront 0)
+    float dfirst = 0.f;
+    if (wave <= 1) {
+        const u64 from = *lastbmu_io;
+        const u64 node = wave == 0 ? online_first_try_node(from, lane >> 3, (u64)a.W, (u64)a.H) : from;
+        const float d = vsom_group_dist_lat<CLR>(a.d.xa, a.d.xb, a.d.ma + (size_t)node * a.d.ldm,
+                                                 a.d.mb + (size_t)node * a.d.ldm, a.d.L, lane & 7);
+        if (wave == 0)
+            dfirst = d;
+        else if (lane == 0)
+            sown = d;
+    }
+    __syncthreads();
     if (wave == 0) {
-        const u64 b = online_local_search<CLR>(a, lastbmu_io, lane);
+        const u64 b = online_local_search<CLR>(a, lastbmu_io, lane, &sown, dfirst);
         if (lane == 0)
             sbmu = b;
     }
@@ -335,11 +371,17 @@ __global__ __launch_bounds__(1024) void online_small_kernel(
         dx = dx < 0 ? -dx : dx;
         dy = dy < 0 ? -dy : dy;
         const double h = lutd[(size_t)dy * lutw + dx];
-        online_node_update<KIND, false>((size_t)(j * (u64)a.W + i), h, lane, 64, xs, xp, yp, D, P, ppitch, pitch,
+        const size_t n = (size_t)(j * (u64)a.W + i);
+        online_node_update<KIND, false>(n, h, lane, 64, xs, xp, yp, D, P, ppitch, pitch,
                                         eta, decay_fn, map, Smap, sigmap, weight);
+        if (n == (size_t)bmu) {        // the wavefront that rewrote the BMU's row finishes the sample while
+            __threadfence_block();     // the others update their nodes
+            online_post<CLR>(a, bmu, lane, hits, lastbmu_io, residual, fB, add_hit);
+        }
     }
-    __syncthreads();   // the BMU row may have been rewritten by another wave of this workgroup
-    if (wave == 0)
+    // sigma < 0.4 truncates the window to nothing (:899-903): the BMU is not updated, the sample still counts
+    const bool inside = (u64)bx >= startX && (u64)bx < endX && (u64)by >= startY && (u64)by < endY;
+    if (!inside && wave == 0)
         online_post<CLR>(a, bmu, lane, hits, lastbmu_io, residual, fB, add_hit);
 }
 
