@@ -164,3 +164,42 @@ def test_full_size_shortlist_equals_exact_kernel():
     for s in rs.randint(0, B, size=24):
         assert o.find_bmu(X[s]) == int(i_s[s])
     ctx.close()
+
+
+@pytest.mark.parametrize("W,J", [(36, 16), (48, 200)], ids=["small_chain_kernel", "assembly_update"])
+def test_nonfinite_and_huge_samples(W, J):
+    """NaN, +-inf and 1e30 (squares overflow) inside SAMPLES: the shortlist's bound does not apply to such
+    rows (device-side fallback to the exact kernel), every distance of a NaN sample is NaN so its BMU
+    is node 0 (Som.cpp:293-309), and phase 2 spreads the NaN through every chain of its column -- all
+    as in the oracle, bit for bit."""
+    H, B = W, 80
+    X = gen.blobs(B, J, 4, 1, 2)
+    X[3, 1] = np.nan
+    X[17, 0] = np.inf
+    X[18, J - 1] = -np.inf
+    X[40, 2] = 1e30
+    X[41, :] = 3e19                      # squares near FLT_MAX, their sum overflows
+    m = gen.random_map(W * H, J, 6)
+    o = po.OracleSom(W, H, J)
+    o.set_state(map=m)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_state(map=m)
+    ctx.upload_chunk(X)
+    lb_o, sq_o = _oracle_bmu(o, X, 8)
+    for mode in (capi.BMU_SHORTLIST, capi.BMU_EXACT, capi.BMU_AUTO):
+        idx, dist = _run(ctx, mode)
+        assert beq(idx, lb_o) and beq(dist, sq_o), mode
+    assert lb_o[3] == 0
+    # the whole epoch on those rows (sigma large enough that every node weighs every sample)
+    ctx.set_bmu_mode(capi.BMU_AUTO)
+    lb = np.zeros(B, np.uint64)
+    mse_o = o.batch_epoch(X, lb, 20.0, True)
+    ctx.upload_chunk(X)
+    mse_g = ctx.batch_epoch(20.0, True)
+    assert beq(np.float32(mse_g), np.float32(mse_o))
+    st = ctx.get_state()
+    for k, ref in (("map", o.map), ("sigma", o.sigma), ("weight", o.weight), ("hits", o.hits)):
+        assert beq(st[k], ref), k
+    # chains are per (node, dim): the columns holding NaN / +-inf samples are NaN in every node
+    assert np.isnan(o.map[:, [0, 1, J - 1]]).all() and not np.isnan(o.map[:, 3]).any()
+    ctx.close()
