@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ X
     const float4 *cp = (const float4 *)cw + nlc;     // {c_j, w_j, c_j+1, w_j+1} of pair row r at cp[r * ldn]
     // Sample pairs, software-pipelined: the scalar loads of x and the (c,w) load of pair r+1 are
     // issued before pair r is consumed (two register sets used alternately).  Reads one pair past
-    // the chunk at most: Xs has B+8 rows, cw ceil(B/2)+8 pair rows.
+    // the chunk at most: Xs has B + VSOM_ROW_PAD rows, cw ceil(B/2)+8 pair rows.
     auto load = [&](float (&xa)[RD], float (&xb)[RD], float4 &cv, int r) {
         vsom_cfp p0 = xr + (size_t)(2 * r) * ldx;
         vsom_cfp p1 = p0 + ldx;
