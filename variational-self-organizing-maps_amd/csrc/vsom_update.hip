@@ -17,14 +17,17 @@
 //                  - vsom_update_{std,fma}_rd{14,16}_gfx950, vsom_update_clr_rp8_gfx950: hand-scheduled
 //                    code object (gen_update_asm.py): lane = node, RD dims (8 CLR pairs) per lane in
 //                    VGPRs, x rows through scalar loads (SGPR operands of v_pk_* ops), a ring of
-//                    (c,w) loads always in flight.
-//                  - update_kernel (Median, ragged tails), update_clr_kernel (ragged tail): the same
-//                    decomposition in HIP, sample pairs software-pipelined.
+//                    (c,w) loads always in flight, x rows prefetched into L2.  A ragged depth is
+//                    covered by a 16/14 column split or by a last slice that runs into the rows'
+//                    zero padding (vsom_update_split; the padding is re-zeroed afterwards).
+//                  - update_kernel (Median; Standard / CLR with VSOM_NO_ASM), update_clr_kernel: the
+//                    same decomposition in HIP, sample pairs software-pipelined.
 //                  - update_chain_kernel: one lane per (node, dim) chain for maps too small to fill
 //                    the chip with lane = node.
 //                  Every fp32 operation is rounded separately (-ffp-contract=off), so the result is
 //                  bit-identical to the reference's SSE2 build (VSOM_UPDATE_FMA opts out, 1e-5).
-//   sigma_finalize_kernel : sigmaMap = sqrt(S / W) for the columns the assembly kernels left as S.
+//   sigma_finalize_kernel : sigmaMap = sqrt(S / W) for the columns the assembly kernels left as S
+//                  (+ zeroes of the padding columns a ragged last slice wrote).
 #include "vsom_device.hpp"
 #include <cmath>
 #include <cstdlib>
