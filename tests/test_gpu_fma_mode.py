@@ -21,6 +21,8 @@ def rel_err(a, b):
 
 @pytest.mark.parametrize("W,H,J,B,sigma,kind", [(24, 24, 784, 512, 8.0, "mnist"), (32, 32, 28, 1500, 10.0, "blobs"),
                                                 (16, 16, 48, 4096, 6.0, "blobs"),
+                                                # ragged depths: 16/14 column split (794), padded last slice (75)
+                                                (40, 40, 794, 300, 9.0, "mnist"), (48, 48, 75, 700, 8.0, "blobs"),
                                                 (128, 128, 784, 4096, 32.0, "mnist")])
 def test_fma_mode_within_tolerance(W, H, J, B, sigma, kind):
     X = gen.mnist_like(B, 3, J) if kind == "mnist" else gen.blobs(B, J, 5, 1, 2, sigma=0.4)
