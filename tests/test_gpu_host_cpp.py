@@ -1,6 +1,7 @@
 """GPU: the C++ host mirror (variational-self-organizing-maps_amd/host, libsom_hip.so) driven the
 way the reference's perf harness drives libsom; its results are compared bit for bit with the
 oracle running the same schedules."""
+import math
 import os
 import subprocess
 import tempfile
@@ -75,6 +76,24 @@ def test_batch_training_through_cpp_api(dumps):
     dump = read_dump(os.path.join(d, "batch_std.bin"))
     check_state(dump, o)
     assert done == 5 and beq(dump["mse"], mse)
+
+
+def test_batch_training_on_a_preloaded_dataset(dumps):
+    """the caller ran loadNextDataFromStream() before train(BatchMap): epoch 0 sees
+    hasReadWholeDataStream() already true, trains nothing and records 0/0 = NaN; the stream is reset and
+    epochs 1.. train with the local search (Som.cpp:735-749; isFirst only for i == 0, :738)"""
+    d, out, err = dumps
+    assert "no prefetched chunk" not in out + err
+    rows = make_rows(50, 9, 12345)
+    o = po.OracleSom(10, 10, 9, po.STANDARD)
+    o.random_initialize(42, 1.0)
+    mse = [np.float32(np.nan)]
+    for e in (1, 2):
+        lb = np.zeros(50, np.uint64)                     # lastBMU zeroed by the reload
+        mse.append(np.float32(o.batch_epoch(rows, lb, 6.0 * math.exp(-0.2 * e), False)))
+    dump = read_dump(os.path.join(d, "batch_preloaded.bin"))
+    check_state(dump, o)
+    assert beq(dump["mse"], np.array(mse, np.float32))
 
 
 def test_online_training_through_cpp_api(dumps):

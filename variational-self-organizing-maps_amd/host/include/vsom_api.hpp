@@ -345,6 +345,28 @@ struct Transformation {
 #include <mutex>
 
 #define VERSION 1.00
+
+// argv positions of the reference's CLI (include/SOM.hpp:17-35; apps/main.cpp indexes argv with them)
+#define ARG_SETTING 2
+
+#define ARG_DB_FILE 3
+#define ARG_SOM_FILE 4
+
+// Training parameters
+#define ARG_SOM_HEIGHT 5
+#define ARG_SOM_WIDTH 6
+#define ARG_SOM_ETA0 7
+#define ARG_SOM_ETA_DEC 8
+#define ARG_SOM_SIGMA0 9
+#define ARG_SOM_SIGMA_DEC 10
+#define ARG_SOM_EPOCHS 11
+#define ARG_SOM_INIT_SIGMA 12
+#define ARG_SOM_WEIGHT_DECAY_FUNCTION 13
+
+// Measuring parameters
+#define ARG_ALLOWED_STD_DEV 6
+#define ARG_MIN_BMU_HITS 5
+
 #define SIGMA_SWITCH_TO_LOCAL 1
 
 struct vsom_ctx;
@@ -444,6 +466,11 @@ public:
     void addBmu(SomIndex position);
     void save(const char *filename) const;   // Octave text format of the reference (Som.cpp:1209-1294)
     void load(const char *filename);         // that format (Som.cpp:1343-1597), or saveBinary's
+    // Som.cpp:1296-1341: sets width / height from the file's "# columns:" / "# rows:" lines and returns a
+    // vector of the file's model-vector length (length 1 when the file names none).  [MI355X build] when
+    // the dimensions change, the device state is rebuilt zeroed at the new size (the reference leaves its
+    // `map` vectors at the old size, which the next access overruns).
+    Eigen::VectorXf getSizeFromFile(const char *filename);
     void saveBinary(const char *filename) const;   // [MI355X build] lossless, incl. SMap
 
     // ---- [MI355X build] bulk state access (row-major N x depth) and device selection -----------

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdlib>
+#include <cstring>   // real Eigen pulls it in; apps/main.cpp:43 relies on std::strcmp through SOM.hpp
 #include <initializer_list>
 #include <ostream>
 #include <vector>

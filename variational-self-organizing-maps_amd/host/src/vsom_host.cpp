@@ -832,6 +832,10 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
         }
         // the next epoch will run (and therefore reload the stream from its start, :737,749)?
         const bool another = i + 1 < numberOfEpochs && sigmaOf(i + 1) >= 1.0;
+        // set only where the next epoch's first chunk really was loaded and its copy started: an epoch
+        // that found the stream already read to its end (a caller who loaded the single chunk before
+        // train()) processes no chunk, records 0/0 = NaN and resets the stream like Som.cpp:735-749
+        bool prefetchedNext = false;
         while (have) {
             const size_t Bcur = B;
             // (also for an empty chunk: the reference's epoch then zeroes the map, see trainBatchSomEpoch)
@@ -851,6 +855,7 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
                 data.loadNextDataFromStream();
                 B = data.size();
                 check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+                prefetchedNext = true;
             } else if (Bcur > 0) {
                 // the chunk still held by `data` when training ends keeps its BMUs (Som.cpp:777,800)
                 std::vector<uint64_t> lb(Bcur);
@@ -873,7 +878,7 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
             const std::lock_guard<std::mutex> lock(metricsMutex);
             metrics.MeanSquaredError[i] = meanSquareError;
         }
-        if (another)
+        if (prefetchedNext)
             have = true;              // chunk 0 of epoch i+1 is already loaded and on its way
         else
             data.resetStreamLoadPosition();   // :749
@@ -1252,6 +1257,29 @@ void Som::saveBinary(const char *fileName) const
     f.write((const char *)S.data(), S.size() * 4);
     f.write((const char *)w.data(), w.size() * 4);
     f.write((const char *)hh.data(), hh.size() * 8);
+}
+
+// Som.cpp:1296-1341.  The reference assigns `height` from "# rows:" and `width` from "# columns:" and
+// returns a vector whose length is the last number of the line after "# ndims:" (length 1 otherwise);
+// a file that cannot be opened ends the process (:1305-1309).
+Eigen::VectorXf Som::getSizeFromFile(const char *fileName)
+{
+    size_t w = width, h = height, d = 1;
+    if (!vsom::read_octave_dims(fileName, w, h, d)) {
+        std::cout << "Could not open file " << fileName << " for reading. Quitting...\n";
+        std::exit(EXIT_FAILURE);
+    }
+    if (w != width || h != height) {
+        width = w;
+        height = h;
+        uMatrix.assign(width * height, 0.0);
+        if (ctx)
+            vsom_destroy(ctx);
+        ctx = nullptr;
+        createContext();
+        hostStale = true;
+    }
+    return Eigen::VectorXf((Eigen::Index)d);
 }
 
 // Som.cpp:1343-1597: reads the Octave text checkpoint into the EXISTING map (dimensions come from

@@ -155,6 +155,18 @@ int main(int argc, char **argv)
         dump(out + "/batch_std.bin", som, met.MeanSquaredError);
         std::cout << "batch_std hits0=" << som.getBmuHits()[0] << " neuron0[0]=" << som.getNeuron(size_t{0})[0] << "\n";
     }
+    // ---- batch map on a DataSet whose single chunk the caller loaded BEFORE train(): the first epoch finds
+    //      the stream already read to its end, processes nothing and records 0/0 (Som.cpp:735-749); the
+    //      following epochs reload and train (local search: only epoch 0 passes isFirst) ----
+    {
+        ArrayDataLoader loader(rows.data(), NROWS, J);
+        DataSet ds(loader);
+        Som som{W, H, ds, Transformation::Standard(loader.getNames())};
+        som.randomInitialize(42, 1);
+        ds.loadNextDataFromStream();
+        som.train(ds, 3, 0.0, 0.0, 6.0, 0.2, Som::WeigthDecayFunction::BatchMap);
+        dump(out + "/batch_preloaded.bin", som, som.getMetrics().MeanSquaredError);
+    }
     // ---- online, exponential decay, median estimator ----
     {
         ArrayDataLoader loader(rows.data(), NROWS, J, CHUNK);
