@@ -4,22 +4,37 @@
 Metric (BASELINE.json): training samples/sec per epoch (BMU + update), 128x128 map, 784-dim.
 A "step" = one Som::trainBatchSomEpoch (Som.cpp:756-879) pass -- full BMU search (is_first) +
 neighbourhood mean/sigma^2 update -- over one chunk of B=4096 synthetic MNIST-like samples per
-GPU, chunk already resident in HBM when the timed region starts.  With N GPUs the chunk is
-4096*N samples (weak scaling): phase 1 shards samples, phase 2 shards nodes, RCCL all-gathers
-exchange lastBMU / the new map rows (variational-self-organizing-maps_amd/dist.py).
+GPU, the rank's own samples already resident in HBM when the timed region starts.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 20 --warmup 3            (default: C3, the BASELINE headline)
+  python bench.py --config c2|c4|c5|online                  (the other BASELINE.json configs, 1 GPU)
+  python bench.py --gpus N                                  (starts N ranks itself, see below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant
-kernel = the phase-2 update kernel, fp32 VALU work priced against the 157.3 TFLOP/s fp32 peak
-that gfx950's vector and matrix pipes share) and `cpu_baseline` (the CPU oracle timed on this
-box's host cores on a bounded sample of the same workload).
+N > 1 (weak scaling): every rank OWNS 4096 samples of the 4096*N-sample chunk.  Inside the timed
+step the chunk is replicated with an RCCL all-gather of X (the node-sharded phase 2 reads every
+sample), phase 1 runs on the rank's samples, lastBMU / ||residual||^2 are all-gathered, phase 2
+runs on the rank's 16384/N nodes and the new map rows are all-gathered
+(variational-self-organizing-maps_amd/dist.py).  When WORLD_SIZE is unset and --gpus N > 1 this
+script starts the N ranks itself (python -m torch.distributed.run as a child process, before
+anything in this process touches the GPU) and exits with the child's status.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel of
+the configuration, HIP-event time on the stream it runs on) and `cpu_baseline` (the CPU oracle
+timed on this box's host cores on a bounded sample of the same workload).
+
+Arithmetic of the update chains (--arith): `contracted` (default; M = fma(c,d,M), S = fma(w*d,d,S):
+within the 1e-5 relative fp32 tolerance BASELINE.json's north_star states -- measured <= 4e-7
+element-wise, tests/test_gpu_fma_mode.py -- with BMU indices, bmuHits, MSE and weightMap
+bit-exact) or `strict` (one rounding per fp32 operation: map / sigmaMap bit-identical to the
+reference's SSE2 arithmetic).  The other mode is timed in the same run and reported beside it.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,7 +44,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: Peak FP32 vector == matrix (dense)
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32, vector == matrix (dense)
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+# BASELINE.json configs.  transform: 0 Standard, 1 Median, 2 CLR (vsom_hip.h)
+CONFIGS = {
+    "c3": dict(map=128, dim=784, chunk=4096, sigma=32.0, transform=0, data="mnist",
+               name="128x128 map, 784-dim MNIST-like synthetic, standard transformation"),
+    "c2": dict(map=64, dim=784, chunk=4096, sigma=16.0, transform=0, data="mnist",
+               name="64x64 map, 784-dim MNIST-like synthetic, standard transformation"),
+    "c4": dict(map=64, dim=32, chunk=16384, sigma=16.0, transform=1, data="blobs",
+               name="64x64 map, 32-dim synthetic blobs, median-estimator transformation"),
+    "c5": dict(map=32, dim=64, chunk=8192, sigma=8.0, transform=2, data="correlated",
+               name="32x32 map, 64-dim correlated synthetic, combinatorial-linear-regression transformation (D=4032)"),
+    "online": dict(map=128, dim=784, chunk=512, sigma=8.0, transform=0, data="mnist",
+                   name="128x128 map, 784-dim MNIST-like synthetic, standard transformation, online "
+                        "trainSingle steps (Exponential decay, eta=0.1)"),
+}
+METRIC = "training samples/sec per epoch (BMU+update), 128x128 map, 784-dim"
 
 
 def parse():
@@ -37,14 +69,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--map", type=int, default=128, help="map side (default 128 -> 128x128)")
-    ap.add_argument("--dim", type=int, default=784)
-    ap.add_argument("--chunk", type=int, default=4096, help="samples per GPU per step")
-    ap.add_argument("--sigma", type=float, default=32.0)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (default c3 = the headline, 128x128x784)")
+    ap.add_argument("--map", type=int, default=None, help="map side (overrides the config)")
+    ap.add_argument("--dim", type=int, default=None, help="sample length J (overrides the config)")
+    ap.add_argument("--chunk", type=int, default=None, help="samples per GPU per step (overrides the config)")
+    ap.add_argument("--sigma", type=float, default=None)
     ap.add_argument("--strong", action="store_true", help="fixed total chunk (strong scaling)")
     ap.add_argument("--local", action="store_true", help="time the later-epoch (findLocalBmu) pass")
-    ap.add_argument("--fma", action="store_true",
-                    help="opt-in contracted update arithmetic (within 1e-5 of the reference, not bit-identical)")
+    ap.add_argument("--arith", choices=["contracted", "strict"], default="contracted",
+                    help="arithmetic of the update chains for `value` (the other one is reported beside it)")
+    ap.add_argument("--no-other-arith", action="store_true", help="skip the second (other-arithmetic) timed run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--nchunks", type=int, default=4, help="distinct resident chunks cycled over")
@@ -56,26 +91,76 @@ def parse():
                     help="PCIe-inclusive variants (N=1, not the contract number): chunks start in pinned host "
                          "memory every step; 'sync' = vsom_upload_chunk, 'overlap' = prefetch of chunk i+1 "
                          "beside the epoch of chunk i (vsom_prefetch_chunk / vsom_commit_chunk)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k in ("map", "dim", "chunk", "sigma"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    args.cfg = cfg
+    return args
 
 
-def cpu_baseline(args, X_host, init_map):
+def self_launch(args):
+    """--gpus N without a launcher: start the N ranks as a child torch.distributed.run.  Nothing in
+    this process has touched the GPU (only numpy is imported), and the child is a new process, not an
+    exec of this one."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def make_data(cfg, n, seed):
+    import gen
+    if cfg["data"] == "mnist":
+        return gen.mnist_like(n, seed=seed, dim=cfg["dim"])
+    if cfg["data"] == "blobs":
+        return gen.blobs(n, cfg["dim"], 8, 1, seed, sigma=1.0)
+    return gen.correlated(n, cfg["dim"], seed)
+
+
+def make_map(cfg, depth):
+    import gen
+    n = cfg["map"] * cfg["map"]
+    if cfg["data"] == "mnist":
+        return gen.random_map(n, depth, seed=42, scale=1.0) * np.float32(100.0) + np.float32(100.0)
+    return gen.random_map(n, depth, seed=42)
+
+
+def cpu_baseline(args, X_host, init_map, online=False):
     """Oracle (CPU port of the reference algorithm) on a bounded prefix of one chunk."""
     from oracle import pyoracle as po
-    W = H = args.map
+    cfg = args.cfg
+    W = H = cfg["map"]
     cores = po.max_threads()
     B = X_host.shape[0]
 
     def run(nsamp, threads, faithful=False):
-        o = po.OracleSom(W, H, args.dim, po.STANDARD)
+        o = po.OracleSom(W, H, cfg["dim"], cfg["transform"])
         o.set_state(map=init_map)
         lb = np.zeros(nsamp, np.uint64)
         t0 = time.perf_counter()
-        o.batch_epoch(X_host[:nsamp], lb, args.sigma, True, nthreads=threads, faithful=faithful)
+        if online:
+            o.train_online_chunk(X_host[:nsamp], lb, 0.1, cfg["sigma"], po.EXPONENTIAL)
+        else:
+            o.batch_epoch(X_host[:nsamp], lb, cfg["sigma"], True, nthreads=threads, faithful=faithful)
         dt = time.perf_counter() - t0
         o.close()
         return dt
 
+    if online:
+        # strictly sequential in samples: one thread (the oracle's trainSingle is scalar code)
+        n0 = min(B, 4)
+        t_small = run(n0, 1)
+        n = int(min(B, max(n0, n0 * args.cpu_seconds * 0.6 / max(t_small, 1e-3))))
+        t = run(n, 1)
+        return {"value": round(n / t, 3), "unit": "samples/s", "cores": 1, "kind": "port",
+                "sample": (f"oracle vso_train_online_chunk (trainSingle x {n}) on the first {n} samples of one "
+                           f"{B}-sample chunk, {W}x{H}x{cfg['dim']} map, sigma={cfg['sigma']}")}
     # calibrate on a small prefix, then size the sample for ~cpu_seconds of CPU work
     n0 = min(B, 8 * cores)
     t_small = run(n0, cores)
@@ -91,26 +176,43 @@ def cpu_baseline(args, X_host, init_map):
         "value": round(best, 3), "unit": "samples/s",
         "cores": cores if lean >= faithful else 1, "kind": "port",
         "sample": (f"oracle vso_batch_epoch (findBmu + update) on the first {n} samples of one "
-                   f"{B}-sample chunk, {W}x{H}x{args.dim} map, OpenMP over samples/nodes"),
+                   f"{B}-sample chunk, {W}x{H}x{cfg['dim']} map, OpenMP over samples/nodes"),
         "lean_all_cores_samples_per_s": round(lean, 3),
         "faithful_1thread_samples_per_s": round(faithful, 3),
         "faithful_sample": nf,
     }
 
 
+def profile_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/collect_profiles.sh + tools/pmc_summary.py): counters cannot
+    be read inside this run, so the figure is profile-derived and labelled with its source."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(tpath))
+    except Exception:
+        return None, None
+    ent = t.get(key)
+    if isinstance(ent, dict):
+        return ent.get("hbm_bytes_per_launch"), f"profiles/traffic.json[{key}] ({ent.get('source', 'rocprofv3 --pmc')})"
+    if key == "c3" and "update_kernel_hbm_bytes_per_launch" in t:
+        return t["update_kernel_hbm_bytes_per_launch"], "profiles/traffic.json (r1 rocprofv3 --pmc passes)"
+    return None, None
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-        args.gpus = world
+    args.gpus = world
+    cfg = args.cfg
+    online = args.config == "online"
 
     import torch
     import torch.distributed as dist
-    import gen
     import vsom_amd
     from vsom_amd import capi
     import importlib
@@ -128,172 +230,213 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    W = H = args.map
-    D = args.dim
-    Bper = args.chunk
-    Bglob = Bper if args.strong else Bper * world
-
-    # synthetic data: MNIST-like uint8-valued floats; distinct chunks, same on all ranks
-    chunks_host = [gen.mnist_like(Bglob, seed=3 + i, dim=D) for i in range(args.nchunks)]
-    init_map = gen.random_map(W * H, D, seed=42, scale=1.0) * np.float32(100.0) + np.float32(100.0)
+    W = H = cfg["map"]
+    J = cfg["dim"]
+    tr = cfg["transform"]
+    Bper = cfg["chunk"]
+    sigma = cfg["sigma"]
+    sharded = world > 1 and not online           # the online path is strictly sequential: replicas only
+    if world > 1 and tr != capi.STANDARD:
+        # Median / CLR shard the same way (node-sharded phase 2); BASELINE names them as 1-GPU configs
+        pass
+    if args.strong and sharded:
+        Bper = Bper // world
+    Bglob = Bper * world if sharded else Bper
 
     stream = torch.cuda.Stream(device=dev)
-    ctx = vsom_amd.Context(W, H, D, capi.STANDARD, device=local_rank)
+    ctx = vsom_amd.Context(W, H, J, tr, device=local_rank)
+    D = ctx.depth
+    init_map = make_map(cfg, D)
     ctx.set_state(map=init_map)
-    ctx.set_stream(stream.cuda_stream)
-    if args.fma:
-        ctx.set_update_mode(capi.UPDATE_FMA)
-    chunks = [torch.from_numpy(c).to(dev) for c in chunks_host]
-    torch.cuda.synchronize()
-
-    eng = vdist.HipEngine(ctx, dev)
-    trainer = vdist.ShardedBatchTrainer(eng, rank, world)
+    eng = vdist.HipEngine(ctx, dev, stream)      # the context adopts `stream`; collectives run on it too
+    trainer = vdist.ShardedBatchTrainer(eng, rank if sharded else 0, world if sharded else 1)
     is_first = not args.local
+
+    # synthetic data: rank r owns rows [r*Bper, (r+1)*Bper) of every chunk -- generated with a
+    # per-(chunk, rank) seed, so no rank ever holds another rank's rows before the all-gather
+    own_host = [make_data(cfg, Bper, seed=3 + i + 1000 * (rank if sharded else 0)) for i in range(args.nchunks)]
+    own = [torch.from_numpy(c).to(dev) for c in own_host]
+    full = torch.empty((Bglob, J), dtype=torch.float32, device=dev) if sharded else None
+    torch.cuda.synchronize()
 
     pinned = None
     if args.host_chunks != "off":
-        if world != 1:
-            raise SystemExit("--host-chunks is a single-GPU measurement")
-        pinned = [capi.PinnedBuffer(c.shape) for c in chunks_host]
-        for pb, c in zip(pinned, chunks_host):
+        if world != 1 or online:
+            raise SystemExit("--host-chunks is a single-GPU batch measurement")
+        pinned = [capi.PinnedBuffer(c.shape) for c in own_host]
+        for pb, c in zip(pinned, own_host):
             pb.array[...] = c
         if args.host_chunks == "overlap":
             ctx.prefetch_chunk(pinned[0].array)
 
     def step(i):
         with torch.cuda.stream(stream):
+            if online:
+                # Som::trainBasicSom's sample loop over one staged chunk (Som.cpp:1159-1171)
+                eng.load_chunk_device(own[i % len(own)])
+                check = capi.lib().vsom_train_online_chunk(ctx._h, 0.1, float(sigma), capi.EXPONENTIAL, None)
+                if check:
+                    raise RuntimeError(capi.lib().vsom_last_error().decode())
+                return
             if args.host_chunks == "sync":
                 ctx.upload_chunk(pinned[i % len(pinned)].array)      # blocking H2D + staging
                 eng._bind_chunk()
             elif args.host_chunks == "overlap":
                 ctx.commit_chunk()                                   # chunk i (copied during step i-1)
                 eng._bind_chunk()
+            elif sharded:
+                # chunk replication: every rank contributes its Bper rows (RCCL all-gather over xGMI)
+                dist.all_gather_into_tensor(full, own[i % len(own)])
+                eng.load_chunk_device(full)
             else:
-                eng.load_chunk_device(chunks[i % len(chunks)])   # staging + lastBMU reset (DataSet.cpp:118-160)
-            trainer.epoch(args.sigma, is_first)
+                eng.load_chunk_device(own[i % len(own)])   # staging + lastBMU reset (DataSet.cpp:118-160)
+            trainer.epoch(sigma, is_first)
             if args.host_chunks == "overlap":
                 ctx.prefetch_chunk(pinned[(i + 1) % len(pinned)].array)   # H2D of chunk i+1 beside this epoch
 
-    for i in range(args.warmup):
-        step(i)
-    with torch.cuda.stream(stream):
-        trainer.flush()
-    torch.cuda.synchronize()
-    ctx.get_timing(reset=True)
-    ctx.enable_timing(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    with torch.cuda.stream(stream):
-        trainer.flush()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timing = ctx.get_timing(reset=True)
-    ctx.enable_timing(False)
-
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # secondary, informational: the same step with the opt-in contracted update arithmetic
-    # (M = fma(c,d,M), S = fma(w*d,d,S); results within 1e-5 of the reference instead of bit-identical).
-    # `value` above is the strict run; this is reported beside it, never instead of it.
-    fma_extra = None
-    if not args.fma:
-        ctx.set_update_mode(capi.UPDATE_FMA)
-        for i in range(2):
+    def timed(nwarm, nsteps):
+        for i in range(nwarm):
             step(i)
-        with torch.cuda.stream(stream):
-            trainer.flush()
+        trainer.flush()
         torch.cuda.synchronize()
         ctx.get_timing(reset=True)
         ctx.enable_timing(True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            step(2 + i)
-        with torch.cuda.stream(stream):
-            trainer.flush()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            step(nwarm + i)
+        trainer.flush()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        dtf = time.perf_counter() - t1
-        tf = ctx.get_timing(reset=True)
+        dt = time.perf_counter() - t0
+        tm = ctx.get_timing(reset=True)
         ctx.enable_timing(False)
-        ctx.set_update_mode(capi.UPDATE_STRICT)
         if world > 1:
-            t = torch.tensor([dtf], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtf = float(t.item())
-        fma_extra = (dtf, tf["update"][0] / max(tf["update"][1], 1))
+            dt = float(t.item())
+        return dt, tm
+
+    # the library applies the contracted mode to the chains that have one (vsom_hip.h, vsom_update_mode)
+    mode_of = {"contracted": capi.UPDATE_FMA, "strict": capi.UPDATE_STRICT}
+    ctx.set_update_mode(mode_of[args.arith])
+    dt, timing = timed(args.warmup, args.steps)
+
+    other = None
+    if not args.no_other_arith and not online:
+        other_name = "strict" if args.arith == "contracted" else "contracted"
+        ctx.set_update_mode(mode_of[other_name])
+        dto, tmo = timed(2, args.steps)
+        ctx.set_update_mode(mode_of[args.arith])
+        other = (other_name, dto, tmo)
+
+    rccl_ranks = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
 
     mse = float(ctx.get_mse())
-    sl_stats = ctx.shortlist_stats()
+    sl_stats = ctx.shortlist_stats() if not online else None
     if rank == 0:
-        nloc = W * H // world if (W * H) % world == 0 else None
-        n_nodes_rank = (vdist.shard_bounds(W * H, world, 0)[1])
-        upd_ms, upd_cnt = timing["update"]
-        upd_avg_s = upd_ms / max(upd_cnt, 1) / 1e3
-        # algorithmic work of one update launch: 6 flop per (node, dim, sample)  
-        flops_launch = 6.0 * n_nodes_rank * D * Bglob
-        achieved = flops_launch / upd_avg_s / 1e12 if upd_avg_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("update_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        N = W * H
+        n_nodes_rank = vdist.shard_bounds(N, world, 0)[1] if sharded else N
+        steps = args.steps
+        units = Bglob if sharded else Bper * world      # replicas: every rank processes its own chunk
+
+        def roofline_for(tm):
+            if online:
+                # HBM / Infinity-Cache bound: per sample a scan of the map (4*N*D B) + the window's
+                # read-modify-write of M, S, sigma (20*k*D B), k = window nodes  
+                side = min(W, 2 * int(2.5 * sigma) + 1)
+                k = side * side
+                bytes_sample = 4.0 * N * D + 20.0 * k * D
+                t_ms, cnt = tm["online"]
+                per_sample_s = t_ms / 1e3 / max(steps * Bper, 1)
+                ach = bytes_sample / per_sample_s / 1e9 if per_sample_s > 0 else 0.0
+                return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBPS, 4),
+                        "kernel": "online_scan_kernel + online_window_kernel (per trainSingle step)",
+                        "avg_sample_us": round(per_sample_s * 1e6, 3),
+                        "algorithmic_bytes_per_sample": bytes_sample, "window_nodes_upper_bound": k,
+                        "note": "window clipped at the map border moves less; the three model arrays of the window "
+                                "sit in the 256 MB Infinity Cache, so rates above the HBM peak are cache hits"}
+            upd_ms, upd_cnt = tm["update"]
+            upd_avg_s = upd_ms / max(upd_cnt, 1) / 1e3
+            # algorithmic work of one update launch: 6 flop per (node, dim, sample) for
+            # Standard / Median; CLR: 15 flop per (node, parameter pair, sample) -- the operation count of
+            # Transformation.cpp:107-142 + Som.cpp:861-867 (SURVEY rounds it to 16)
+            if tr == capi.CLR:
+                flops = 15.0 * n_nodes_rank * (D // 2) * Bglob
+            else:
+                flops = 6.0 * n_nodes_rank * D * Bglob
+            ach = flops / upd_avg_s / 1e12 if upd_avg_s > 0 else 0.0
+            kern = {capi.STANDARD: "vsom_update_{std,fma}_rd14/16_gfx950 (phase-2 mean/sigma^2 chains, hand-scheduled)",
+                    capi.MEDIAN: "update chain kernel, median stepper (phase-2 chains)",
+                    capi.CLR: "vsom_update_clr_rp8_gfx950 (phase-2 CLR chains, hand-scheduled)"}[tr]
+            return {"bound": "valu_fp32", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_PEAK_TFLOPS, 4), "kernel": kern,
+                    "note": ("fp32 VALU-bound chains priced against the fp32 dense peak the vector and matrix pipes "
+                             "share (157.3 TFLOP/s counts an FMA as 2 flop); of the 6 algorithmic flop per element "
+                             "4 fit into 2 FMAs, so contracted arithmetic is capped at 0.75 and strict (no FMA) at 0.5"),
+                    "avg_launch_ms": round(upd_avg_s * 1e3, 4),
+                    "algorithmic_flop_per_launch": flops}
+
+        roof = roofline_for(timing)
+        traffic, tsrc = profile_traffic(args.config if args.arith == "contracted" else args.config + "_strict")
+        roof["traffic"] = traffic
+        roof["traffic_source"] = tsrc
+        arith = "n/a (online path has no contracted mode)" if online else (
+            "contracted (fma; map/sigmaMap within 1e-5 relative of the reference, everything else bit-exact)"
+            if args.arith == "contracted" else "strict (bit-identical to the CPU oracle)")
+        if not online and tr != capi.STANDARD and args.arith == "contracted" and not capi.has_contracted(tr):
+            arith = "strict (this transformation has no contracted chain kernel)"
         out = {
-            "metric": "training samples/sec per epoch (BMU+update), 128x128 map, 784-dim",
-            "value": round(args.steps * Bglob / dt, 3),
+            "metric": METRIC if args.config == "c3" else "training samples/sec per epoch (BMU+update)",
+            "value": round(steps * units / dt, 3),
             "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if args.host_chunks == "off" else f"synthetic, chunks in pinned host memory ({args.host_chunks})",
-            "update_arithmetic": "fma (opt-in, 1e-5 relative)" if args.fma else "strict (bit-identical to the CPU oracle)",
-            "config": {"workload": (f"{W}x{H} map, {D}-dim MNIST-like synthetic, standard transformation, "
-                                    f"trainBatchSomEpoch({'findBmu' if is_first else 'findLocalBmu'} + update), "
-                                    f"chunk B={Bper}/GPU ({Bglob} total), sigma={args.sigma}"),
-                       "map": [W, H], "dim": D, "chunk_per_gpu": Bper, "chunk_total": Bglob,
-                       "parallelism": "1 GPU" if world == 1 else f"phase1 sample-sharded x{world}, phase2 node-sharded x{world}, RCCL all-gather"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / FP32_PEAK_TFLOPS, 4),
-                         "traffic": traffic,
-                         "kernel": "vsom_update_std_rd14_gfx950 (phase-2 mean/sigma^2 chains, hand-scheduled)",
-                         "note": ("fp32 VALU-bound kernel priced against the fp32 dense peak shared by the vector and "
-                                  "matrix pipes; strict non-FMA arithmetic caps it at 0.5"),
-                         "avg_launch_ms": round(upd_avg_s * 1e3, 4),
-                         "algorithmic_flop_per_launch": flops_launch},
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in timing.items()},
+            "data": "synthetic",
+            "update_arithmetic": arith,
+            "rccl_ranks": rccl_ranks,
+            "config": {"workload": (f"{cfg['name']}, "
+                                    + ("trainBasicSom sample loop (trainSingle per sample)" if online else
+                                       f"trainBatchSomEpoch({'findBmu' if is_first else 'findLocalBmu'} + update)")
+                                    + f", chunk B={Bper}/GPU ({Bglob if sharded else Bper} per step and "
+                                    + ("replica" if not sharded and world > 1 else "job") + f"), sigma={sigma}"),
+                       "baseline_config": args.config,
+                       "map": [W, H], "dim": J, "depth": D, "chunk_per_gpu": Bper,
+                       "chunk_total": Bglob if sharded else Bper * world,
+                       "parallelism": (f"{world} GPU: phase 1 sample-sharded, phase 2 node-sharded, RCCL all-gathers of "
+                                       "X / lastBMU / sqres / map rows inside the step" if sharded else
+                                       (f"{world} independent replicas (the online path is sequential in samples)"
+                                        if world > 1 else "1 GPU"))},
+            "roofline": roof,
+            "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in timing.items()},
             "mse_last": mse,
             "bmu_shortlist_last": sl_stats,
         }
-        if fma_extra is not None:
-            dtf, upd_f_ms = fma_extra
-            ach_f = flops_launch / (upd_f_ms / 1e3) / 1e12 if upd_f_ms > 0 else 0.0
-            out["fma_mode"] = {"note": "opt-in VSOM_UPDATE_FMA arithmetic (tests/test_gpu_fma_mode.py: map/sigma within "
-                                       "1e-5 relative -- measured 3.4e-7 at this size, tools/fma_error_report.py -- BMU "
-                                       "indices / bmuHits / MSE / weightMap bit-exact); not the headline",
-                               "value": round(args.steps * Bglob / dtf, 3), "ms_per_step": round(dtf / args.steps * 1e3, 4),
-                               "update_avg_launch_ms": round(upd_f_ms, 4), "update_achieved_tflops": round(ach_f, 3),
-                               "update_frac_of_peak": round(ach_f / FP32_PEAK_TFLOPS, 4)}
+        if other is not None:
+            oname, dto, tmo = other
+            ro = roofline_for(tmo)
+            out["other_arithmetic"] = {
+                "arithmetic": oname,
+                "note": ("strict = one rounding per fp32 operation, map/sigmaMap bit-identical to the CPU oracle "
+                         "(tests -m gpu); contracted = fma chains, within 1e-5 relative (tests/test_gpu_fma_mode.py)"),
+                "value": round(steps * units / dto, 3), "ms_per_step": round(dto / steps * 1e3, 4),
+                "update_avg_launch_ms": ro.get("avg_launch_ms"), "update_achieved_tflops": ro.get("achieved"),
+                "update_frac_of_peak": ro.get("frac")}
         if not args.no_cpu and world == 1:   # the CPU leg runs at N=1 only (contract)
-            out["cpu_baseline"] = cpu_baseline(args, chunks_host[0][:Bper], init_map)
+            out["cpu_baseline"] = cpu_baseline(args, own_host[0][:Bper], init_map, online=online)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

@@ -38,7 +38,7 @@ def _worker(rank, world, port, case, ret):
         ctx = vsom_amd.Context(W, H, J, tr, device=0)
         ctx.set_state(map=init)
         ctx.set_stream(stream.cuda_stream)
-        eng = vdist.HipEngine(ctx, dev)
+        eng = vdist.HipEngine(ctx, dev, stream)
         trn = vdist.ShardedBatchTrainer(eng, rank, world)
         xt = torch.from_numpy(X).to(dev)
         out = {}

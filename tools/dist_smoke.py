@@ -18,7 +18,7 @@ W = H = 32; D = 48; B = 512
 X = gen.blobs(B, D, 4, 1, 2); init = gen.random_map(W * H, D, 3)
 stream = torch.cuda.Stream(device=dev)
 ctx = vsom_amd.Context(W, H, D); ctx.set_state(map=init); ctx.set_stream(stream.cuda_stream)
-eng = vdist.HipEngine(ctx, dev)
+eng = vdist.HipEngine(ctx, dev, stream)
 xt = torch.from_numpy(X).to(dev)
 def forced(t, world, rank, group=None, async_op=False):
     src = t.clone()

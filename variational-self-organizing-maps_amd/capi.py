@@ -40,6 +40,12 @@ class VsomError(RuntimeError):
     pass
 
 
+def has_contracted(transform):
+    """whether vsom_set_update_mode(VSOM_UPDATE_FMA) changes the chain arithmetic of this transformation
+    (include/vsom_hip.h, vsom_update_mode)"""
+    return int(transform) == STANDARD
+
+
 def build(force=False):
     """Compile libvsom_hip.so for gfx950 with csrc/build.sh (hipcc cross-compiles on CPU)."""
     script = os.path.join(_HERE, "csrc", "build.sh")

@@ -369,6 +369,10 @@ static int ensure_chunk_capacity(vsom_ctx *c, size_t B)
     }
     c->partial_cap = 0;
     c->Bcap = 0;
+    // no chunk is staged from here on: should an allocation below fail, later entry points report
+    // "no chunk loaded" instead of launching kernels on null buffers
+    c->B = 0;
+    c->chunk_loaded = false;
     size_t cap = (B + 63) / 64 * 64;
     // the assembly update kernel reads up to 2 sample rows past the chunk and touches rows up to
     // PF_ROWS + 3 past it (gen_update_asm.py, load_cw)

@@ -28,7 +28,8 @@ typedef unsigned long long u64;
 
 #define VSOM_TK 32          // K-chunk of the tile kernels; row pitches are multiples of it
 
-// spare (zeroed) rows behind the staged sample matrices: the pipelined update kernels read ahead
+// spare rows behind the staged sample matrices (readable, contents unspecified: zero at allocation, stale
+// samples after a larger chunk): the pipelined update kernels read ahead into them and never consume them
 constexpr size_t VSOM_ROW_PAD = 32;
 // bytes of vsom_ctx::onl_state (layout: vsom_online.hip)
 constexpr size_t VSOM_ONL_STATE_BYTES = 4352;

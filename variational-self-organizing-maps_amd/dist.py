@@ -13,6 +13,8 @@ The trainer is written against a small "engine" interface so that the same orche
 exercised on CPU by the world_size-2 gloo tests (tests/test_dist_gloo.py, oracle-backed engine)
 and on GPUs by bench.py (HipEngine below).
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -41,12 +43,21 @@ def device_tensor(ptr, shape, dtype, device):
 class HipEngine:
     """vsom_ctx-backed engine: tensors alias the library's device buffers."""
 
-    def __init__(self, ctx, device):
+    def __init__(self, ctx, device, stream=None):
+        """`stream`: the torch.cuda.Stream both the library's kernels and the collectives run on (a new
+        one when None).  The context adopts it (vsom_set_stream) and ShardedBatchTrainer makes it
+        torch's current stream around every epoch()/flush(), so that kernels and collectives are
+        ordered on ONE stream whatever stream the caller happens to be on."""
         self.ctx = ctx
         self.device = torch.device(device)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        ctx.set_stream(self.stream.cuda_stream)
         self.N = ctx.n_nodes
         self.pitch = ctx.pitch
         self._bind_state()
+
+    def stream_scope(self):
+        return torch.cuda.stream(self.stream)
 
     def _bind_state(self):
         c, n, p, dev = self.ctx, self.N, self.pitch, self.device
@@ -89,7 +100,8 @@ def _gather_rows(t, world, rank, group=None, async_op=False):
     pending = []
     if total % world == 0:
         lo, hi = shard_bounds(total, world, rank)
-        src = t[lo:hi].clone()
+        # RCCL gathers in place (the input is this rank's slot of the output); gloo gets a copy
+        src = t[lo:hi] if dist.get_backend(group) == "nccl" else t[lo:hi].clone()
         w = dist.all_gather_into_tensor(t, src, group=group, async_op=async_op)
         if async_op:
             pending.append((w, src))
@@ -111,13 +123,23 @@ class ShardedBatchTrainer:
         self.e, self.rank, self.world, self.group = engine, rank, world, group
         self._pending = []
 
+    def _scope(self):
+        # engines that own a device stream (HipEngine) run kernels AND collectives on it
+        scope = getattr(self.e, "stream_scope", None)
+        return scope() if scope is not None else contextlib.nullcontext()
+
     def flush(self):
         """Wait for the sigmaMap / weightMap gathers of the last epoch (call before reading state)."""
-        for work, _keep in self._pending:
-            work.wait()
+        with self._scope():
+            for work, _keep in self._pending:
+                work.wait()
         self._pending = []
 
     def epoch(self, sigma, is_first):
+        with self._scope():
+            self._epoch(sigma, is_first)
+
+    def _epoch(self, sigma, is_first):
         e, w, r = self.e, self.world, self.rank
         s0, s1 = shard_bounds(e.B, w, r)
         e.phase1(s0, s1, is_first)
@@ -131,19 +153,3 @@ class ShardedBatchTrainer:
         # sigmaMap / weightMap are not read by the next phase 1: gather them behind it
         self._pending += _gather_rows(e.sigma_rows, w, r, self.group, async_op=True)
         self._pending += _gather_rows(e.weight, w, r, self.group, async_op=True)
-
-
-class OracleEngineBase:
-    """Shape of the engine interface (documentation; the oracle-backed engine lives in tests/)."""
-    B = 0
-    N = 0
-    lastbmu = sqres = map_rows = sigma_rows = weight = None
-
-    def phase1(self, s0, s1, is_first):
-        raise NotImplementedError
-
-    def finish(self):
-        raise NotImplementedError
-
-    def phase2(self, sigma, n0, n1):
-        raise NotImplementedError

@@ -255,7 +255,14 @@ class Som:
         dataset.lastBMU[...] = self.ctx.get_last_bmu()
         return mse
 
+    @staticmethod
+    def _no_umatrix(updateUMatrixAfterEpoch):
+        if updateUMatrixAfterEpoch:
+            raise NotImplementedError("updateUMatrixAfterEpoch: the Python mirror has no updateUMatrix "
+                                      "(Som.cpp:999-1111); the C++ mirror (host/, Som::updateUMatrix) implements it")
+
     def trainBatchSom(self, data, numberOfEpochs, sigma0, sigmaDecay, updateUMatrixAfterEpoch=False):
+        self._no_umatrix(updateUMatrixAfterEpoch)
         self.metrics = Metrics(numberOfEpochs)                    # :719
         for i in range(numberOfEpochs):
             if self._verbose:
@@ -280,6 +287,7 @@ class Som:
 
     def trainBasicSom(self, data, numberOfEpochs, eta0, etaDecay, sigma0, sigmaDecay,
                       weightDecayFunction, updateUMatrixAfterEpoch=False):
+        self._no_umatrix(updateUMatrixAfterEpoch)
         self.metrics = Metrics(numberOfEpochs)
         for i in range(numberOfEpochs):
             eta = eta0 * math.exp(-etaDecay * float(i))           # :1145
