@@ -208,6 +208,48 @@ int vsom_train_online_chunk(vsom_ctx *ctx, double eta, double sigma, int decay_f
 int vsom_train_online_chunk_acc(vsom_ctx *ctx, double eta, double sigma, int decay_fn, int first_chunk,
                                 float *mse_out);
 
+/* ---- multi-GPU batch epoch, one process, the GPUs of one node ------------------------
+ * Som::trainBatchSomEpoch's two loops shard differently: phase 1 (Som.cpp:764-782 / 786-805) is
+ * independent per SAMPLE, phase 2 (Som.cpp:809-876) is independent per NODE but sequential in samples
+ * (the variance accumulator uses the prefix mean).  A group holds one context per device, each with
+ * the whole map and the whole chunk; an epoch runs phase 1 on the device's samples, all-gathers
+ * lastBMU / ||residual||^2, forms bmuHits and the MSE on every device, runs phase 2 on the device's
+ * nodes and all-gathers the new map rows (sigmaMap / weightMap rows follow on a second stream behind the
+ * next search).  Every device ends with the bit-identical state of the single-GPU epoch.
+ * Transport: RCCL over xGMI (librccl is bound at run time; ncclCommInitAll over the devices);
+ * VSOM_GROUP_TRANSPORT=peer, or a device list that repeats a device (rehearsal of the N > 1 flow on a
+ * one-GPU box, which RCCL refuses), uses ordered peer copies instead.
+ * devices = NULL means devices 0 .. ndev-1; ndev = 0 means every visible device.
+ * vsom_group_ctx(g, r) exposes a member for the single-context calls (searches, getters): call
+ * vsom_group_synchronize first, and write state only through vsom_group_set_state.               */
+typedef struct vsom_group vsom_group;
+int vsom_group_create(vsom_group **out, int ndev, const int *devices, uint32_t width, uint32_t height,
+                      uint32_t in_len, int transform);
+void vsom_group_destroy(vsom_group *g);
+int vsom_group_size(const vsom_group *g);
+vsom_ctx *vsom_group_ctx(vsom_group *g, int rank);
+const char *vsom_group_transport(const vsom_group *g);   /* "rccl" or "peer" */
+int vsom_group_synchronize(vsom_group *g);
+int vsom_group_set_state(vsom_group *g, const float *map, const float *sigma, const float *S,
+                         const float *weight, const uint64_t *bmu_hits);
+int vsom_group_get_state(vsom_group *g, float *map, float *sigma, float *S, float *weight,
+                         uint64_t *bmu_hits);
+int vsom_group_set_update_mode(vsom_group *g, int mode);
+int vsom_group_set_bmu_mode(vsom_group *g, int mode);
+/* DataSet::loadNextDataFromStream for the group: every device copies ITS 1/n of the rows from the host
+ * and the rest arrives by all-gather; upload = prefetch + commit + wait (same contract as the
+ * single-context calls above) */
+int vsom_group_upload_chunk(vsom_group *g, const float *x_host, size_t B);
+int vsom_group_prefetch_chunk(vsom_group *g, const float *x_host, size_t B);
+int vsom_group_prefetch_wait(vsom_group *g);
+int vsom_group_commit_chunk(vsom_group *g);
+int vsom_group_set_last_bmu(vsom_group *g, const uint64_t *in_host);
+int vsom_group_get_last_bmu(vsom_group *g, uint64_t *out_host);
+/* Som::trainBatchSomEpoch (Som.cpp:756-879) over the group */
+int vsom_group_batch_epoch_async(vsom_group *g, double sigma, int is_first);
+int vsom_group_batch_epoch(vsom_group *g, double sigma, int is_first, float *mse_out);
+int vsom_group_get_mse(vsom_group *g, float *mse_out);
+
 /* ---- static helper: Som::calculateNeighbourhoodWeight (Som.cpp:949-975) ---------------- */
 double vsom_neighbourhood_weight(size_t cx, size_t cy, size_t bx, size_t by, double sigma);
 

@@ -110,14 +110,26 @@ def _asm_cases(n, seed):
 ASM_CASES = _asm_cases(int(os.environ.get("VSOM_ASM_SWEEP_N", "8")), int(os.environ.get("VSOM_SWEEP_SEED", "20240611")))
 
 
+@pytest.mark.parametrize("tr", [po.STANDARD, po.MEDIAN], ids=["std", "median"])
 @pytest.mark.parametrize("name,W,H,J,B,sigma,seed", ASM_CASES, ids=[c[0] for c in ASM_CASES])
-def test_random_shape_assembly_update(name, W, H, J, B, sigma, seed):
+def test_random_shape_assembly_update(name, W, H, J, B, sigma, seed, tr):
     rs = np.random.RandomState(seed)
     X = (rs.randn(B, J) * rs.choice([0.1, 1.0, 50.0])).astype(np.float32)
     X[rs.rand(B, J) < 0.1] = 0.0
     init = gen.random_map(W * H, J, seed=seed % 1000)
-    ctx = vsom_amd.Context(W, H, J, po.STANDARD)
-    orc = po.OracleSom(W, H, J, po.STANDARD)
+    if tr == po.MEDIAN:
+        # what the packed sign of the Median kernels (clamped multiplications, gen_update_asm.py) must get
+        # right: -0, denormal and huge differences, +-inf and NaN samples, x == M exactly
+        X[rs.rand(B, J) < 0.02] = -0.0
+        X[rs.rand(B, J) < 0.01] = np.float32(1e-42)
+        X[rs.rand(B, J) < 0.01] = np.float32(-3e-45)
+        X[rs.rand(B, J) < 0.01] = np.float32(3e38)
+        X[rs.rand(B, J) < 0.002] = np.inf
+        X[rs.rand(B, J) < 0.002] = -np.inf
+        X[rs.rand(B, J) < 0.002] = np.nan
+        init[rs.rand(*init.shape) < 0.05] = 0.0
+    ctx = vsom_amd.Context(W, H, J, tr)
+    orc = po.OracleSom(W, H, J, tr)
     ctx.set_state(map=init)
     orc.set_state(map=init)
     lb = np.zeros(B, np.uint64)
@@ -141,4 +153,32 @@ def test_random_shape_assembly_update(name, W, H, J, B, sigma, seed):
     st = ctx.get_state()
     for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("weight", orc.weight), ("hits", orc.hits)):
         assert _same(st[k], ref), (name, "sharded " + k)
+    ctx.close()
+
+
+@pytest.mark.parametrize("tr", [po.STANDARD, po.MEDIAN], ids=["std", "median"])
+@pytest.mark.parametrize("B", [1, 2, 3, 7, 8, 9])
+def test_shortest_chunks_on_the_assembly_update_path(B, tr):
+    """B = 1, 2: the assembly kernels' ring of (c,w) loads and the x-row read-ahead reach past the chunk
+    from the first instruction on (VSOM_ROW_PAD spare rows, ceil(B/2)+8 pair rows); 48x48x128 is past the
+    chain-kernel threshold, so lane = node assembly kernels run."""
+    W = H = 48
+    J = 128
+    rs = np.random.RandomState(100 + B)
+    X = rs.randn(B, J).astype(np.float32)
+    init = gen.random_map(W * H, J, seed=7)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    orc = po.OracleSom(W, H, J, tr)
+    ctx.set_state(map=init)
+    orc.set_state(map=init)
+    # a longer chunk first: the spare rows behind the short one then hold stale samples, not zeros
+    ctx.upload_chunk(rs.randn(64, J).astype(np.float32))
+    ctx.upload_chunk(X)
+    lb = np.zeros(B, np.uint64)
+    mse_o = orc.batch_epoch(X, lb, 6.0, True)
+    mse_g = ctx.batch_epoch(6.0, True)
+    assert _same(ctx.get_last_bmu(), lb) and _same(np.float32(mse_g), np.float32(mse_o))
+    st = ctx.get_state()
+    for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("weight", orc.weight), ("hits", orc.hits)):
+        assert _same(st[k], ref), (B, k)
     ctx.close()

@@ -5,4 +5,4 @@ at the repository root (or importlib.import_module("variational-self-organizing-
 """
 from . import capi  # noqa: F401
 from .capi import (BATCHMAP, CLR, EXPONENTIAL, INVERSE_PROPORTIONAL, MEDIAN, STANDARD,  # noqa: F401
-                   Context, VsomError)
+                   Context, Group, VsomError)

@@ -33,6 +33,11 @@ SYMBOLS = [
     "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk", "vsom_train_online_chunk_acc",
     "vsom_neighbourhood_weight", "vsom_device_ptr", "vsom_chunk_size", "vsom_pitch",
     "vsom_chunk_pitch", "vsom_enable_timing", "vsom_get_timing",
+    "vsom_group_create", "vsom_group_destroy", "vsom_group_size", "vsom_group_ctx", "vsom_group_transport",
+    "vsom_group_synchronize", "vsom_group_set_state", "vsom_group_get_state", "vsom_group_set_update_mode",
+    "vsom_group_set_bmu_mode", "vsom_group_upload_chunk", "vsom_group_prefetch_chunk", "vsom_group_prefetch_wait",
+    "vsom_group_commit_chunk", "vsom_group_set_last_bmu", "vsom_group_get_last_bmu",
+    "vsom_group_batch_epoch_async", "vsom_group_batch_epoch", "vsom_group_get_mse",
 ]
 
 
@@ -119,6 +124,28 @@ def lib():
     L.vsom_device_ptr.restype = vp
     L.vsom_enable_timing.argtypes = [vp, C.c_int]
     L.vsom_get_timing.argtypes = [vp, fp, C.POINTER(C.c_uint32), C.c_int]
+    L.vsom_group_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.vsom_group_destroy.argtypes = [vp]
+    L.vsom_group_destroy.restype = None
+    L.vsom_group_size.argtypes = [vp]
+    L.vsom_group_ctx.argtypes = [vp, C.c_int]
+    L.vsom_group_ctx.restype = vp
+    L.vsom_group_transport.argtypes = [vp]
+    L.vsom_group_transport.restype = C.c_char_p
+    L.vsom_group_synchronize.argtypes = [vp]
+    L.vsom_group_set_state.argtypes = [vp, fp, fp, fp, fp, u64p]
+    L.vsom_group_get_state.argtypes = [vp, fp, fp, fp, fp, u64p]
+    L.vsom_group_set_update_mode.argtypes = [vp, C.c_int]
+    L.vsom_group_set_bmu_mode.argtypes = [vp, C.c_int]
+    L.vsom_group_upload_chunk.argtypes = [vp, fp, C.c_size_t]
+    L.vsom_group_prefetch_chunk.argtypes = [vp, fp, C.c_size_t]
+    L.vsom_group_prefetch_wait.argtypes = [vp]
+    L.vsom_group_commit_chunk.argtypes = [vp]
+    L.vsom_group_set_last_bmu.argtypes = [vp, u64p]
+    L.vsom_group_get_last_bmu.argtypes = [vp, u64p]
+    L.vsom_group_batch_epoch_async.argtypes = [vp, C.c_double, C.c_int]
+    L.vsom_group_batch_epoch.argtypes = [vp, C.c_double, C.c_int, fp]
+    L.vsom_group_get_mse.argtypes = [vp, fp]
     _lib = L
     return L
 
@@ -176,10 +203,14 @@ class PinnedBuffer:
 class Context:
     """RAII wrapper of a vsom_ctx (one per GPU)."""
 
-    def __init__(self, width, height, in_len, transform=STANDARD, device=0):
-        self._h = C.c_void_p()
-        check(lib().vsom_create(C.byref(self._h), int(device), int(width), int(height), int(in_len),
-                                int(transform)))
+    def __init__(self, width, height, in_len, transform=STANDARD, device=0, _borrowed=None):
+        self._owned = _borrowed is None
+        if _borrowed is None:
+            self._h = C.c_void_p()
+            check(lib().vsom_create(C.byref(self._h), int(device), int(width), int(height), int(in_len),
+                                    int(transform)))
+        else:
+            self._h = C.c_void_p(_borrowed)       # a member of a Group: the group owns it
         self.width, self.height, self.in_len = int(width), int(height), int(in_len)
         self.transform, self.device = int(transform), int(device)
         self.depth = int(lib().vsom_depth(self._h))
@@ -189,7 +220,8 @@ class Context:
 
     def close(self):
         if self._h:
-            lib().vsom_destroy(self._h)
+            if self._owned:
+                lib().vsom_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -382,3 +414,110 @@ class Context:
         cnt = (C.c_uint32 * T_COUNT)()
         check(lib().vsom_get_timing(self._h, ms, cnt, int(bool(reset))))
         return {TIMER_NAMES[i]: (float(ms[i]), int(cnt[i])) for i in range(T_COUNT)}
+
+
+class Group:
+    """RAII wrapper of a vsom_group: Som::trainBatchSomEpoch over several GPUs from one process
+    (include/vsom_hip.h, "multi-GPU batch epoch").  devices=None: devices 0..ndev-1; a list that repeats
+    a device rehearses the N > 1 flow on one GPU (peer-copy transport)."""
+
+    def __init__(self, width, height, in_len, transform=STANDARD, ndev=0, devices=None):
+        self._h = C.c_void_p()
+        devs = None
+        if devices is not None:
+            ndev = len(devices)
+            devs = (C.c_int * ndev)(*[int(d) for d in devices])
+        check(lib().vsom_group_create(C.byref(self._h), int(ndev), devs, int(width), int(height), int(in_len),
+                                      int(transform)))
+        self.size = int(lib().vsom_group_size(self._h))
+        self.transport = lib().vsom_group_transport(self._h).decode()
+        self.width, self.height, self.in_len, self.transform = int(width), int(height), int(in_len), int(transform)
+        c0 = self.member(0)
+        self.depth, self.n_nodes = c0.depth, c0.n_nodes
+
+    def member(self, rank):
+        h = lib().vsom_group_ctx(self._h, int(rank))
+        if not h:
+            raise VsomError("rank out of range")
+        return Context(self.width, self.height, self.in_len, self.transform, _borrowed=h)
+
+    def close(self):
+        if self._h:
+            lib().vsom_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib().vsom_group_synchronize(self._h))
+
+    def set_update_mode(self, mode):
+        check(lib().vsom_group_set_update_mode(self._h, int(mode)))
+
+    def set_bmu_mode(self, mode):
+        check(lib().vsom_group_set_bmu_mode(self._h, int(mode)))
+
+    def set_state(self, map=None, sigma=None, S=None, weight=None, hits=None):
+        n, d = self.n_nodes, self.depth
+
+        def f2(a, size):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            assert a.size == size, (a.shape, size)
+            return a
+
+        m, s, ss, w = f2(map, n * d), f2(sigma, n * d), f2(S, n * d), f2(weight, n)
+        h = None if hits is None else np.ascontiguousarray(hits, dtype=np.uint64)
+        check(lib().vsom_group_set_state(self._h, _f(m), _f(s), _f(ss), _f(w), _u(h)))
+
+    def get_state(self):
+        n, d = self.n_nodes, self.depth
+        m, s, ss = (np.empty((n, d), np.float32) for _ in range(3))
+        w, h = np.empty(n, np.float32), np.empty(n, np.uint64)
+        check(lib().vsom_group_get_state(self._h, _f(m), _f(s), _f(ss), _f(w), _u(h)))
+        return {"map": m, "sigma": s, "S": ss, "weight": w, "hits": h}
+
+    def upload_chunk(self, X):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        assert X.ndim == 2 and X.shape[1] == self.in_len, (X.shape, self.in_len)
+        self._B = X.shape[0]
+        check(lib().vsom_group_upload_chunk(self._h, _f(X), X.shape[0]))
+
+    def prefetch_chunk(self, X):
+        """X must stay alive (and unchanged) until commit_chunk/prefetch_wait; pinned memory makes it asynchronous"""
+        assert X.dtype == np.float32 and X.flags["C_CONTIGUOUS"] and X.shape[1] == self.in_len
+        self._B = X.shape[0]
+        check(lib().vsom_group_prefetch_chunk(self._h, _f(X), X.shape[0]))
+
+    def prefetch_wait(self):
+        check(lib().vsom_group_prefetch_wait(self._h))
+
+    def commit_chunk(self):
+        check(lib().vsom_group_commit_chunk(self._h))
+
+    def set_last_bmu(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.uint64)
+        check(lib().vsom_group_set_last_bmu(self._h, _u(idx)))
+
+    def get_last_bmu(self):
+        out = np.empty(self._B, np.uint64)
+        check(lib().vsom_group_get_last_bmu(self._h, _u(out)))
+        return out
+
+    def batch_epoch_async(self, sigma, is_first):
+        check(lib().vsom_group_batch_epoch_async(self._h, float(sigma), int(bool(is_first))))
+
+    def batch_epoch(self, sigma, is_first):
+        mse = C.c_float()
+        check(lib().vsom_group_batch_epoch(self._h, float(sigma), int(bool(is_first)), C.byref(mse)))
+        return np.float32(mse.value)
+
+    def get_mse(self):
+        mse = C.c_float()
+        check(lib().vsom_group_get_mse(self._h, C.byref(mse)))
+        return np.float32(mse.value)

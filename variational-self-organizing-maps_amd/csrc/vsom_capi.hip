@@ -61,6 +61,73 @@ static inline uint32_t roundup(uint32_t v, uint32_t m) { return (v + m - 1) / m 
             return vsom_fail(VSOM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_e)); \
     } while (0)
 
+// ---- pieces of the double-buffered ingest shared with the multi-GPU group (vsom_group.hip) -------------
+// Rows [r0,r1) of a B-row host chunk -> the same rows of the context's NEXT raw device buffer, on the
+// copy stream (a group copies each device's shard only and all-gathers the rest over xGMI).
+int vsom_prefetch_rows(vsom_ctx *c, const float *x_host, size_t B, size_t r0, size_t r1)
+{
+    CHECK_CTX_NOJOIN(c);
+    if (B > 0 && !x_host)
+        return vsom_fail(VSOM_ERR_INVALID, "x_host is null");
+    if (B > 0x7FFFFFFFull)
+        return vsom_fail(VSOM_ERR_INVALID, "chunk too large");
+    if (r0 > r1 || r1 > B)
+        return vsom_fail(VSOM_ERR_INVALID, "row range out of bounds");
+    const int k = c->next_slot;
+    const size_t need = B * c->J;
+    // the staging kernels of the chunk committed from this slot two prefetches ago must be done
+    if (c->staged_valid[k])
+        VSOM_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_staged[k], 0));
+    if (need > c->Xnext_cap[k]) {
+        if (c->staged_valid[k])
+            VSOM_HIP_CHECK(hipEventSynchronize(c->ev_staged[k]));
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+        if (c->Xnext[k])
+            (void)hipFree(c->Xnext[k]);
+        c->Xnext[k] = nullptr;
+        c->Xnext_cap[k] = 0;
+        VSOM_HIP_CHECK(hipMalloc(&c->Xnext[k], need * 4));
+        c->Xnext_cap[k] = need;
+    }
+    if (r1 > r0)
+        VSOM_HIP_CHECK(hipMemcpyAsync(c->Xnext[k] + r0 * c->J, x_host + r0 * c->J, (r1 - r0) * c->J * 4,
+                                      hipMemcpyHostToDevice, c->copy_stream));
+    VSOM_HIP_CHECK(hipEventRecord(c->ev_copied[k], c->copy_stream));
+    c->Bnext = B;
+    c->ready_slot = k;
+    c->next_slot = k ^ 1;
+    return VSOM_OK;
+}
+
+// first half of vsom_commit_chunk: the compute stream waits for the copy; *raw = the B x J rows
+int vsom_commit_begin(vsom_ctx *c, float **raw, size_t *B)
+{
+    CHECK_CTX(c);
+    if (c->ready_slot < 0)
+        return vsom_fail(VSOM_ERR_INVALID, "no prefetched chunk to commit");
+    const int k = c->ready_slot;
+    VSOM_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_copied[k], 0));
+    *raw = c->Xnext[k];
+    *B = c->Bnext;
+    return VSOM_OK;
+}
+
+// second half: stage the rows (lastBMU := 0) and mark the slot reusable once staging has read it
+int vsom_commit_end(vsom_ctx *c)
+{
+    CHECK_CTX(c);
+    if (c->ready_slot < 0)
+        return vsom_fail(VSOM_ERR_INVALID, "no prefetched chunk to commit");
+    const int k = c->ready_slot;
+    c->ready_slot = -1;
+    int rc = vsom_set_chunk_device(c, c->Xnext[k], c->Bnext);
+    if (rc)
+        return rc;
+    VSOM_HIP_CHECK(hipEventRecord(c->ev_staged[k], c->stream));
+    c->staged_valid[k] = true;
+    return VSOM_OK;
+}
+
 extern "C" {
 
 const char *vsom_last_error(void) { return g_last_error.c_str(); }
@@ -458,34 +525,7 @@ int vsom_host_free(void *p)
 
 int vsom_prefetch_chunk(vsom_ctx *c, const float *x_host, size_t B)
 {
-    CHECK_CTX_NOJOIN(c);
-    if (B > 0 && !x_host)
-        return vsom_fail(VSOM_ERR_INVALID, "x_host is null");
-    if (B > 0x7FFFFFFFull)
-        return vsom_fail(VSOM_ERR_INVALID, "chunk too large");
-    const int k = c->next_slot;
-    const size_t need = B * c->J;
-    // the staging kernels of the chunk committed from this slot two prefetches ago must be done
-    if (c->staged_valid[k])
-        VSOM_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_staged[k], 0));
-    if (need > c->Xnext_cap[k]) {
-        if (c->staged_valid[k])
-            VSOM_HIP_CHECK(hipEventSynchronize(c->ev_staged[k]));
-        VSOM_HIP_CHECK(hipStreamSynchronize(c->copy_stream));
-        if (c->Xnext[k])
-            (void)hipFree(c->Xnext[k]);
-        c->Xnext[k] = nullptr;
-        c->Xnext_cap[k] = 0;
-        VSOM_HIP_CHECK(hipMalloc(&c->Xnext[k], need * 4));
-        c->Xnext_cap[k] = need;
-    }
-    if (need)
-        VSOM_HIP_CHECK(hipMemcpyAsync(c->Xnext[k], x_host, need * 4, hipMemcpyHostToDevice, c->copy_stream));
-    VSOM_HIP_CHECK(hipEventRecord(c->ev_copied[k], c->copy_stream));
-    c->Bnext = B;
-    c->ready_slot = k;
-    c->next_slot = k ^ 1;
-    return VSOM_OK;
+    return vsom_prefetch_rows(c, x_host, B, 0, B);
 }
 
 int vsom_prefetch_wait(vsom_ctx *c)
@@ -497,18 +537,12 @@ int vsom_prefetch_wait(vsom_ctx *c)
 
 int vsom_commit_chunk(vsom_ctx *c)
 {
-    CHECK_CTX(c);
-    if (c->ready_slot < 0)
-        return vsom_fail(VSOM_ERR_INVALID, "no prefetched chunk to commit");
-    const int k = c->ready_slot;
-    c->ready_slot = -1;
-    VSOM_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_copied[k], 0));
-    int rc = vsom_set_chunk_device(c, c->Xnext[k], c->Bnext);
+    float *raw = nullptr;
+    size_t B = 0;
+    int rc = vsom_commit_begin(c, &raw, &B);
     if (rc)
         return rc;
-    VSOM_HIP_CHECK(hipEventRecord(c->ev_staged[k], c->stream));
-    c->staged_valid[k] = true;
-    return VSOM_OK;
+    return vsom_commit_end(c);
 }
 
 int vsom_get_last_bmu(vsom_ctx *c, uint64_t *out_host)

@@ -94,7 +94,7 @@ struct vsom_ctx {
 
     // hand-scheduled update kernel (code object loaded with hipModuleLoadData)
     void *upd_module = nullptr, *upd_fn16 = nullptr, *upd_fn14 = nullptr, *upd_fma16 = nullptr, *upd_fma14 = nullptr,
-         *upd_clr8 = nullptr;
+         *upd_clr8 = nullptr, *upd_med16 = nullptr, *upd_med14 = nullptr;
     int update_mode = VSOM_UPDATE_STRICT;
     bool use_asm = true;
     bool use_chain = true;
@@ -135,6 +135,10 @@ struct TimerScope {
 
 // kernel launchers (each enqueues on ctx->stream and returns a vsom_status) -------------------
 int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B);
+// pieces of the double-buffered ingest shared with the multi-GPU group (vsom_capi.hip)
+int vsom_prefetch_rows(vsom_ctx *c, const float *x_host, size_t B, size_t r0, size_t r1);
+int vsom_commit_begin(vsom_ctx *c, float **raw, size_t *B);
+int vsom_commit_end(vsom_ctx *c);
 int launch_bmu_full(vsom_ctx *c, size_t s0, size_t s1);           // findBmu for samples [s0,s1)
 int launch_bmu_local(vsom_ctx *c, size_t s0, size_t s1);          // findLocalBmu
 int launch_pair_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *rows_dev, size_t count,

@@ -761,18 +761,22 @@ int vsom_load_asm_module(vsom_ctx *c)
         return VSOM_OK;
     hipModule_t mod;
     VSOM_HIP_CHECK(hipModuleLoadData(&mod, vsom_update_hsaco));
-    hipFunction_t f16, f14, m16, m14, fclr;
+    hipFunction_t f16, f14, m16, m14, fclr, d16, d14;
     VSOM_HIP_CHECK(hipModuleGetFunction(&f16, mod, "vsom_update_std_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&f14, mod, "vsom_update_std_rd14_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&m16, mod, "vsom_update_fma_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&m14, mod, "vsom_update_fma_rd14_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&fclr, mod, "vsom_update_clr_rp8_gfx950"));
+    VSOM_HIP_CHECK(hipModuleGetFunction(&d16, mod, "vsom_update_med_rd16_gfx950"));
+    VSOM_HIP_CHECK(hipModuleGetFunction(&d14, mod, "vsom_update_med_rd14_gfx950"));
     c->upd_module = mod;
     c->upd_fn16 = f16;
     c->upd_fn14 = f14;
     c->upd_fma16 = m16;
     c->upd_fma14 = m14;
     c->upd_clr8 = fclr;
+    c->upd_med16 = d16;
+    c->upd_med14 = d14;
     return VSOM_OK;
 }
 
@@ -1000,8 +1004,8 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         } else {
             constexpr int RD = 16;
             int dbase = 0;
-            if (c->transform == VSOM_STANDARD && c->use_asm) {
-                // hand-scheduled kernels, 16 or 14 dims per wavefront: the first n16 slices by the
+            if ((c->transform == VSOM_STANDARD || c->transform == VSOM_MEDIAN) && c->use_asm) {
+                // hand-scheduled kernels (Standard strict / contracted, Median), 16 or 14 dims per wavefront: the first n16 slices by the
                 // 16-wide kernel, the following n14 by the 14-wide one on the side stream (the two run
                 // concurrently; vsom_update_split picks the pair).  Columns past D are the zero padding
                 // of the rows; sigma_finalize_kernel re-zeroes them afterwards.
@@ -1010,6 +1014,9 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 unsigned n16 = 0, n14 = 0;
                 vsom_update_split(c->D, c->pitch < c->xpitch ? c->pitch : c->xpitch, n16, n14);
                 const bool fma = c->update_mode == VSOM_UPDATE_FMA;
+                const bool med = c->transform == VSOM_MEDIAN;     // its FMAs are exact: one kernel for both modes
+                void *const fn16 = med ? c->upd_med16 : (fma ? c->upd_fma16 : c->upd_fn16);
+                void *const fn14 = med ? c->upd_med14 : (fma ? c->upd_fma14 : c->upd_fn14);
                 auto launch = [&](void *fn, unsigned nsl, unsigned col0, hipStream_t st) -> int {
                     UpdAsmArgs a;
                     a.xs = c->Xs + col0;
@@ -1039,10 +1046,9 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                         VSOM_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
                         VSOM_HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
                     }
-                    if (n16 > 0 && (rc = launch(fma ? c->upd_fma16 : c->upd_fn16, n16, 0, c->stream)))
+                    if (n16 > 0 && (rc = launch(fn16, n16, 0, c->stream)))
                         return rc;
-                    if (n14 > 0 &&
-                        (rc = launch(fma ? c->upd_fma14 : c->upd_fn14, n14, n16 * 16, both ? c->aux_stream : c->stream)))
+                    if (n14 > 0 && (rc = launch(fn14, n14, n16 * 16, both ? c->aux_stream : c->stream)))
                         return rc;
                     if (both) {
                         VSOM_HIP_CHECK(hipEventRecord(c->ev_join, c->aux_stream));
