@@ -49,14 +49,22 @@ def beq(a, b):
     return (a == b).all()
 
 
-@pytest.fixture(scope="module")
-def dumps():
+# "single": one GPU.  "group3": VSOM_DEVICES=0,0,0 -- Som then trains through the vsom_group_* entry points
+# with three members on the one device (peer-copy transport; sample-sharded phase 1, node-sharded phase 2),
+# and every dump must still equal the oracle's
+@pytest.fixture(scope="module", params=["single", "group3"])
+def dumps(request):
     exe = os.path.join(HOST, "host_api_test")
     if not os.path.exists(exe):
         subprocess.check_call(["bash", os.path.join(HOST, "build.sh")], stdout=subprocess.DEVNULL)
     d = tempfile.mkdtemp(prefix="vsom_host_")
-    res = subprocess.run([exe, d], capture_output=True, text=True, timeout=300)
+    env = dict(os.environ)
+    env.pop("VSOM_DEVICES", None)
+    if request.param == "group3":
+        env["VSOM_DEVICES"] = "0,0,0"
+    res = subprocess.run([exe, d], capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode == 0, res.stdout + res.stderr
+    assert ("group_members=3" if request.param == "group3" else "group_members=1") in res.stdout
     return d, res.stdout, res.stderr
 
 

@@ -370,6 +370,7 @@ struct Transformation {
 #define SIGMA_SWITCH_TO_LOCAL 1
 
 struct vsom_ctx;
+struct vsom_group;
 
 class Som {
 protected:
@@ -477,10 +478,18 @@ public:
     void setState(const float *map, const float *sigma, const float *S, const float *weight, const uint64_t *hits);
     void getState(float *map, float *sigma, float *S, float *weight, uint64_t *hits) const;
     static void setDefaultDevice(int device);
+    // devices the batch-map training runs on: {} = all visible (or the list in VSOM_DEVICES), one entry =
+    // single GPU, several = sample/node-sharded epochs through vsom_group_* (vsom_host.cpp, training_devices)
+    static void setDevices(const std::vector<int> &devices);
     vsom_ctx *context() const noexcept { return ctx; }
+    vsom_group *group() const noexcept { return grp; }
 
 private:
-    vsom_ctx *ctx = nullptr;
+    vsom_ctx *ctx = nullptr;          // the context searches, getters and the online path use (member 0 of grp)
+    vsom_group *grp = nullptr;        // set when the Som trains on more than one GPU; owns ctx then
+    bool replicasStale = false;       // member 0 was trained alone (online path): the others lag behind
+    void destroyContext();
+    void syncReplicas();
     size_t inLen = 0;                 // J: sample length (depth = transform.Length(J))
     mutable bool hostStale = true;    // host mirrors below are out of date
     mutable std::vector<float> hMap, hSigma, hWeight;

@@ -447,6 +447,42 @@ void DataSet::shuffle() {}
 static int g_default_device = 0;
 void Som::setDefaultDevice(int device) { g_default_device = device; }
 
+// Devices a Som trains on.  Empty (default) = every visible device when the environment variable
+// VSOM_DEVICES is unset; VSOM_DEVICES="0,1,2,3" (or Som::setDevices) names them; a single entry keeps
+// the single-GPU path.  More than one entry makes the batch-map training members run through the
+// vsom_group_* entry points (phase 1 sample-sharded, phase 2 node-sharded, all-gathers over xGMI).
+// A list that repeats a device rehearses that flow on one GPU (the library then copies between the
+// members instead of calling RCCL, include/vsom_hip.h).
+static std::vector<int> g_devices;
+static bool g_devices_set = false;
+void Som::setDevices(const std::vector<int> &devices)
+{
+    g_devices = devices;
+    g_devices_set = true;
+}
+
+static std::vector<int> training_devices()
+{
+    if (g_devices_set)
+        return g_devices.empty() ? std::vector<int>{g_default_device} : g_devices;
+    std::vector<int> out;
+    if (const char *e = std::getenv("VSOM_DEVICES")) {
+        std::stringstream ss(e);
+        std::string tok;
+        while (std::getline(ss, tok, ','))
+            if (!tok.empty())
+                out.push_back(std::atoi(tok.c_str()));
+        if (!out.empty())
+            return out;
+    }
+    const int n = vsom_device_count();
+    if (n <= 1)
+        return {g_default_device};
+    for (int d = 0; d < n; ++d)
+        out.push_back(d);
+    return out;
+}
+
 static void check(int rc, const char *what)
 {
     if (rc != 0)
@@ -460,7 +496,39 @@ void Som::createContext()
         ctx = nullptr;   // state-less shell: accessors work on zeros, training throws
         return;
     }
-    check(vsom_create(&ctx, g_default_device, (uint32_t)width, (uint32_t)height, (uint32_t)inLen, kind), "vsom_create");
+    const std::vector<int> devs = training_devices();
+    if (devs.size() > 1) {
+        check(vsom_group_create(&grp, (int)devs.size(), devs.data(), (uint32_t)width, (uint32_t)height, (uint32_t)inLen, kind),
+              "vsom_group_create");
+        ctx = vsom_group_ctx(grp, 0);     // searches, getters and the online path use member 0 (the state is replicated)
+        replicasStale = false;
+        return;
+    }
+    check(vsom_create(&ctx, devs[0], (uint32_t)width, (uint32_t)height, (uint32_t)inLen, kind), "vsom_create");
+}
+
+void Som::destroyContext()
+{
+    if (grp)
+        vsom_group_destroy(grp);   // owns its members, ctx included
+    else if (ctx)
+        vsom_destroy(ctx);
+    grp = nullptr;
+    ctx = nullptr;
+}
+
+// the online members (trainSingle / trainBasicSom) train member 0 only -- that path is strictly sequential
+// in samples, "replicas only" -- so before the next sharded epoch the other members take over its state
+void Som::syncReplicas()
+{
+    if (!grp || !replicasStale)
+        return;
+    const size_t N = width * height;
+    std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
+    std::vector<uint64_t> hh(N);
+    check(vsom_get_state(ctx, m.data(), s.data(), S.data(), w.data(), hh.data()), "vsom_get_state");
+    check(vsom_group_set_state(grp, m.data(), s.data(), S.data(), w.data(), hh.data()), "vsom_group_set_state");
+    replicasStale = false;
 }
 
 void Som::requireDevicePath(const char *what) const
@@ -554,9 +622,7 @@ Som &Som::operator=(const Som &other)
 {
     if (this == &other)
         return *this;
-    if (ctx)
-        vsom_destroy(ctx);
-    ctx = nullptr;
+    destroyContext();
     transform = other.transform;
     uMatrix = other.uMatrix;
     height = other.height;
@@ -576,16 +642,15 @@ Som &Som::operator=(const Som &other)
     return *this;
 }
 
-Som::~Som()
-{
-    if (ctx)
-        vsom_destroy(ctx);
-}
+Som::~Som() { destroyContext(); }
 
 void Som::setState(const float *map, const float *sigma, const float *S, const float *weight, const uint64_t *hits)
 {
     requireDevicePath("setState");
-    check(vsom_set_state(ctx, map, sigma, S, weight, hits), "vsom_set_state");
+    if (grp)
+        check(vsom_group_set_state(grp, map, sigma, S, weight, hits), "vsom_group_set_state");
+    else
+        check(vsom_set_state(ctx, map, sigma, S, weight, hits), "vsom_set_state");
     hostStale = true;
 }
 
@@ -720,7 +785,10 @@ void Som::addBmu(SomIndex pos)   // Som.cpp:1189-1192
     std::vector<uint64_t> hh(N);
     check(vsom_get_state(ctx, nullptr, nullptr, nullptr, nullptr, hh.data()), "vsom_get_state");
     hh[getIndex(pos)] += 1;
-    check(vsom_set_state(ctx, nullptr, nullptr, nullptr, nullptr, hh.data()), "vsom_set_state");
+    if (grp && !replicasStale)
+        check(vsom_group_set_state(grp, nullptr, nullptr, nullptr, nullptr, hh.data()), "vsom_group_set_state");
+    else
+        check(vsom_set_state(ctx, nullptr, nullptr, nullptr, nullptr, hh.data()), "vsom_set_state");
     hostStale = true;
 }
 
@@ -789,16 +857,25 @@ float Som::trainBatchSomEpoch(DataSet &dataset, double currentSigma, bool isFirs
     // B == 0 is not skipped: the reference's epoch over an empty chunk still rewrites every neuron
     // (zero model vector, NaN sigma, zero weight -- Som.cpp:840-875), e.g. after the zero-row load that
     // ends every chunked MnistDataLoader pass
-    check(vsom_upload_chunk(ctx, dataset.contiguous(), B), "vsom_upload_chunk");
     std::vector<uint64_t> lb(B);
-    if (!isFirst) {
+    if (!isFirst)
         for (size_t s = 0; s < B; ++s)
             lb[s] = dataset.getLastBMU(s);
-        check(vsom_set_last_bmu(ctx, lb.data()), "vsom_set_last_bmu");
-    }
     float mse = 0.f;
-    check(vsom_batch_epoch(ctx, currentSigma, isFirst ? 1 : 0, &mse), "vsom_batch_epoch");
-    check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
+    if (grp) {   // several GPUs: samples sharded in phase 1, nodes in phase 2 (include/vsom_hip.h, vsom_group_*)
+        syncReplicas();
+        check(vsom_group_upload_chunk(grp, dataset.contiguous(), B), "vsom_group_upload_chunk");
+        if (!isFirst)
+            check(vsom_group_set_last_bmu(grp, lb.data()), "vsom_group_set_last_bmu");
+        check(vsom_group_batch_epoch(grp, currentSigma, isFirst ? 1 : 0, &mse), "vsom_group_batch_epoch");
+        check(vsom_group_get_last_bmu(grp, lb.data()), "vsom_group_get_last_bmu");
+    } else {
+        check(vsom_upload_chunk(ctx, dataset.contiguous(), B), "vsom_upload_chunk");
+        if (!isFirst)
+            check(vsom_set_last_bmu(ctx, lb.data()), "vsom_set_last_bmu");
+        check(vsom_batch_epoch(ctx, currentSigma, isFirst ? 1 : 0, &mse), "vsom_batch_epoch");
+        check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
+    }
     for (size_t s = 0; s < B; ++s)
         dataset.getLastBMU(s) = (size_t)lb[s];   // *data.lastBMU = index (Som.cpp:777,800)
     hostStale = true;
@@ -817,6 +894,28 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
     auto sigmaOf = [&](size_t e) { return sigma0 * std::exp(-sigmaDecay * static_cast<double>(e)); };   // :727
     bool have = false;                // a loaded chunk is waiting in `data`, its copy is in flight
     size_t B = 0;
+    // one GPU: the context's entry points; several: the group's (same contracts, include/vsom_hip.h)
+    syncReplicas();
+    auto prefetch = [&](const float *x, size_t n) {
+        check(grp ? vsom_group_prefetch_chunk(grp, x, n) : vsom_prefetch_chunk(ctx, x, n), "vsom_prefetch_chunk");
+    };
+    auto commit = [&] { check(grp ? vsom_group_commit_chunk(grp) : vsom_commit_chunk(ctx), "vsom_commit_chunk"); };
+    auto epochAsync = [&](double sg, int first) {
+        check(grp ? vsom_group_batch_epoch_async(grp, sg, first) : vsom_batch_epoch_async(ctx, sg, first), "vsom_batch_epoch_async");
+    };
+    auto lastBmu = [&](uint64_t *out) {
+        check(grp ? vsom_group_get_last_bmu(grp, out) : vsom_get_last_bmu(ctx, out), "vsom_get_last_bmu");
+    };
+    auto getMse = [&](float *out) { check(grp ? vsom_group_get_mse(grp, out) : vsom_get_mse(ctx, out), "vsom_get_mse"); };
+    // leaving (normally or by exception): the members' deferred sigmaMap / weightMap gathers are joined
+    struct Join {
+        vsom_group *g;
+        ~Join()
+        {
+            if (g)
+                (void)vsom_group_synchronize(g);
+        }
+    } join{grp};
     for (size_t i = 0; i < numberOfEpochs; ++i) {
         std::cout << "Training VSOM epoch " << i << "/" << numberOfEpochs << '\n';
         const auto sigma = sigmaOf(i);
@@ -827,7 +926,7 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
         if (!have && !data.hasReadWholeDataStream()) {   // :735 (the first chunk may already be in flight)
             data.loadNextDataFromStream();
             B = data.size();
-            check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+            prefetch(data.contiguous(), B);
             have = true;
         }
         // the next epoch will run (and therefore reload the stream from its start, :737,749)?
@@ -839,14 +938,14 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
         while (have) {
             const size_t Bcur = B;
             // (also for an empty chunk: the reference's epoch then zeroes the map, see trainBatchSomEpoch)
-            check(vsom_commit_chunk(ctx), "vsom_commit_chunk");   // lastBMU := 0 (DataSet.cpp:136-137)
-            check(vsom_batch_epoch_async(ctx, sigma, i == 0 ? 1 : 0), "vsom_batch_epoch_async");
+            commit();   // lastBMU := 0 (DataSet.cpp:136-137)
+            epochAsync(sigma, i == 0 ? 1 : 0);
             have = false;
             const bool last = data.hasReadWholeDataStream();
             if (!last) {
                 data.loadNextDataFromStream();   // host work beside the device epoch
                 B = data.size();
-                check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+                prefetch(data.contiguous(), B);
                 have = true;
             } else if (another) {
                 // last chunk of this epoch: load the next epoch's first chunk beside it (the BMUs of
@@ -854,17 +953,17 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
                 data.resetStreamLoadPosition();   // :749
                 data.loadNextDataFromStream();
                 B = data.size();
-                check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+                prefetch(data.contiguous(), B);
                 prefetchedNext = true;
             } else if (Bcur > 0) {
                 // the chunk still held by `data` when training ends keeps its BMUs (Som.cpp:777,800)
                 std::vector<uint64_t> lb(Bcur);
-                check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
+                lastBmu(lb.data());
                 for (size_t s = 0; s < Bcur; ++s)
                     data.getLastBMU(s) = (size_t)lb[s];
             }
             float mse = 0.f;
-            check(vsom_get_mse(ctx, &mse), "vsom_get_mse");
+            getMse(&mse);
             meanSquareError += mse;
             ++countDataChunks;
             if (last) {
@@ -908,6 +1007,7 @@ Som::TrainingReturnValue Som::trainSingle(const Eigen::VectorXf &v, const Eigen:
           "vsom_train_single");
     lastBMU = (size_t)lb;
     hostStale = true;
+    replicasStale = grp != nullptr;
     return TrainingReturnValue{SomIndex((size_t)bmu % width, (size_t)bmu / width), residual, dist};
 }
 
@@ -915,6 +1015,10 @@ void Som::trainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, doubl
                         double sigmaDecay, WeigthDecayFunction weightDecayFunction, bool updateUMatrixAfterEpoch)
 {
     requireDevicePath("trainBasicSom");
+    if (grp) {
+        check(vsom_group_synchronize(grp), "vsom_group_synchronize");
+        replicasStale = true;                 // the online path trains member 0 only (sequential in samples)
+    }
     metrics = Som::Metrics(numberOfEpochs);   // Som.cpp:1139
     for (size_t i = 0; i < numberOfEpochs; ++i) {
         auto eta = eta0 * std::exp(-etaDecay * static_cast<double>(i));         // :1145
@@ -1273,9 +1377,7 @@ Eigen::VectorXf Som::getSizeFromFile(const char *fileName)
         width = w;
         height = h;
         uMatrix.assign(width * height, 0.0);
-        if (ctx)
-            vsom_destroy(ctx);
-        ctx = nullptr;
+        destroyContext();
         createContext();
         hostStale = true;
     }
@@ -1295,9 +1397,7 @@ void Som::load(const char *fileName)
     uint64_t hdr[6] = {0, 0, 0, 0, 0, 0};
     f.read((char *)hdr, sizeof(hdr));
     if (f && hdr[0] == 0x314d4f5356ull) {
-        if (ctx)
-            vsom_destroy(ctx);
-        ctx = nullptr;
+        destroyContext();
         width = hdr[1];
         height = hdr[2];
         depth = hdr[3];

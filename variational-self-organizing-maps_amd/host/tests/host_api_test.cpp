@@ -4,6 +4,7 @@
 // Writes the resulting state to binary dumps that tests/test_gpu_host_cpp.py compares with the oracle.
 //   usage: host_api_test <outdir>
 #include "SOM.hpp"
+#include "vsom_hip.h"
 #include "DataSet.hpp"
 #include "Transformation.hpp"
 #include "MnistDataLoader.hpp"
@@ -150,6 +151,7 @@ int main(int argc, char **argv)
         DataSet ds(loader);
         Som som{W, H, ds, Transformation::Standard(loader.getNames())};
         som.randomInitialize(42, 1);
+        std::cout << "group_members=" << (som.group() ? vsom_group_size(som.group()) : 1) << "\n";
         som.train(ds, 5, 0.001, 0.01, 10.0, 0.3, Som::WeigthDecayFunction::BatchMap);
         auto met = som.getMetrics();
         dump(out + "/batch_std.bin", som, met.MeanSquaredError);
