@@ -188,10 +188,11 @@ def test_mnist_loader_to_batch_training_end_to_end(tmp_path):
     assert (dump["map"] == 0).all() and np.isnan(dump["sigma"]).all()    # the empty chunk's doing
 
 
-def test_custom_transformation_is_rejected_not_emulated(dumps):
+def test_custom_transformation_trains_on_the_host_without_a_device_context(dumps):
+    """caller-supplied hooks: no device context, training on the host (tests/test_host_custom.py holds that
+    path to the oracle), consumers outside training throw"""
     _, out, err = dumps
-    assert "custom_transformation_rejected=1 kind=-1" in out
-    assert "no CPU fallback" in err
+    assert "custom_transformation_host_path=1 consumers_throw=1 kind=-1" in out, out + err
 
 
 def test_next_rows_restricted_bmu_bmd_umatrix_evaluate(dumps):

@@ -300,9 +300,11 @@ public:
 //
 // [MI355X build] the std::function hooks cannot run on the device.  The three built-in
 // transformations are recognised by the *type* of the callable stored in Comparer/Stepper
-// (vsom::*Comparer / vsom::*Stepper below) and run as HIP kernels; any other callable makes the
-// training entry points of Som throw (no CPU fallback).  The functors also work on the host, so
-// code that calls transform.Comparer(...) directly keeps working.
+// (vsom::*Comparer / vsom::*Stepper below) and run as HIP kernels -- they have no host training path.
+// Any other callable (a caller's own lambdas, tests/test1.cpp:56-84) makes the Som keep its state on the
+// host and run distance / search / batch epoch / online step there with the caller's hooks
+// (src/vsom_custom.cpp); the consumers outside training (U-matrix, evaluate, ...) then throw.  The
+// built-in functors also work on the host, so code that calls transform.Comparer(...) directly keeps working.
 
 #include <functional>
 #include <sstream>
@@ -494,6 +496,19 @@ private:
     mutable bool hostStale = true;    // host mirrors below are out of date
     mutable std::vector<float> hMap, hSigma, hWeight;
     mutable std::vector<uint64_t> hHits;
+    // host execution for user-supplied hooks (kind() == vsom::Custom; src/vsom_custom.cpp): the state then
+    // lives in hMap / hSigma / hS / hWeight / hHits and ctx stays null
+    mutable std::vector<float> hS;
+    void hostEnsure() const;
+    double hostDist(size_t pos, const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const Eigen::VectorXf &weights) const;
+    size_t hostFindBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const Eigen::VectorXf &weights) const;
+    size_t hostFindLocalBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, size_t start, const Eigen::VectorXf &weights) const;
+    float hostBatchEpoch(DataSet &dataset, double currentSigma, bool isFirst);
+    void hostTrainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, double sigmaDecay, bool updateUMatrixAfterEpoch);
+    TrainingReturnValue hostTrainSingle(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const Eigen::VectorXf &weights,
+                                        double eta, double sigma, size_t &lastBMU, WeigthDecayFunction fn);
+    void hostTrainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, double etaDecay, double sigma0, double sigmaDecay,
+                           WeigthDecayFunction fn, bool updateUMatrixAfterEpoch);
     void createContext();
     void requireDevicePath(const char *what) const;
     void refreshHost() const;

@@ -536,8 +536,8 @@ void Som::requireDevicePath(const char *what) const
     if (!ctx)
         throw std::runtime_error(std::string(what) +
                                  ": this Transformation is not one of Standard / StandardMedianEstimator / "
-                                 "CombinatorialLinearRegression; custom std::function hooks cannot run on the "
-                                 "GPU and this build has no CPU fallback");
+                                 "CombinatorialLinearRegression; with custom std::function hooks only the training "
+                                 "path (distance, findBmu, findLocalBmu, train*) runs, on the host");
 }
 
 void Som::Construct(size_t inWidth, size_t inHeight, size_t inDepth, std::vector<std::string> names)
@@ -646,7 +646,16 @@ Som::~Som() { destroyContext(); }
 
 void Som::setState(const float *map, const float *sigma, const float *S, const float *weight, const uint64_t *hits)
 {
-    requireDevicePath("setState");
+    if (!ctx) {   // custom hooks: the host arrays ARE the state
+        hostEnsure();
+        const size_t N = width * height;
+        if (map) hMap.assign(map, map + N * depth);
+        if (sigma) hSigma.assign(sigma, sigma + N * depth);
+        if (S) hS.assign(S, S + N * depth);
+        if (weight) hWeight.assign(weight, weight + N);
+        if (hits) hHits.assign(hits, hits + N);
+        return;
+    }
     if (grp)
         check(vsom_group_set_state(grp, map, sigma, S, weight, hits), "vsom_group_set_state");
     else
@@ -656,7 +665,15 @@ void Som::setState(const float *map, const float *sigma, const float *S, const f
 
 void Som::getState(float *map, float *sigma, float *S, float *weight, uint64_t *hits) const
 {
-    requireDevicePath("getState");
+    if (!ctx) {
+        hostEnsure();
+        if (map) std::copy(hMap.begin(), hMap.end(), map);
+        if (sigma) std::copy(hSigma.begin(), hSigma.end(), sigma);
+        if (S) std::copy(hS.begin(), hS.end(), S);
+        if (weight) std::copy(hWeight.begin(), hWeight.end(), weight);
+        if (hits) std::copy(hHits.begin(), hHits.end(), hits);
+        return;
+    }
     check(vsom_get_state(ctx, map, sigma, S, weight, hits), "vsom_get_state");
 }
 
@@ -765,7 +782,6 @@ void Som::displayUMatrix() const
 // Som.cpp:977-997: glibc srand/rand, node-major, dim-minor; everything else zero
 void Som::randomInitialize(int seed, float sigma)
 {
-    requireDevicePath("randomInitialize");
     std::srand((unsigned)seed);
     metrics = Metrics{depth};
     const size_t N = width * height;
@@ -780,7 +796,11 @@ void Som::randomInitialize(int seed, float sigma)
 
 void Som::addBmu(SomIndex pos)   // Som.cpp:1189-1192
 {
-    requireDevicePath("addBmu");
+    if (!ctx) {
+        hostEnsure();
+        hHits[getIndex(pos)] += 1;
+        return;
+    }
     const size_t N = width * height;
     std::vector<uint64_t> hh(N);
     check(vsom_get_state(ctx, nullptr, nullptr, nullptr, nullptr, hh.data()), "vsom_get_state");
@@ -813,9 +833,12 @@ SomIndex Som::findBmu(const Eigen::VectorXf &v) const
     return findBmu(v, ones, ones);
 }
 
-SomIndex Som::findBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &, const Eigen::VectorXf &) const
+SomIndex Som::findBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const Eigen::VectorXf &weights) const
 {
-    requireDevicePath("findBmu");
+    if (!ctx) {   // custom hooks: host search (vsom_custom.cpp)
+        const size_t idx = hostFindBmu(v, valid, weights);
+        return SomIndex(idx % width, idx / width);
+    }
     if ((size_t)v.size() != inLen)
         throw std::invalid_argument("sample length does not match the map");
     uint64_t idx = 0;
@@ -823,9 +846,13 @@ SomIndex Som::findBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &, const E
     return SomIndex((size_t)idx % width, (size_t)idx / width);   // Som.cpp:306
 }
 
-SomIndex Som::findLocalBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &, const size_t &lastBMUref,
-                           const Eigen::VectorXf &) const
+SomIndex Som::findLocalBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const size_t &lastBMUref,
+                           const Eigen::VectorXf &weights) const
 {
+    if (!ctx) {
+        const size_t idx = hostFindLocalBmu(v, valid, lastBMUref, weights);
+        return SomIndex(idx % width, idx / width);
+    }
     stageOne(v);
     uint64_t idx = lastBMUref;
     check(vsom_set_last_bmu(ctx, &idx), "vsom_set_last_bmu");
@@ -839,9 +866,11 @@ double Som::euclidianWeightedDist(const SomIndex &pos, const Eigen::VectorXf &v,
     return euclidianWeightedDist(pos.getY() * width + pos.getX(), v, valid, weights);
 }
 
-double Som::euclidianWeightedDist(const size_t &pos, const Eigen::VectorXf &v, const Eigen::VectorXf &,
-                                  const Eigen::VectorXf &) const
+double Som::euclidianWeightedDist(const size_t &pos, const Eigen::VectorXf &v, const Eigen::VectorXf &valid,
+                                  const Eigen::VectorXf &weights) const
 {
+    if (!ctx)
+        return hostDist(pos, v, valid, weights);
     stageOne(v);
     uint64_t node = pos, row = 0;
     float d = 0.f;
@@ -852,7 +881,8 @@ double Som::euclidianWeightedDist(const size_t &pos, const Eigen::VectorXf &v, c
 // ---- batch training ----------------------------------------------------------------------------
 float Som::trainBatchSomEpoch(DataSet &dataset, double currentSigma, bool isFirst)
 {
-    requireDevicePath("trainBatchSomEpoch");
+    if (!ctx)
+        return hostBatchEpoch(dataset, currentSigma, isFirst);
     const size_t B = dataset.size();
     // B == 0 is not skipped: the reference's epoch over an empty chunk still rewrites every neuron
     // (zero model vector, NaN sigma, zero weight -- Som.cpp:840-875), e.g. after the zero-row load that
@@ -889,7 +919,8 @@ float Som::trainBatchSomEpoch(DataSet &dataset, double currentSigma, bool isFirs
 void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, double sigmaDecay,
                         bool updateUMatrixAfterEpoch)
 {
-    requireDevicePath("trainBatchSom");
+    if (!ctx)
+        return hostTrainBatchSom(data, numberOfEpochs, sigma0, sigmaDecay, updateUMatrixAfterEpoch);
     metrics = Som::Metrics(numberOfEpochs);   // Som.cpp:719
     auto sigmaOf = [&](size_t e) { return sigma0 * std::exp(-sigmaDecay * static_cast<double>(e)); };   // :727
     bool have = false;                // a loaded chunk is waiting in `data`, its copy is in flight
@@ -993,11 +1024,12 @@ static int decay_code(Som::WeigthDecayFunction f)
            : f == Som::WeigthDecayFunction::InverseProportional ? VSOM_INVERSE_PROPORTIONAL : VSOM_BATCHMAP;
 }
 
-Som::TrainingReturnValue Som::trainSingle(const Eigen::VectorXf &v, const Eigen::VectorXf &, const Eigen::VectorXf &,
+Som::TrainingReturnValue Som::trainSingle(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const Eigen::VectorXf &weights,
                                           const double eta, const double sigma, size_t &lastBMU,
                                           const WeigthDecayFunction weightDecayFunction)
 {
-    requireDevicePath("trainSingle");
+    if (!ctx)
+        return hostTrainSingle(v, valid, weights, eta, sigma, lastBMU, weightDecayFunction);
     if ((size_t)v.size() != inLen)
         throw std::invalid_argument("sample length does not match the map");
     Eigen::VectorXf residual((Eigen::Index)vsom_residual_len(ctx));
@@ -1014,7 +1046,8 @@ Som::TrainingReturnValue Som::trainSingle(const Eigen::VectorXf &v, const Eigen:
 void Som::trainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, double etaDecay, double sigma0,
                         double sigmaDecay, WeigthDecayFunction weightDecayFunction, bool updateUMatrixAfterEpoch)
 {
-    requireDevicePath("trainBasicSom");
+    if (!ctx)
+        return hostTrainBasicSom(data, numberOfEpochs, eta0, etaDecay, sigma0, sigmaDecay, weightDecayFunction, updateUMatrixAfterEpoch);
     if (grp) {
         check(vsom_group_synchronize(grp), "vsom_group_synchronize");
         replicasStale = true;                 // the online path trains member 0 only (sequential in samples)
