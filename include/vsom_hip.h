@@ -67,13 +67,13 @@ typedef enum vsom_bmu_mode {
 typedef enum vsom_update_mode {
     VSOM_UPDATE_STRICT = 0, /* one rounding per fp32 operation: bit-identical to the reference's SSE2
                                build (default)                                                    */
-    VSOM_UPDATE_FMA = 1     /* contracted chains: Standard M = fma(c,d,M), S = fma(w*d,d,S) (1/3 fewer VALU
-                               ops); CLR inner = fma(A,x',B) - y', A/B/S_A/S_B accumulated with fma (10
-                               instead of 15 ops).  map / sigmaMap then differ from the reference by
-                               rounding only: |err| <= 1e-5 * max(|ref|, scale of the chain's operands)
-                               (measured 1e-7; pure element-wise <= 4e-7 on the MNIST workloads), while BMU
-                               indices, bmuHits, MSE and weightMap stay bit-exact.  The Median chains are
-                               bit-identical in both modes (their fused operations are exact).          */
+    VSOM_UPDATE_FMA = 1     /* contracted Standard chains: M = fma(c,d,M), S = fma(w*d,d,S) (1/3 fewer VALU
+                               ops).  map / sigmaMap then differ from the reference by rounding only:
+                               |err| <= 1e-5 * max(|ref|, scale of the chain's operands) (measured 1e-7; pure
+                               element-wise <= 4e-7 on the MNIST workloads), while BMU indices, bmuHits, MSE
+                               and weightMap stay bit-exact.  Median and CLR have ONE arithmetic, bit-identical
+                               to the reference, in both modes: the Median chains' fused operations are exact,
+                               and the CLR recurrence amplifies rounding differences beyond the tolerance.  */
 } vsom_update_mode;
 
 /* selectors for vsom_device_ptr / vsom_get_timing */

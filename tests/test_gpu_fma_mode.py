@@ -25,13 +25,10 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 
 
-def run_pair(W, H, J, B, sigma, kind, tr=capi.STANDARD):
-    if tr == capi.CLR:
-        X = gen.correlated(B, J, 5)
-        init = gen.random_map(W * H, capi.model_length(tr, J), 42)
-    else:
-        X = gen.mnist_like(B, 3, J) if kind == "mnist" else gen.blobs(B, J, 5, 1, 2, sigma=0.4)
-        init = gen.random_map(W * H, J, 42) * (np.float32(100) if kind == "mnist" else np.float32(1))
+def run_pair(W, H, J, B, sigma, kind):
+    tr = capi.STANDARD
+    X = gen.mnist_like(B, 3, J) if kind == "mnist" else gen.blobs(B, J, 5, 1, 2, sigma=0.4)
+    init = gen.random_map(W * H, J, 42) * (np.float32(100) if kind == "mnist" else np.float32(1))
     o = po.OracleSom(W, H, J, tr)
     o.set_state(map=init)
     lb = np.zeros(B, np.uint64)
@@ -108,23 +105,28 @@ def test_contracted_mode_on_signed_data_bounded_by_operand_scale(W, H, J, B, sig
     ctx.close()
 
 
-@pytest.mark.parametrize("W,H,J,B,sigma", [(12, 12, 9, 300, 3.0), (32, 32, 64, 2048, 8.0)], ids=["12x12_J9", "C5_shape_B2048"])
-def test_contracted_mode_clr(W, H, J, B, sigma):
-    """CombinatorialLinearRegression chains (Transformation.cpp:107-142): inner = fma(A,x',B) - y', the four
-    accumulations fused.  The operands of a parameter pair's chains are its steps aDelta = -2*inner*x' and
-    m2 = -2*inner, whose magnitudes no input column bounds, so the scale is taken per node and part:
-    |a-b| <= 1e-5 * max(|b|, largest |reference| of that node's A (or B) part)."""
-    X, init, o, ctx, st = run_pair(W, H, J, B, sigma, None, tr=capi.CLR)
-    P = capi.model_length(capi.CLR, J) // 2
-    for k, ref in (("map", o.map), ("sigma", o.sigma)):
-        a, b = st[k].astype(np.float64), ref.astype(np.float64)
-        for part in (slice(0, P), slice(P, 2 * P)):
-            ap, bp = a[:, part], b[:, part]
-            scale = np.abs(bp).max(axis=1, keepdims=True)
-            assert (np.abs(ap - bp) <= RTOL * np.maximum(np.abs(bp), scale)).all(), k
-        worst, over, _ = elementwise(st[k], ref)
-        assert over / b.size < 0.01, (k, worst, over)
-    strict_again(ctx, init, X, sigma, o, W * H)
+def test_clr_has_one_arithmetic():
+    """CombinatorialLinearRegression (Transformation.cpp:107-142): the recurrence feeds its own rounding
+    back (inner = A*x' + B - y' depends on the accumulated A, B), and a fused variant measured 2e-5 of the
+    node scale off the reference on a 12x12, J=9 map -- outside the tolerance -- so the library keeps CLR
+    bit-identical whatever the mode says"""
+    W, H, J, B, sigma = 12, 12, 9, 300, 3.0
+    X = gen.correlated(B, J, 5)
+    init = gen.random_map(W * H, capi.model_length(capi.CLR, J), 42)
+    o = po.OracleSom(W, H, J, capi.CLR)
+    o.set_state(map=init)
+    lb = np.zeros(B, np.uint64)
+    o.batch_epoch(X, lb, sigma, True, nthreads=16)
+    ctx = vsom_amd.Context(W, H, J, capi.CLR)
+    ctx.set_state(map=init)
+    ctx.set_update_mode(capi.UPDATE_FMA)
+    ctx.upload_chunk(X)
+    ctx.batch_epoch(sigma, True)
+    st = ctx.get_state()
+    assert (st["map"].view(np.uint32) == o.map.view(np.uint32)).all()
+    same = (st["sigma"].view(np.uint32) == o.sigma.view(np.uint32)) | (np.isnan(st["sigma"]) & np.isnan(o.sigma))
+    assert same.all()
+    assert not capi.has_contracted(capi.CLR) and not capi.has_contracted(capi.MEDIAN) and capi.has_contracted(capi.STANDARD)
     ctx.close()
 
 

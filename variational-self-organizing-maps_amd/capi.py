@@ -48,7 +48,7 @@ class VsomError(RuntimeError):
 def has_contracted(transform):
     """whether vsom_set_update_mode(VSOM_UPDATE_FMA) changes the chain arithmetic of this transformation
     (include/vsom_hip.h, vsom_update_mode)"""
-    return int(transform) in (STANDARD, CLR)      # Median: its fused operations are exact, one arithmetic
+    return int(transform) == STANDARD      # Median (exact fused operations) and CLR have one arithmetic
 
 
 def build(force=False):

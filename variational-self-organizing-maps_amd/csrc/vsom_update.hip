@@ -761,13 +761,12 @@ int vsom_load_asm_module(vsom_ctx *c)
         return VSOM_OK;
     hipModule_t mod;
     VSOM_HIP_CHECK(hipModuleLoadData(&mod, vsom_update_hsaco));
-    hipFunction_t f16, f14, m16, m14, fclr, fclrf, d16, d14;
+    hipFunction_t f16, f14, m16, m14, fclr, d16, d14;
     VSOM_HIP_CHECK(hipModuleGetFunction(&f16, mod, "vsom_update_std_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&f14, mod, "vsom_update_std_rd14_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&m16, mod, "vsom_update_fma_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&m14, mod, "vsom_update_fma_rd14_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&fclr, mod, "vsom_update_clr_rp8_gfx950"));
-    VSOM_HIP_CHECK(hipModuleGetFunction(&fclrf, mod, "vsom_update_clrfma_rp8_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&d16, mod, "vsom_update_med_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&d14, mod, "vsom_update_med_rd14_gfx950"));
     c->upd_module = mod;
@@ -776,7 +775,6 @@ int vsom_load_asm_module(vsom_ctx *c)
     c->upd_fma16 = m16;
     c->upd_fma14 = m14;
     c->upd_clr8 = fclr;
-    c->upd_clr8_fma = fclrf;
     c->upd_med16 = d16;
     c->upd_med14 = d14;
     return VSOM_OK;
@@ -974,8 +972,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     size_t sz = sizeof(a);
                     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
                                      HIP_LAUNCH_PARAM_END};
-                    void *const fnc = c->update_mode == VSOM_UPDATE_FMA ? c->upd_clr8_fma : c->upd_clr8;
-                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fnc, 8 * ((nfull + 3) / 4), (gx + 7) / 8, 1,
+                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)c->upd_clr8, 8 * ((nfull + 3) / 4), (gx + 7) / 8, 1,
                                                          256, 1, 1, 0, c->stream, nullptr, extra));
                     pbase = (int)c->part_len;
                     sig_cols = (int)(nfull * RP);
