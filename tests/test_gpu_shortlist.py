@@ -203,3 +203,88 @@ def test_nonfinite_and_huge_samples(W, J):
     # chains are per (node, dim): the columns holding NaN / +-inf samples are NaN in every node
     assert np.isnan(o.map[:, [0, 1, J - 1]]).all() and not np.isnan(o.map[:, 3]).any()
     ctx.close()
+
+
+# ---- CombinatorialLinearRegression comparer (Transformation.cpp:82-106): one contraction of length
+#      P + 3J over derived features prunes, the exact-order kernel decides (vsom_shortlist.hip) ----
+CLR_CASES = [
+    ("clr_J24", 32, 32, 24, 300),        # P = 276 (not a multiple of 32)
+    ("clr_J12_ragged", 37, 29, 12, 130), # P = 66, non-square map
+    ("clr_J64", 32, 32, 64, 256),        # C5's shape: P = 2016
+    ("clr_J3", 40, 40, 3, 200),          # P = 3: everything is tail
+    ("clr_J33", 33, 33, 33, 96),         # odd J, P = 528
+]
+
+
+def _clr_pair(W, H, J, B, seed=42):
+    X = gen.correlated(B, J, 5)
+    init = gen.random_map(W * H, capi.model_length(capi.CLR, J), seed)
+    o = po.OracleSom(W, H, J, po.CLR)
+    o.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, capi.CLR)
+    ctx.set_state(map=init)
+    ctx.upload_chunk(X)
+    return X, init, o, ctx
+
+
+@pytest.mark.parametrize("name,W,H,J,B", CLR_CASES, ids=[c[0] for c in CLR_CASES])
+def test_clr_shortlist_equals_oracle(name, W, H, J, B):
+    X, init, o, ctx = _clr_pair(W, H, J, B)
+    lb_o, sq_o = _oracle_bmu(o, X)
+    for mode in (capi.BMU_SHORTLIST, capi.BMU_EXACT):
+        idx, dist = _run(ctx, mode)
+        assert beq(idx, lb_o), (name, mode)
+        assert beq(dist, sq_o), (name, mode)
+    # trained maps (small residuals: the expansion cancels, the bound has to cope): three epochs
+    sig = max(W, H) / 4.0
+    ctx.set_bmu_mode(capi.BMU_SHORTLIST)
+    for ep in range(3):
+        lb = np.zeros(B, np.uint64)
+        o.batch_epoch(X, lb, sig, ep == 0, nthreads=16)
+        ctx.upload_chunk(X)
+        ctx.batch_epoch(sig, ep == 0)
+        assert beq(ctx.get_last_bmu(), lb), (name, ep)
+        lb_o, sq_o = _oracle_bmu(o, X)
+        ctx.upload_chunk(X)
+        idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+        assert beq(idx, lb_o) and beq(dist, sq_o), (name, "trained", ep)
+    st = ctx.get_state()
+    assert beq(st["map"], o.map) and beq(st["sigma"], o.sigma), name
+    stats = ctx.shortlist_stats()
+    assert stats["searches"] > 0
+    ctx.close()
+
+
+def test_clr_shortlist_duplicates_zero_map_nan_and_inf_rows():
+    W = H = 34
+    J, B = 10, 120
+    X, init, o, ctx = _clr_pair(W, H, J, B, seed=5)
+    m = init.copy()
+    m[900:1000] = m[100:200]             # exact duplicates at higher indices: the lowest index wins
+    m[17] = m[1100]
+    m[5:400:7] = np.nan                  # poisoned rows never win
+    for mm in (m, np.zeros_like(m)):
+        o.set_state(map=mm)
+        ctx.set_state(map=mm)
+        lb_o, sq_o = _oracle_bmu(o, X, 8)
+        idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+        assert beq(idx, lb_o) and beq(dist, sq_o)
+    # NaN at node 0 (Som.cpp:293-299: nothing compares below NaN, node 0 stays) and an inf row
+    m2 = init.copy()
+    m2[0, 3] = np.nan
+    m2[77, 1] = np.inf
+    o.set_state(map=m2)
+    ctx.set_state(map=m2)
+    lb_o, sq_o = _oracle_bmu(o, X, 8)
+    idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+    assert beq(idx, lb_o) and beq(dist, sq_o)
+    # huge samples: the features overflow, every sample goes to the exact kernel
+    Xb = X.copy()
+    Xb[::3] *= np.float32(1e20)
+    o.set_state(map=init)
+    ctx.set_state(map=init)
+    ctx.upload_chunk(Xb)
+    lb_o, sq_o = _oracle_bmu(o, Xb, 8)
+    idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+    assert beq(idx, lb_o) and beq(dist, sq_o)
+    ctx.close()

@@ -357,7 +357,8 @@ int launch_bmu_full(vsom_ctx *c, size_t s0, size_t s1)
     // for the contraction to outweigh writing and re-reading the B x N approximation matrix
     // (measured on 64x64 maps, B = 16384: D = 32 exact 0.22 vs 0.36 ms, D = 64 0.34 vs 0.39, D = 128
     // 0.61 vs 0.47)
-    const bool can = c->transform != VSOM_CLR;
+    // (CLR: one contraction of length P + 3J over derived features, vsom_shortlist.hip "CLR shortlist")
+    const bool can = true;
     bool want = c->bmu_mode == VSOM_BMU_SHORTLIST;
     if (c->bmu_mode == VSOM_BMU_AUTO && c->N >= 1024 && (s1 - s0) >= 64 && c->D > 64) {
         want = true;

@@ -83,6 +83,8 @@ struct vsom_ctx {
     int *sl_list = nullptr; size_t sl_list_cap = 0;
     float *sl_tmin = nullptr; size_t sl_tmin_cap = 0;
     unsigned *sl_fb = nullptr;      // pinned host feedback: {redo samples, candidates, rows, seq}
+    float *sl_fs = nullptr, *sl_fm = nullptr;      // CLR shortlist: sample / node feature rows (vsom_shortlist.hip)
+    size_t sl_fs_cap = 0, sl_fm_cap = 0;           // bytes
     int sl_skip = 0;
 
     // neighbourhood

@@ -1,6 +1,7 @@
 // vsom_shortlist.hip -- Som::findBmu (Som.cpp:291-309) through an MFMA shortlist (gfx950).
 //
-// Standard / Median comparer only (distance = sum_d (M_d - x_d)^2).  The result is REQUIRED to
+// Standard / Median comparer (distance = sum_d (M_d - x_d)^2) and, further down, the
+// CombinatorialLinearRegression comparer (Transformation.cpp:82-106).  The result is REQUIRED to
 // be identical to the exact-order search of vsom_bmu.hip (and is checked against it and against
 // the oracle in tests): the matrix pipe only prunes, every returned index/distance comes from an
 // exact-order evaluation.
@@ -229,18 +230,74 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict
 // shortlist are spread over the wavefronts (the evaluations are chains of dependent row reads, so
 // more wavefronts per sample is what shortens them).  stats: [0] samples sent to the exact redo
 // list, [1] total candidates
+// CLR candidate evaluation for sl_select_kernel<true>: the sample's x' / y' rows sit in LDS (every
+// candidate of the sample reads them), the node's A / B rows come from L2 in batches of U elements per
+// accumulator class, all 2U loads issued before the first use.  Same operations in the same order per
+// class as vsom_group_dist<true>, hence the same bits.
+template <int U>
+__device__ __forceinline__ float sl_clr_dist(const float *xl, const float *yl, const float *__restrict__ ma,
+                                             const float *__restrict__ mb, int L, int k)
+{
+    const int L8 = L & ~7;
+    float acc = 0.f;
+    int d = k;
+    for (; d + 8 * (U - 1) < L8; d += 8 * U) {
+        float av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            av[u] = ma[d + 8 * u];
+            bv[u] = mb[d + 8 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float r = vsom_resid<true>(xl[d + 8 * u], yl[d + 8 * u], av[u], bv[u]);
+            const float p = r * r;
+            acc = acc + p;
+        }
+    }
+    for (; d < L8; d += 8) {
+        const float r = vsom_resid<true>(xl[d], yl[d], ma[d], mb[d]);
+        const float p = r * r;
+        acc = acc + p;
+    }
+    float q = acc + __shfl_xor(acc, 4);
+    const int rem = L - L8;
+    if (rem >= 4) {
+        const int e = L8 + (k & 3);
+        const float r = vsom_resid<true>(xl[e], yl[e], ma[e], mb[e]);
+        const float p = r * r;
+        q = q + p;
+    }
+    const float t = q + __shfl_xor(q, 2);
+    float res = t + __shfl_xor(t, 1);
+    for (int tt = (rem >= 4 ? 4 : 0); tt < rem; ++tt) {
+        const int e = L8 + tt;
+        const float r = vsom_resid<true>(xl[e], yl[e], ma[e], mb[e]);
+        const float p = r * r;
+        res = res + p;
+    }
+    return res;
+}
+
+// CLR = true: the CombinatorialLinearRegression variant (features and bound: "CLR shortlist" below);
+// xraw = the staged sample rows (J values each) for the per-sample constants, c_e1 the coefficient of the
+// sqrt term of the exact-order error.
+template <bool CLR>
 __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int s1, int N, int D,
                                                         const float *__restrict__ G, int ldg,
                                                         const float *__restrict__ tmin, int ntm,
                                                         const unsigned *__restrict__ scal, float c_g1, float c_g2,
                                                         u64 *__restrict__ lastbmu, float *__restrict__ sqres,
                                                         unsigned *__restrict__ redo_count, int *__restrict__ redo_list,
-                                                        unsigned *__restrict__ stats)
+                                                        unsigned *__restrict__ stats,
+                                                        const float *__restrict__ xraw, int ldxr, int J, float c_e1,
+                                                        unsigned cmax)
 {
     __shared__ unsigned cand[SL_CMAX];
     __shared__ unsigned s_cnt;
     __shared__ u64 s_best[4];
     __shared__ int s_nan0;
+    extern __shared__ __attribute__((aligned(16))) float s_xy[];   // CLR: x' row | y' row (2 * ldx floats)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int s = s0 + blockIdx.x;
     if (s >= s1)
@@ -248,20 +305,45 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     if (threadIdx.x == 0)
         s_cnt = 0u;
     const float *xr = a.xa + (size_t)s * a.ldx;
+    const float *yr = a.xb + (size_t)s * a.ldx;          // CLR: y' row (Standard: same as xr, unused)
     const float *g = G + (size_t)(s - s0) * ldg;
     const float *tm = tmin + (size_t)(s - s0) * ntm;
+    if (CLR) {   // rows are padded to a multiple of 32 floats: 16-byte copies
+        const float4 *sx = reinterpret_cast<const float4 *>(xr), *sy = reinterpret_cast<const float4 *>(yr);
+        float4 *dx = reinterpret_cast<float4 *>(s_xy), *dy = reinterpret_cast<float4 *>(s_xy + a.ldx);
+        for (int i = threadIdx.x; i < (a.ldx >> 2); i += 256) {
+            dx[i] = sx[i];
+            dy[i] = sy[i];
+        }
+    }
     // |x|^2 and the row minimum of the approximations: every wavefront computes both, in the same
     // order, so all of them hold identical values (a NaN never replaces the incumbent minimum)
-    float nx = 0.f;
-    for (int d = lane; d < D; d += 64) {
-        float v = xr[d];
-        float p = v * v;
-        nx = nx + p;
+    float nx = 0.f, cx = 0.f;
+    if (CLR) {
+        // cx = sum_p x'_p^2, cy = sum_p y'_p^2: column t is the first index of J-1-t pairs and the
+        // second index of t pairs (pairs i<j, Transformation.cpp:94-101); nx holds cy
+        const float *xw = xraw + (size_t)s * ldxr;
+        for (int t = lane; t < J; t += 64) {
+            const float v = xw[t];
+            const float q = v * v;
+            cx = cx + q * (float)(J - 1 - t);
+            nx = nx + q * (float)t;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            cx = cx + __shfl_xor(cx, off);
+            nx = nx + __shfl_xor(nx, off);
+        }
+    } else {
+        for (int d = lane; d < D; d += 64) {
+            float v = xr[d];
+            float p = v * v;
+            nx = nx + p;
+        }
+        for (int off = 32; off > 0; off >>= 1)
+            nx = nx + __shfl_xor(nx, off);
     }
-    for (int off = 32; off > 0; off >>= 1)
-        nx = nx + __shfl_xor(nx, off);
     const float nmax = __uint_as_float(scal[0]);
-    bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f);
+    bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f) || !(cx <= 3.0e38f);
     float m = __uint_as_float(0x7F800000u);
     for (int i = lane; i < ntm; i += 64) {
         float v = tm[i];
@@ -273,12 +355,28 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     }
     __syncthreads();   // s_cnt = 0 visible
     if (!bad) {
-        // T_s = 4*g1*(nMmax+nx) + 2.1*g2*(m + nx + 2*g1*(nMmax+nx)), inflated by 1.05 (header)
-        const float ea = c_g1 * (nmax + nx);                 // c_g1 = 2*g1
-        float dj = m + nx;
-        dj = dj + ea;
-        dj = dj > 0.f ? dj : 0.f;
-        const float T = 1.05f * (2.f * ea + c_g2 * dj);      // c_g2 = 2.1*g2
+        float T;
+        if (CLR) {
+            // "CLR shortlist" below: Q bounds sum_p (A x')^2 + B^2 + y'^2 for every node
+            const float amax2 = __uint_as_float(scal[3]);
+            const float Q = 1.01f * (amax2 * cx + nmax + nx);
+            const float ea = c_g1 * Q;                       // c_g1 = ga
+            float dj = m + nx;
+            dj = dj + ea;
+            dj = dj > 0.f ? dj : 0.f;
+            const float dd = 1.02f * dj + 2.0e-5f * Q;       // covers d_jm and d_i* (derivation below)
+            const float ee = c_e1 * sqrtf(dd * Q) + c_g2 * dd;
+            T = 1.05f * (2.f * ea + 2.f * ee);
+            if (!(Q <= 3.0e38f))
+                bad = true;
+        } else {
+            // T_s = 4*g1*(nMmax+nx) + 2.1*g2*(m + nx + 2*g1*(nMmax+nx)), inflated by 1.05 (header)
+            const float ea = c_g1 * (nmax + nx);             // c_g1 = 2*g1
+            float dj = m + nx;
+            dj = dj + ea;
+            dj = dj > 0.f ? dj : 0.f;
+            T = 1.05f * (2.f * ea + c_g2 * dj);              // c_g2 = 2.1*g2
+        }
         const float thr = m + T;
         if (!(thr < 3.0e38f))
             bad = true;                                      // nothing finite to compare with
@@ -309,7 +407,7 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     }
     __syncthreads();
     const unsigned cnt = s_cnt;
-    if (cnt > SL_CMAX)
+    if (cnt > cmax)     // cmax <= SL_CMAX: beyond it the exact tile kernel is the cheaper way to search this sample
         bad = true;
     if (bad) {   // block-uniform
         if (threadIdx.x == 0) {
@@ -324,7 +422,7 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     const int grp = lane >> 3, k = lane & 7;
     u64 best = ~0ull;
     if (wave == 0) {
-        float d0 = vsom_group_dist<false>(xr, xr, a.ma, a.ma, a.L, k);
+        float d0 = CLR ? sl_clr_dist<8>(s_xy, s_xy + a.ldx, a.ma, a.mb, a.L, k) : vsom_group_dist<false>(xr, xr, a.ma, a.ma, a.L, k);
         d0 = __shfl(d0, 0);
         best = vsom_key(d0, 0u);
         if (lane == 0)
@@ -333,7 +431,8 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     for (unsigned c0 = 0; c0 < cnt; c0 += 32) {
         const unsigned ci = c0 + (unsigned)(wave * 8 + grp);
         const unsigned node = cand[ci < cnt ? ci : cnt - 1];
-        float d = vsom_group_dist<false>(xr, xr, a.ma + (size_t)node * a.ldm, a.ma, a.L, k);
+        float d = CLR ? sl_clr_dist<8>(s_xy, s_xy + a.ldx, a.ma + (size_t)node * a.ldm, a.mb + (size_t)node * a.ldm, a.L, k)
+                      : vsom_group_dist<false>(xr, xr, a.ma + (size_t)node * a.ldm, a.ma, a.L, k);
         u64 key = ci < cnt ? vsom_key(d, node) : ~0ull;
         best = key < best ? key : best;
     }
@@ -385,10 +484,14 @@ __global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsi
 // host side ------------------------------------------------------------------------------------
 int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount);
 
+static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1);
+
 int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
 {
     if (s1 <= s0)
         return VSOM_OK;
+    if (c->transform == VSOM_CLR)
+        return launch_bmu_full_shortlist_clr(c, s0, s1);
     const size_t nrows = s1 - s0;
     const size_t ldg = ((size_t)c->N + 127) / 128 * 128;
     const size_t need = nrows * ldg;
@@ -439,11 +542,219 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     const double u = 5.9604644775390625e-08;   // 2^-24
     const double K = (double)c->xpitch;
     const double g1 = ((double)GK + K / GK + 3.0) * u, g2 = ((double)c->D / 8.0 + 10.0) * u;
-    hipLaunchKernelGGL(sl_select_kernel, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0,
+    hipLaunchKernelGGL(sl_select_kernel<false>, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0,
                        (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(2.0 * g1), (float)(2.1 * g2),
-                       c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4);
+                       c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, (const float *)nullptr, 0, 0, 0.f, (unsigned)SL_CMAX);
     hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows);
     VSOM_HIP_CHECK(hipGetLastError());
     // exact-order redo of the listed samples (device-side count; blocks beyond it exit at once)
+    return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2);
+}
+
+// ==============================================================================================
+// CLR shortlist: Som::findBmu for the CombinatorialLinearRegression comparer (Transformation.cpp:82-106)
+// ==============================================================================================
+// Exact distance of sample s and node n:  d = sum_p r_p^2,  r_p = A_p x'_p + B_p - y'_p,  x'_p = x[i(p)],
+// y'_p = x[j(p)], pairs i<j lexicographic, P = J(J-1)/2.  Expanding the square and grouping by input column,
+//   d - sum_p y'_p^2 = nB_n - 2 * < phi(s), psi(n) >,         nB_n = sum_p B_p^2,
+//   phi = [ x_i x_j (P) | x_t^2 (J) | x_t (J) | x_t (J) ],
+//   psi = [ A_p     (P) | -1/2 sum_{p:i(p)=t} A_p^2 | -sum_{p:i(p)=t} A_p B_p | +sum_{p:j(p)=t} B_p ],
+// i.e. ONE contraction of length K = P + 3J (not 4P) that sl_gemm_kernel computes as it stands
+// (G = nrm - 2 X.M^T with X = phi rows, M = psi rows, nrm = nB).  sum_p y'^2 =: cy_s is constant per sample.
+//
+// Bound (u = 2^-24).  Let Q_ns = sum_p (A_p x'_p)^2 + B_p^2 + y'_p^2  <=  amax2 * cx_s + nBmax + cy_s =: Q_s
+// (amax2 = max A_p^2 and nBmax = max nB over the map, cx_s = sum_p x'_p^2).
+//  (a) approximation:  sum_k |phi_k psi_k| <= sum_p [A^2x'^2 + 2|A B x'| + 2|A x' y'| + 2|B y'|] <= 3 Q_ns
+//      (2|ab| <= a^2 + b^2).  Features carry relative errors <= gf = (J+3)u (one product + a sequential sum of
+//      <= J terms), the contraction g1 = (GK + K/GK + 3)u as for the Standard search, nB (P/256+12)u:
+//          |G_ns + cy_s - d_ns| <= Ea := ga * Q_s,     ga = 3.01*(g1 + gf) + (P/256 + 19)u
+//      (the last 7u: rounding of nB - 2*dot itself, |G| <= nB + 6 Q_ns).
+//  (b) exact-order value e_ns (three roundings per residual, a square, Eigen's sum tree):
+//      |fl(r_p) - r_p| <= 3.01u * rho_p,  rho_p = |A x'| + |B| + |y'|,  sum rho_p^2 <= 3 Q_ns, so
+//          |e_ns - d_ns| <= 6.1u * sqrt(3 d_ns Q_s) + g2 * d_ns =: Ee(d_ns),     g2 = (P/8 + 10)u.
+//  (c) with i* the reference argmin and jm = argmin G (m = G_jm):  d_jm <= dj := m + cy + Ea, and
+//      d_i* <= e_i* + Ee <= e_jm + Ee <= dj + Ee(dj) + Ee(d_i*), which for coefficients of this size gives
+//      d_i* <= 1.0002 dj + 1e-6 Q_s; both are below dd := 1.02 dj + 2e-5 Q_s.  Then
+//          G_i* <= m + 2 Ea + 2 Ee(dd) =: m + T_s            (inflated by 1.05 for the fp32 evaluation).
+// Everything within T_s of the row minimum is re-evaluated in the reference's order; rows with NaN drop
+// out (G = NaN), node 0 is always evaluated, an inf anywhere in the map sends the chunk to the exact kernel.
+// A candidate costs ~1 ns here (16 KB of model rows gathered from L2) against ~280 ns per sample in the
+// exact tile kernel at C5's size, so a sample with more than 128 candidates -- maps with many (near-)
+// duplicate nodes: after a batch epoch on strongly correlated data whole rows of the map can coincide --
+// goes to the redo list instead (measured at C5: 1 candidate per sample on a random map 0.65 ms, 32 per
+// sample 0.69 ms, every node a candidate 8-9 ms before the cap; the exact kernel alone 2.3-2.5 ms).
+
+// phi rows.  One workgroup per sample; Kp = P32 + roundup(3J, 32), P32 = roundup(P, 32).
+__global__ __launch_bounds__(256) void clr_sample_feat_kernel(const float *__restrict__ XP, const float *__restrict__ YP, int ldp,
+                                                              int P, const float *__restrict__ Xs, int ldx, int J,
+                                                              float *__restrict__ Fs, int Kp, int P32, int s0, int s1)
+{
+    const int s = s0 + blockIdx.x;
+    if (s >= s1)
+        return;
+    const float *xp = XP + (size_t)s * ldp, *yp = YP + (size_t)s * ldp, *x = Xs + (size_t)s * ldx;
+    float *f = Fs + (size_t)s * Kp;
+    for (int p = threadIdx.x; p < P32; p += 256)
+        f[p] = p < P ? xp[p] * yp[p] : 0.f;
+    for (int t = threadIdx.x; t < Kp - P32; t += 256) {
+        float v = 0.f;
+        if (t < J)
+            v = x[t] * x[t];
+        else if (t < 3 * J)
+            v = x[t < 2 * J ? t - J : t - 2 * J];
+        f[P32 + t] = v;
+    }
+}
+
+// psi rows, nB, and the map-wide maxima.  One workgroup per node.
+__global__ __launch_bounds__(256) void clr_node_feat_kernel(const float *__restrict__ map, int ldm, int ppitch, int P, int J,
+                                                            float *__restrict__ Fm, int Kp, int P32, int N,
+                                                            float *__restrict__ nB, unsigned *__restrict__ scal)
+{
+    const int n = blockIdx.x;
+    if (n >= N)
+        return;
+    const float *A = map + (size_t)n * ldm, *Bv = A + ppitch;
+    float *f = Fm + (size_t)n * Kp;
+    float sb = 0.f, amax = 0.f;
+    bool inf = false, nan = false;
+    for (int p = threadIdx.x; p < P32; p += 256) {
+        const float a = p < P ? A[p] : 0.f, b = p < P ? Bv[p] : 0.f;
+        f[p] = a;
+        const float a2 = a * a, b2 = b * b;
+        sb = sb + b2;
+        nan |= (a2 != a2) || (b2 != b2);
+        inf |= (a2 > 3.0e38f) || (b2 > 3.0e38f);
+        amax = a2 > amax ? a2 : amax;
+    }
+    for (int t = threadIdx.x; t < Kp - P32; t += 256) {
+        float v = 0.f;
+        if (t < J) {                                 // -1/2 sum_{i(p)=t} A_p^2 : pairs off(t) .. off(t)+J-2-t
+            const int off = t * (2 * J - t - 1) / 2;
+            float acc = 0.f;
+            for (int q = 0; q < J - 1 - t; ++q) {
+                const float a = A[off + q];
+                acc = acc + a * a;
+            }
+            v = -0.5f * acc;
+        } else if (t < 2 * J) {                      // -sum_{i(p)=t} A_p B_p
+            const int tt = t - J, off = tt * (2 * J - tt - 1) / 2;
+            float acc = 0.f;
+            for (int q = 0; q < J - 1 - tt; ++q) {
+                const float ab = A[off + q] * Bv[off + q];
+                acc = acc + ab;
+            }
+            v = -acc;
+        } else if (t < 3 * J) {                      // +sum_{j(p)=t} B_p : pairs (i, t), i < t, at off(i) + t-i-1
+            const int tt = t - 2 * J;
+            float acc = 0.f;
+            for (int i = 0; i < tt; ++i)
+                acc = acc + Bv[i * (2 * J - i - 1) / 2 + (tt - i - 1)];
+            v = acc;
+        }
+        f[P32 + t] = v;
+    }
+    // block reductions: nB (sum), amax2 (max), flags
+    __shared__ float ssum[4], smax[4];
+    __shared__ int sflag[2];
+    if (threadIdx.x < 2)
+        sflag[threadIdx.x] = 0;
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+        sb = sb + __shfl_xor(sb, off);
+        const float o = __shfl_xor(amax, off);
+        amax = o > amax ? o : amax;
+    }
+    if (inf)
+        atomicOr(&sflag[0], 1);
+    if (nan)
+        atomicOr(&sflag[1], 1);
+    if ((threadIdx.x & 63) == 0) {
+        ssum[threadIdx.x >> 6] = sb;
+        smax[threadIdx.x >> 6] = amax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);
+        float am = smax[0];
+        for (int i = 1; i < 4; ++i)
+            am = smax[i] > am ? smax[i] : am;
+        nB[n] = tot;
+        if (sflag[0] || tot > 3.0e38f)
+            atomicOr(&scal[1], 1u);                  // an inf somewhere: the bound does not apply
+        else if (!sflag[1]) {                        // NaN rows are legal and excluded from every search
+            atomicMax(&scal[0], __float_as_uint(tot));
+            atomicMax(&scal[3], __float_as_uint(am));
+        }
+    }
+}
+
+static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
+{
+    // the select kernel keeps the sample's x' / y' rows in LDS (2 * part_pitch floats beside 8.3 KB of
+    // static storage): beyond 48 KB (J > 110) the exact-order kernel searches instead
+    if ((size_t)2 * c->part_pitch * sizeof(float) > 48 * 1024)
+        return launch_bmu_full_exact_list(c, s0, s1, nullptr, nullptr);
+    const size_t nrows = s1 - s0;
+    const uint32_t P = c->part_len, J = c->J;
+    const uint32_t P32 = (P + 31) / 32 * 32, Kp = P32 + (3 * J + 31) / 32 * 32;
+    const size_t ldg = ((size_t)c->N + 127) / 128 * 128;
+    const size_t ntm = (((size_t)c->N + GT - 1) / GT) * 2;
+    auto grow = [](void **buf, size_t *cap, size_t need_bytes) -> int {
+        if (need_bytes <= *cap)
+            return VSOM_OK;
+        if (*buf)
+            VSOM_HIP_CHECK(hipFree(*buf));
+        *buf = nullptr;
+        *cap = 0;
+        VSOM_HIP_CHECK(hipMalloc(buf, need_bytes));
+        *cap = need_bytes;
+        return VSOM_OK;
+    };
+    int rc;
+    size_t capG = c->sl_cap * sizeof(float), capT = c->sl_tmin_cap * sizeof(float), capL = c->sl_list_cap * sizeof(int);
+    if ((rc = grow((void **)&c->sl_G, &capG, nrows * ldg * sizeof(float))) ||
+        (rc = grow((void **)&c->sl_tmin, &capT, nrows * ntm * sizeof(float))) ||
+        (rc = grow((void **)&c->sl_list, &capL, nrows * sizeof(int))) ||
+        (rc = grow((void **)&c->sl_fs, &c->sl_fs_cap, c->B * (size_t)Kp * sizeof(float))) ||
+        (rc = grow((void **)&c->sl_fm, &c->sl_fm_cap, (size_t)c->N * Kp * sizeof(float))))
+        return rc;
+    c->sl_cap = capG / sizeof(float);
+    c->sl_tmin_cap = capT / sizeof(float);
+    c->sl_list_cap = capL / sizeof(int);
+    if (!c->sl_nrm) {
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_nrm, (size_t)c->N * sizeof(float)));
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 8192));
+        VSOM_HIP_CHECK(hipHostMalloc(&c->sl_fb, 64));
+        std::memset(c->sl_fb, 0, 64);
+    }
+    // scal: [0] max nB bits, [1] non-finite flag, [2] redo count, [3] max A^2 bits, [4] redo samples
+    unsigned *scal = c->sl_scal;
+    hipLaunchKernelGGL(sl_reset_kernel, dim3(1), dim3(64), 0, c->stream, scal);
+    hipLaunchKernelGGL(clr_node_feat_kernel, dim3((unsigned)c->N), dim3(256), 0, c->stream, c->map, (int)c->pitch,
+                       (int)c->part_pitch, (int)P, (int)J, c->sl_fm, (int)Kp, (int)P32, (int)c->N, c->sl_nrm, scal);
+    hipLaunchKernelGGL(clr_sample_feat_kernel, dim3((unsigned)nrows), dim3(256), 0, c->stream, c->XP, c->YP, (int)c->part_pitch,
+                       (int)P, c->Xs, (int)c->xpitch, (int)J, c->sl_fs, (int)Kp, (int)P32, (int)s0, (int)s1);
+    dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
+    hipLaunchKernelGGL(sl_gemm_kernel, grid, dim3(256), 0, c->stream, c->sl_fs, (int)Kp, (int)s0, (int)s1, c->sl_fm, (int)Kp,
+                       (int)c->N, (int)Kp, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm);
+    DistArgs a;
+    a.xa = c->XP;
+    a.xb = c->YP;
+    a.ldx = (int)c->part_pitch;
+    a.ma = c->map;
+    a.mb = c->map + c->part_pitch;
+    a.ldm = (int)c->pitch;
+    a.L = (int)P;
+    const double u = 5.9604644775390625e-08;   // 2^-24
+    const double g1 = ((double)GK + (double)Kp / GK + 3.0) * u, gf = ((double)J + 3.0) * u;
+    const double ga = 3.01 * (g1 + gf) + ((double)P / 256.0 + 12.0 + 7.0) * u;   // + the final nB - 2*dot rounding
+    const double g2 = ((double)P / 8.0 + 10.0) * u, e1 = 6.1 * 1.7320508075688773 * u;
+    const size_t xy_bytes = (size_t)2 * c->part_pitch * sizeof(float);   // + 8.3 KB static: fits the default 64 KB up to J = 120
+    hipLaunchKernelGGL(sl_select_kernel<true>, dim3((unsigned)nrows), dim3(256), xy_bytes, c->stream, a, (int)s0, (int)s1, (int)c->N,
+                       (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(1.0001 * ga), (float)(1.0001 * g2),
+                       c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, c->Xs, (int)c->xpitch, (int)J, (float)(1.0001 * e1), 128u);
+    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows);
+    VSOM_HIP_CHECK(hipGetLastError());
     return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2);
 }
