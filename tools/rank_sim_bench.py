@@ -23,6 +23,8 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     X = gen.mnist_like(B, 3, D)
     ctx = vsom_amd.Context(W, W, D)
     ctx.set_state(map=init)
+    if os.environ.get("VSOM_SIM_FMA"):          # the contracted update arithmetic (bench.py's default)
+        ctx.set_update_mode(1)
     ctx.upload_chunk(X)
     n1 = W * W // world
     steps = int(os.environ.get("VSOM_SIM_STEPS", "5"))

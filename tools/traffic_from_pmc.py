@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the committed rocprofv3 PMC summaries (profiles/r2_<cfg>_pmc.txt, written by
+tools/collect_profiles.sh + tools/pmc_summary.py): HBM-side bytes per launch of each configuration's dominant
+kernel = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes).  The factor 2 is the gfx950 correction of
+MI355X_MICROARCH.md ("FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read",
+16 B per lane -- the (c,w) stream of the chain kernels and the scan of the online kernels are such reads;
+the counter also tallies Infinity-Cache hits, so this is memory-side traffic, an upper bound of HBM bytes).
+bench.py quotes these figures as `roofline.traffic` with their source."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+KERNEL = {"c3": r"vsom_update_fma_rd14_gfx950", "c3_strict": r"vsom_update_std_rd14_gfx950",
+          "c2": r"vsom_update_fma_rd14_gfx950", "c4": r"update_chain_kernel", "c5": r"vsom_update_clr_rp8_gfx950",
+          "online": r"online_window_kernel"}
+
+
+def counters(path, kernel):
+    vals, cur = {}, None
+    for ln in open(path):
+        if not ln.startswith(" ") and not ln.startswith("#"):
+            cur = ln.split("  dispatches=")[0].strip()
+        elif cur and re.search(kernel, cur):
+            parts = ln.split()
+            if len(parts) == 2:
+                vals.setdefault(parts[0], float(parts[1]))
+    return vals
+
+
+out = {"_doc": __doc__.strip().replace("\n", " ")}
+for cfg, kern in KERNEL.items():
+    p = os.path.join(PROF, f"r2_{cfg}_pmc.txt")
+    if not os.path.exists(p):
+        continue
+    v = counters(p, kern)
+    if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+        continue
+    ent = {"kernel": kern, "fetch_size_kib": v["FETCH_SIZE"], "write_size_kib": v["WRITE_SIZE"],
+           "hbm_bytes_per_launch": int(round((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0)),
+           "source": f"profiles/r2_{cfg}_pmc.txt, separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE"}
+    if "TCC_HIT" in v and "TCC_MISS" in v:
+        ent["l2_hit_rate"] = round(v["TCC_HIT"] / (v["TCC_HIT"] + v["TCC_MISS"]), 4)
+    out[cfg] = ent
+json.dump(out, open(os.path.join(PROF, "traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
