@@ -236,9 +236,6 @@ def main():
     Bper = cfg["chunk"]
     sigma = cfg["sigma"]
     sharded = world > 1 and not online           # the online path is strictly sequential: replicas only
-    if world > 1 and tr != capi.STANDARD:
-        # Median / CLR shard the same way (node-sharded phase 2); BASELINE names them as 1-GPU configs
-        pass
     if args.strong and sharded:
         Bper = Bper // world
     Bglob = Bper * world if sharded else Bper

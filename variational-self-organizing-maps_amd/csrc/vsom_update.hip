@@ -14,14 +14,15 @@
 //                  eight look up / divide / store (cw_kernel / cw16_kernel are the earlier
 //                  redundant-chain versions, kept behind VSOM_CW_MODE for comparison).
 //   update_*     : the N*D chains.
-//                  - vsom_update_{std,fma}_rd{14,16}_gfx950, vsom_update_clr_rp8_gfx950: hand-scheduled
+//                  - vsom_update_{std,fma,med}_rd{14,16}_gfx950, vsom_update_clr_rp8_gfx950: hand-scheduled
 //                    code object (gen_update_asm.py): lane = node, RD dims (8 CLR pairs) per lane in
 //                    VGPRs, x rows through scalar loads (SGPR operands of v_pk_* ops), a ring of
 //                    (c,w) loads always in flight, x rows prefetched into L2.  A ragged depth is
 //                    covered by a 16/14 column split or by a last slice that runs into the rows'
-//                    zero padding (vsom_update_split; the padding is re-zeroed afterwards).
-//                  - update_kernel (Median; Standard / CLR with VSOM_NO_ASM), update_clr_kernel: the
-//                    same decomposition in HIP, sample pairs software-pipelined.
+//                    zero padding (vsom_update_split; the padding is re-zeroed afterwards).  `med`:
+//                    the Median sign from packed clamped multiplications, bit-identical (compute_median).
+//                  - update_kernel, update_clr_kernel (VSOM_NO_ASM, and depths the assembly kernels do not
+//                    cover): the same decomposition in HIP, sample pairs software-pipelined.
 //                  - update_chain_kernel: one lane per (node, dim) chain for maps too small to fill
 //                    the chip with lane = node.
 //                  Every fp32 operation is rounded separately (-ffp-contract=off), so the result is
