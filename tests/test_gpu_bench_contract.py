@@ -1,0 +1,48 @@
+"""GPU: bench.py's contract -- ONE JSON line with the required keys, `roofline` and (N = 1) `cpu_baseline`;
+`python bench.py --gpus 2` with no launcher starts its two ranks itself (here both on cuda:0 over gloo:
+RCCL refuses one device twice) and times the real step, chunk replication included."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _run(*args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_small_shape():
+    d = _run("--map", "32", "--chunk", "512", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1")
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "valu_fp32" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["other_arithmetic"]["arithmetic"] == "strict" and d["update_arithmetic"].startswith("contracted")
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_self_launch_two_ranks_on_one_device():
+    d = _run("--gpus", "2", "--backend", "gloo", "--share-device", "--map", "32", "--chunk", "256", "--steps", "2",
+             "--warmup", "1", "--no-cpu", "--no-other-arith")
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["rccl_ranks"] == 2
+    assert d["config"]["chunk_total"] == 512 and d["config"]["chunk_per_gpu"] == 256 and d["scaling"] == "weak"
+    assert "cpu_baseline" not in d                      # the CPU leg runs at N = 1 only
+    assert d["value"] > 0 and d["roofline"]["avg_launch_ms"] > 0
+
+
+def test_online_line_is_bandwidth_priced():
+    d = _run("--config", "online", "--map", "32", "--chunk", "64", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1")
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["unit"] == "GB/s" and d["value"] > 0

@@ -139,35 +139,56 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
             for (int k = 0; k < 8; ++k)
                 acc[i][j][k] = 0.f;
 
-    int dk = 0;
-    for (int ch = 0; ch < nchunks; ++ch, dk += VSOM_TK) {
-        if (ch > 0)
-            __syncthreads();
+    // global -> register staging of one K-chunk (2 float4 per operand and thread).  Standard / Median keep
+    // the NEXT chunk's loads in flight while the current one is consumed (register prefetch: the loads used
+    // to be issued and waited for between the two barriers, with only two wavefronts per SIMD to cover
+    // them); the CLR kernel sits at 256 VGPRs and has no room for the second set.
+    float4 gx[2], gm[2], gy[2], gb[2];
+    auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int f = tid + 256 * i;
             int row = f >> 3, c4 = (f & 7) * 4;
             int s = sbase + row, n = nbase + row;
-            float4 vx = make_float4(0.f, 0.f, 0.f, 0.f), vm = vx, vy = vx, vb = vx;
+            gx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            gm[i] = gx[i];
+            gy[i] = gx[i];
+            gb[i] = gx[i];
             if (s < s1) {
                 const size_t srow = slist ? (size_t)slist[s - s0] : (size_t)s;
-                vx = *reinterpret_cast<const float4 *>(a.xa + srow * a.ldx + dk + c4);
+                gx[i] = *reinterpret_cast<const float4 *>(a.xa + srow * a.ldx + k0 + c4);
                 if (CLR)
-                    vy = *reinterpret_cast<const float4 *>(a.xb + srow * a.ldx + dk + c4);
+                    gy[i] = *reinterpret_cast<const float4 *>(a.xb + srow * a.ldx + k0 + c4);
             }
             if (n < N) {
-                vm = *reinterpret_cast<const float4 *>(a.ma + (size_t)n * a.ldm + dk + c4);
+                gm[i] = *reinterpret_cast<const float4 *>(a.ma + (size_t)n * a.ldm + k0 + c4);
                 if (CLR)
-                    vb = *reinterpret_cast<const float4 *>(a.mb + (size_t)n * a.ldm + dk + c4);
+                    gb[i] = *reinterpret_cast<const float4 *>(a.mb + (size_t)n * a.ldm + k0 + c4);
             }
-            *reinterpret_cast<float4 *>(&sx[row * LDT + c4]) = vx;
-            *reinterpret_cast<float4 *>(&sm[row * LDT + c4]) = vm;
+        }
+    };
+    if (!CLR)
+        gload(0);
+    int dk = 0;
+    for (int ch = 0; ch < nchunks; ++ch, dk += VSOM_TK) {
+        if (ch > 0)
+            __syncthreads();
+        if (CLR)
+            gload(dk);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int f = tid + 256 * i;
+            int row = f >> 3, c4 = (f & 7) * 4;
+            *reinterpret_cast<float4 *>(&sx[row * LDT + c4]) = gx[i];
+            *reinterpret_cast<float4 *>(&sm[row * LDT + c4]) = gm[i];
             if (CLR) {
-                *reinterpret_cast<float4 *>(&sy[row * LDT + c4]) = vy;
-                *reinterpret_cast<float4 *>(&sb[row * LDT + c4]) = vb;
+                *reinterpret_cast<float4 *>(&sy[row * LDT + c4]) = gy[i];
+                *reinterpret_cast<float4 *>(&sb[row * LDT + c4]) = gb[i];
             }
         }
         __syncthreads();
+        if (!CLR && ch + 1 < nchunks)
+            gload(dk + VSOM_TK);
 #pragma unroll
         for (int kk = 0; kk < VSOM_TK; kk += 8) {
             if (dk + kk < L8) {   // whole 8-blocks only; the remainder is handled in Eigen's order below
@@ -176,15 +197,18 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
                     float4 xv[4], mv[4], yv[4], bv[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        xv[i] = *reinterpret_cast<const float4 *>(&sx[(ty + 16 * i) * LDT + kk + 4 * h]);
                         mv[i] = *reinterpret_cast<const float4 *>(&sm[(tx + 16 * i) * LDT + kk + 4 * h]);
-                        if (CLR) {
-                            yv[i] = *reinterpret_cast<const float4 *>(&sy[(ty + 16 * i) * LDT + kk + 4 * h]);
+                        if (CLR)
                             bv[i] = *reinterpret_cast<const float4 *>(&sb[(tx + 16 * i) * LDT + kk + 4 * h]);
-                        }
+                        else
+                            xv[i] = *reinterpret_cast<const float4 *>(&sx[(ty + 16 * i) * LDT + kk + 4 * h]);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i) {
+                        if (CLR) {   // the CLR kernel is out of registers: the sample operands one row at a time
+                            xv[i] = *reinterpret_cast<const float4 *>(&sx[(ty + 16 * i) * LDT + kk + 4 * h]);
+                            yv[i] = *reinterpret_cast<const float4 *>(&sy[(ty + 16 * i) * LDT + kk + 4 * h]);
+                        }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float r0 = vsom_resid<CLR>(xv[i].x, CLR ? yv[i].x : 0.f, mv[j].x, CLR ? bv[j].x : 0.f);
@@ -197,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
                             acc[i][j][4 * h + 2] = acc[i][j][4 * h + 2] + p2;
                             acc[i][j][4 * h + 3] = acc[i][j][4 * h + 3] + p3;
                         }
+                    }
                 }
             }
         }
