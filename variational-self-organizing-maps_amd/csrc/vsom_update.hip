@@ -559,6 +559,127 @@ __global__ __launch_bounds__(256) void update_chain_kernel(const float *__restri
     }
 }
 
+// The same chains with TWO dims per lane (packed fp32 arithmetic) for the shapes where even lane = (node, dim)
+// yields no more than two wavefronts per SIMD (C4: 64x64x32): half the wavefronts, each with a ring of
+// NG groups of U samples of loads in flight -- a single wavefront per SIMD has the registers for it (up to
+// 512) and nothing else to cover the L2 / HBM latency with.  Median: the sign through clamped
+// multiplications (see gen_update_asm.py, compute_median: p = [delta > 0], n = [delta < 0], exact fused
+// accumulation, bit-identical); the clamp must pass NaN, so the kernel switches DX10_CLAMP off for itself.
+typedef float vsom_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ vsom_f2 vsom_pk_mul_clamp(vsom_f2 a, vsom_f2 b)
+{
+    vsom_f2 r;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ vsom_f2 vsom_pk_mul_negclamp(vsom_f2 a, vsom_f2 b)
+{
+    vsom_f2 r;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[1,0] clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <bool MEDIAN, int U, int NG, bool FMA>
+__global__ __launch_bounds__(256, 1) void update_chain2_kernel(const float *__restrict__ Xs, int ldx,
+                                                               const float2 *__restrict__ cw, int ldn, int B,
+                                                               int n0, int nloc, int D, int dl_log2,
+                                                               float *__restrict__ map,
+                                                               float *__restrict__ sigma, int pitch,
+                                                               const float *__restrict__ weight)
+{
+    static_assert(U % 2 == 0, "pairs of samples share one float4 of (c,w)");
+    if (MEDIAN)
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 8, 1), 0");   // DX10_CLAMP off: clamp(NaN) = NaN
+    const int DL = 1 << dl_log2;                       // dim PAIRS per node row of the workgroup
+    const int nl = blockIdx.x * (256 >> dl_log2) + ((int)threadIdx.x >> dl_log2);
+    const int dp = blockIdx.y * DL + ((int)threadIdx.x & (DL - 1));
+    const int d = 2 * dp;                              // rows are zero padded to a multiple of 32: d+1 is readable
+    const bool valid = nl < nloc && d < D;
+    const int nlc = nl < nloc ? nl : nloc - 1;
+    const int dc = d < D ? d : (D - 1) & ~1;
+
+    const float *xp = Xs + dc;
+    const float4 *cp = (const float4 *)cw + nlc;      // pair row r at cp[r * ldn]
+    vsom_f2 M = {0.f, 0.f}, S = {0.f, 0.f};            // :843-844
+    const vsom_f2 big = {0x1.0p100f, 0x1.0p100f};
+
+    vsom_f2 x[NG][U];
+    float4 cv[NG][U / 2];
+    const int nfull = B / U;
+    auto load = [&](int slot, int g) {
+        g = g < nfull ? g : nfull - 1;                 // clamped: re-reads the last full group, never past the buffers
+        const float *xq = xp + (size_t)g * U * ldx;
+        const float4 *cq = cp + (size_t)g * (U / 2) * ldn;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            x[slot][u] = *reinterpret_cast<const vsom_f2 *>(xq + (size_t)u * ldx);
+#pragma unroll
+        for (int u = 0; u < U / 2; ++u)
+            cv[slot][u] = cq[(size_t)u * ldn];
+    };
+    auto one = [&](vsom_f2 xv, float c, float w) {
+        const vsom_f2 cc = {c, c}, ww = {w, w};
+        vsom_f2 dl = xv - M;                           // Stepper (Transformation.cpp:12 / :50)
+        if (MEDIAN) {
+            const vsom_f2 t = dl * big;
+            const vsom_f2 pp = vsom_pk_mul_clamp(t, big), nn = vsom_pk_mul_negclamp(t, big);
+            M = __builtin_elementwise_fma(cc, pp, M);  // exact products: rounds like mul + add (:864)
+            M = __builtin_elementwise_fma(-cc, nn, M);
+            S = __builtin_elementwise_fma(ww, pp, S);  // (:867)
+            S = __builtin_elementwise_fma(ww, nn, S);
+        } else if (FMA) {
+            M = __builtin_elementwise_fma(cc, dl, M);
+            S = __builtin_elementwise_fma(ww * dl, dl, S);
+        } else {
+            const vsom_f2 t = cc * dl;
+            M = M + t;                                 // :864
+            vsom_f2 q = ww * dl;
+            q = q * dl;
+            S = S + q;                                 // :867
+        }
+    };
+    auto steps = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float c = (u & 1) ? cv[slot][u >> 1].z : cv[slot][u >> 1].x;
+            const float w = (u & 1) ? cv[slot][u >> 1].w : cv[slot][u >> 1].y;
+            one(x[slot][u], c, w);
+        }
+    };
+    if (nfull > 0) {
+#pragma unroll
+        for (int k = 0; k < NG - 1; ++k)
+            load(k, k);
+    }
+    int g = 0;
+    for (; g + NG <= nfull; g += NG) {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            load((k + NG - 1) % NG, g + k + NG - 1);   // NG-1 groups ahead of the one consumed next
+            steps(k);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NG - 1; ++k)                   // the (< NG) full groups left are already in their slots
+        if (g + k < nfull)
+            steps(k);
+    for (int j = nfull * U; j < B; ++j) {
+        const float2 v = cw[cw2_index(j, ldn, nlc)];
+        one(*reinterpret_cast<const vsom_f2 *>(xp + (size_t)j * ldx), v.x, v.y);
+    }
+    if (valid) {
+        const size_t node = (size_t)(n0 + nl);
+        const float Wf = weight[node];
+        map[node * pitch + d] = M.x;                   // :870
+        sigma[node * pitch + d] = sqrtf(S.x / Wf);     // :873
+        if (d + 1 < D) {
+            map[node * pitch + d + 1] = M.y;
+            sigma[node * pitch + d + 1] = sqrtf(S.y / Wf);
+        }
+    }
+}
+
 // CLR: lane = node, RP pairs per lane; model = [A | B] (Transformation.cpp:107-142)
 template <int RP>
 __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict__ XP,
@@ -994,14 +1115,37 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
             while ((1u << dl_log2) < c->D && dl_log2 < 6)
                 ++dl_log2;
             const unsigned DL = 1u << dl_log2;
-            dim3 grid((unsigned)((nloc + (256 / DL) - 1) / (256 / DL)), (c->D + DL - 1) / DL);
             constexpr int U = 8;
+            // lanes = nloc * D chains; when that is no more than two wavefronts per SIMD, two dims per lane
+            // with a deep load ring (update_chain2_kernel) beat one dim per lane (VSOM_CHAIN2=0/1 overrides)
+            static int chain2_env = -1;
+            if (chain2_env < 0) {
+                const char *e = std::getenv("VSOM_CHAIN2");
+                chain2_env = e ? (e[0] == '1' ? 1 : 0) : 2;
+            }
+            const bool chain2 = chain2_env == 2 ? ((size_t)nloc * c->D <= (size_t)2 * 1024 * 64 && c->D >= 8) : chain2_env == 1;
+            if (chain2) {
+                int pl_log2 = 0;                               // dim pairs per node row of the workgroup
+                while ((2u << pl_log2) < c->D && pl_log2 < 6)
+                    ++pl_log2;
+                const unsigned PL = 1u << pl_log2, npairs = (c->D + 1) / 2;
+                dim3 grid2((unsigned)((nloc + (256 / PL) - 1) / (256 / PL)), (npairs + PL - 1) / PL);
+                constexpr int NG = 4;
+                auto kern2 = c->transform == VSOM_MEDIAN ? update_chain2_kernel<true, U, NG, false>
+                             : (c->update_mode == VSOM_UPDATE_FMA ? update_chain2_kernel<false, U, NG, true>
+                                                                  : update_chain2_kernel<false, U, NG, false>);
+                hipLaunchKernelGGL(kern2, grid2, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->cw, (int)ldn,
+                                   (int)c->B, (int)n0, (int)nloc, (int)c->D, pl_log2, c->map, c->sigma,
+                                   (int)c->pitch, c->weight);
+            } else {
+            dim3 grid((unsigned)((nloc + (256 / DL) - 1) / (256 / DL)), (c->D + DL - 1) / DL);
             auto kern = c->transform == VSOM_MEDIAN ? update_chain_kernel<true, U, false>
                         : (c->update_mode == VSOM_UPDATE_FMA ? update_chain_kernel<false, U, true>
                                                              : update_chain_kernel<false, U, false>);
             hipLaunchKernelGGL(kern, grid, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->cw, (int)ldn,
                                (int)c->B, (int)n0, (int)nloc, (int)c->D, dl_log2, c->map, c->sigma,
                                (int)c->pitch, c->weight);
+            }
         } else {
             constexpr int RD = 16;
             int dbase = 0;
