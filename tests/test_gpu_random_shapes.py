@@ -136,7 +136,16 @@ def test_random_shape_assembly_update(name, W, H, J, B, sigma, seed, tr):
     mse_o = orc.batch_epoch(X, lb, sigma, True)
     ctx.upload_chunk(X)
     mse_g = ctx.batch_epoch(sigma, True)
-    assert _same(ctx.get_last_bmu(), lb), (name, "lastBMU")
+    got = ctx.get_last_bmu()
+    if not _same(got, lb):      # say which samples, what they hold and what a second search returns
+        bad = np.nonzero(got != lb)[0]
+        again = ctx.bmu_batch()[0]
+        ctx.set_bmu_mode(vsom_amd.capi.BMU_EXACT)
+        exact = ctx.bmu_batch()[0]
+        info = [(int(s_), int(lb[s_]), int(got[s_]), int(again[s_]), int(exact[s_]), int(np.isnan(X[s_]).sum()),
+                 int(np.isinf(X[s_]).sum()), int((np.abs(X[s_]) > 1e38).sum())) for s_ in bad[:8]]
+        raise AssertionError((name, "lastBMU", len(bad), "sample/oracle/epoch/again/exact/nan/inf/big", info,
+                              ctx.shortlist_stats()))
     assert _same(np.float32(mse_g), np.float32(mse_o)), (name, "mse")
     st = ctx.get_state()
     for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("weight", orc.weight), ("hits", orc.hits)):

@@ -441,24 +441,27 @@ static int ensure_chunk_capacity(vsom_ctx *c, size_t B)
     c->B = 0;
     c->chunk_loaded = false;
     size_t cap = (B + 63) / 64 * 64;
+    // the fills below go to the context's stream: hipMemset would run on the null stream, which a
+    // non-blocking stream does not wait for -- the fill could then land on top of the rows the staging
+    // kernel writes next (seen as a few zero sample rows in one search of ~600 random cases)
     // the assembly update kernel reads up to 2 sample rows past the chunk and touches rows up to
     // PF_ROWS + 3 past it (gen_update_asm.py, load_cw)
     VSOM_HIP_CHECK(hipMalloc(&c->Xs, (cap + VSOM_ROW_PAD) * c->xpitch * 4));
-    VSOM_HIP_CHECK(hipMemset(c->Xs, 0, (cap + VSOM_ROW_PAD) * c->xpitch * 4));
+    VSOM_HIP_CHECK(hipMemsetAsync(c->Xs, 0, (cap + VSOM_ROW_PAD) * c->xpitch * 4, c->stream));
     if (c->transform == VSOM_CLR) {
         // like Xs: the pipelined update kernels read one sample pair past the chunk
         VSOM_HIP_CHECK(hipMalloc(&c->XP, (cap + VSOM_ROW_PAD) * c->part_pitch * 4));
         VSOM_HIP_CHECK(hipMalloc(&c->YP, (cap + VSOM_ROW_PAD) * c->part_pitch * 4));
-        VSOM_HIP_CHECK(hipMemset(c->XP, 0, (cap + VSOM_ROW_PAD) * c->part_pitch * 4));
-        VSOM_HIP_CHECK(hipMemset(c->YP, 0, (cap + VSOM_ROW_PAD) * c->part_pitch * 4));
+        VSOM_HIP_CHECK(hipMemsetAsync(c->XP, 0, (cap + VSOM_ROW_PAD) * c->part_pitch * 4, c->stream));
+        VSOM_HIP_CHECK(hipMemsetAsync(c->YP, 0, (cap + VSOM_ROW_PAD) * c->part_pitch * 4, c->stream));
     }
     VSOM_HIP_CHECK(hipMalloc(&c->lastbmu, cap * 8));
     VSOM_HIP_CHECK(hipMalloc(&c->sqres, cap * 4));
     VSOM_HIP_CHECK(hipMalloc(&c->bxy, cap * sizeof(int2)));
     VSOM_HIP_CHECK(hipMalloc(&c->nan0, cap));
-    VSOM_HIP_CHECK(hipMemset(c->lastbmu, 0, cap * 8));
-    VSOM_HIP_CHECK(hipMemset(c->sqres, 0, cap * 4));
-    VSOM_HIP_CHECK(hipMemset(c->nan0, 0, cap));
+    VSOM_HIP_CHECK(hipMemsetAsync(c->lastbmu, 0, cap * 8, c->stream));
+    VSOM_HIP_CHECK(hipMemsetAsync(c->sqres, 0, cap * 4, c->stream));
+    VSOM_HIP_CHECK(hipMemsetAsync(c->nan0, 0, cap, c->stream));
     c->Bcap = cap;
     return VSOM_OK;
 }
