@@ -117,3 +117,13 @@ def test_ranks_match_single_context(case):
             assert beq(got[f"mse{ep}"], exp[f"mse{ep}"]), (r, ep, got[f"mse{ep}"], exp[f"mse{ep}"])
         for k in ("map", "sigma", "weight", "hits"):
             assert beq(got[k], st[k]), (r, k)
+
+
+def test_rccl_world_of_one_on_the_aliased_buffers():
+    """tools/dist_smoke.py: a world-size-1 NCCL (RCCL) process group whose collectives run on the zero-copy
+    tensors that alias the library's device buffers -- the code path bench.py --gpus N takes on real peers"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_smoke.py")], capture_output=True, text=True,
+                       timeout=300, env={**os.environ, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    assert r.returncode == 0 and "dist smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

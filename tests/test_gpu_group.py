@@ -148,3 +148,39 @@ def test_group_contracted_mode_and_empty_chunk():
     assert (st["map"] == 0).all() and np.isnan(st["sigma"]).all() and (st["weight"] == 0).all()
     c.close()
     g.close()
+
+
+def _random_group_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        tr = [capi.STANDARD, capi.MEDIAN, capi.CLR][i % 3]
+        W, H = int(rs.randint(2, 40)), int(rs.randint(2, 40))
+        J = int(rs.randint(2, 9)) if tr == capi.CLR else int(rs.choice([1, 3, 8, 17, 33, 64, 100, 200]))
+        B = int(rs.choice([1, 2, 5, 16, 63, 64, 65, 130, 257]))
+        members = int(rs.choice([2, 3, 4, 5]))
+        out.append((f"g{i}_{['std', 'med', 'clr'][tr]}_{W}x{H}x{J}_B{B}_n{members}", W, H, J, tr, B, members,
+                    float(rs.choice([1.5, 3.0, 7.0, 20.0])), int(rs.randint(1, 1 << 30))))
+    return out
+
+
+# VSOM_GROUP_SWEEP_N widens it for occasional long runs (default: 9 cases)
+GROUP_CASES = _random_group_cases(int(__import__("os").environ.get("VSOM_GROUP_SWEEP_N", "9")), 20241004)
+
+
+@pytest.mark.parametrize("name,W,H,J,tr,B,n,sigma,seed", GROUP_CASES, ids=[c[0] for c in GROUP_CASES])
+def test_random_group_shapes_match_oracle(name, W, H, J, tr, B, n, sigma, seed):
+    """random maps / chunks / member counts (more members than samples or nodes included: empty shards):
+    first epoch + two local-search epochs, every member bit-identical to the oracle"""
+    rs = np.random.RandomState(seed)
+    X = (rs.randn(B, J) * rs.choice([0.1, 1.0, 50.0])).astype(np.float32)
+    X[rs.rand(B, J) < 0.1] = 0.0
+    init = gen.random_map(W * H, capi.model_length(tr, J), seed=seed % 1000)
+    g = vsom_amd.Group(W, H, J, tr, devices=[0] * n)
+    sigmas = (sigma, sigma * 0.8, sigma * 0.6)
+    mses, lbs = group_run(g, X, init, sigmas)
+    o, omse, olb = oracle_run(W, H, J, tr, X, init, sigmas)
+    assert all(beq(a, b) for a, b in zip(mses, omse)), name
+    assert all(beq(a, b) for a, b in zip(lbs, olb)), name
+    check_members(g, o)
+    g.close()
