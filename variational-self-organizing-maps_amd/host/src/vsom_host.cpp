@@ -447,9 +447,9 @@ void DataSet::shuffle() {}
 static int g_default_device = 0;
 void Som::setDefaultDevice(int device) { g_default_device = device; }
 
-// Devices a Som trains on.  Empty (default) = every visible device when the environment variable
-// VSOM_DEVICES is unset; VSOM_DEVICES="0,1,2,3" (or Som::setDevices) names them; a single entry keeps
-// the single-GPU path.  More than one entry makes the batch-map training members run through the
+// Devices a Som trains on.  Nothing named: every visible device for maps of at least 1024 nodes, the
+// default device otherwise; VSOM_DEVICES="0,1,2,3" (or Som::setDevices) names them whatever the map size;
+// a single entry keeps the single-GPU path.  More than one entry makes the batch-map training members run through the
 // vsom_group_* entry points (phase 1 sample-sharded, phase 2 node-sharded, all-gathers over xGMI).
 // A list that repeats a device rehearses that flow on one GPU (the library then copies between the
 // members instead of calling RCCL, include/vsom_hip.h).
@@ -461,7 +461,7 @@ void Som::setDevices(const std::vector<int> &devices)
     g_devices_set = true;
 }
 
-static std::vector<int> training_devices()
+static std::vector<int> training_devices(size_t nodes)
 {
     if (g_devices_set)
         return g_devices.empty() ? std::vector<int>{g_default_device} : g_devices;
@@ -475,8 +475,10 @@ static std::vector<int> training_devices()
         if (!out.empty())
             return out;
     }
+    // nothing named: every visible device, but only for maps that have work to shard -- below 1024 nodes a
+    // node shard is a handful of wavefronts (and a group costs an RCCL communicator per Som)
     const int n = vsom_device_count();
-    if (n <= 1)
+    if (n <= 1 || nodes < 1024)
         return {g_default_device};
     for (int d = 0; d < n; ++d)
         out.push_back(d);
@@ -496,7 +498,7 @@ void Som::createContext()
         ctx = nullptr;   // state-less shell: accessors work on zeros, training throws
         return;
     }
-    const std::vector<int> devs = training_devices();
+    const std::vector<int> devs = training_devices(width * height);
     if (devs.size() > 1) {
         check(vsom_group_create(&grp, (int)devs.size(), devs.data(), (uint32_t)width, (uint32_t)height, (uint32_t)inLen, kind),
               "vsom_group_create");
