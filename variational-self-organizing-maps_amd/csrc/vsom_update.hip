@@ -680,6 +680,158 @@ __global__ __launch_bounds__(256, 1) void update_chain2_kernel(const float *__re
     }
 }
 
+// update_chain2_kernel with the operands staged ONCE per workgroup through LDS.  In chain2 every wavefront
+// issues, per sample, a 512-byte x load and half a 1-KB (c,w) load whose lanes mostly repeat addresses --
+// the vector-memory pipe processes every lane's address and return slot, and that, not arithmetic, bounded
+// it (C4: Median and Standard both 0.86 ms).  Here the 256 lanes of a workgroup (NW = 256 >> PLOG nodes x
+// PL = 1 << PLOG dim pairs) fetch each block of CT samples with 16-byte loads that touch every byte once
+// (x: CT rows of PL pairs; (c,w): CT/2 pair rows of NW nodes), two blocks ahead of the one being consumed
+// (registers -> LDS ring of three), and the chains read their operands from LDS as broadcasts.
+template <bool MEDIAN, bool FMA, int PLOG>
+__global__ __launch_bounds__(256, 1) void update_chain3_kernel(const float *__restrict__ Xs, int ldx,
+                                                               const float2 *__restrict__ cw, int ldn, int B,
+                                                               int n0, int nloc, int D,
+                                                               float *__restrict__ map,
+                                                               float *__restrict__ sigma, int pitch,
+                                                               const float *__restrict__ weight)
+{
+    constexpr int PL = 1 << PLOG, NW = 256 >> PLOG, CT = 64;
+    constexpr int XP = CT * PL / 2 / 256;                 // 16-byte pieces of x per thread and block (PL >= 8)
+    constexpr int CP = (CT / 2) * NW / 256 > 0 ? (CT / 2) * NW / 256 : 1;   // ... of (c,w)
+    static_assert(PLOG >= 3 && PLOG <= 6, "8..64 dim pairs per node row");
+    __shared__ __attribute__((aligned(16))) float xs[3][CT][2 * PL];
+    __shared__ __attribute__((aligned(16))) float4 cs[3][CT / 2][NW];
+    if (MEDIAN)
+        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 8, 1), 0");   // DX10_CLAMP off: clamp(NaN) = NaN
+    const int tid = threadIdx.x;
+    const int lnode = tid >> PLOG, lp = tid & (PL - 1);
+    const int nl = blockIdx.x * NW + lnode;
+    const int d = 2 * (blockIdx.y * PL + lp);
+    const bool valid = nl < nloc && d < D;
+    const int nbase = blockIdx.x * NW;                    // first node of the workgroup (local index)
+    const float *xbase = Xs + 2 * blockIdx.y * PL;        // first dim of the workgroup
+    const int nblocks = (B + CT - 1) / CT;
+    const int lastrow = B > 0 ? B - 1 : 0, lastpair = B > 0 ? (B - 1) >> 1 : 0;
+
+    // one thread's share of a block in NAMED registers (arrays behind the lambdas ended up in scratch)
+    auto load_x = [&](int blk, int i) {
+        const int piece = tid + 256 * i;                  // row-major over [CT][PL/2] 16-byte pieces
+        int row = blk * CT + piece / (PL / 2);
+        row = row < lastrow ? row : lastrow;              // clamped: re-reads the last row, never past the chunk
+        return *reinterpret_cast<const float4 *>(xbase + (size_t)row * ldx + 4 * (piece % (PL / 2)));
+    };
+    auto load_c = [&](int blk, int i) {
+        int piece = tid + 256 * i;                        // row-major over [CT/2][NW]
+        piece = piece < (CT / 2) * NW ? piece : (CT / 2) * NW - 1;   // (fewer pieces than threads: PL = 64)
+        int pr = blk * (CT / 2) + piece / NW;
+        pr = pr < lastpair ? pr : lastpair;
+        int node = nbase + piece % NW;
+        node = node < nloc ? node : nloc - 1;
+        return reinterpret_cast<const float4 *>(cw)[(size_t)pr * ldn + node];
+    };
+    auto store_x = [&](int slot, int i, float4 v) {
+        const int piece = tid + 256 * i;
+        *reinterpret_cast<float4 *>(&xs[slot][piece / (PL / 2)][4 * (piece % (PL / 2))]) = v;
+    };
+    auto store_c = [&](int slot, int i, float4 v) {
+        const int piece = tid + 256 * i;
+        if (piece < (CT / 2) * NW)
+            cs[slot][piece / NW][piece % NW] = v;
+    };
+    float4 gx0, gx1, gx2, gx3, gx4, gx5, gx6, gx7, gc0, gc1, gc2, gc3;
+#define VSOM_C3_LOAD(blk)                                                                       \
+    do {                                                                                        \
+        gx0 = load_x(blk, 0);                                                                   \
+        if (XP > 1) gx1 = load_x(blk, 1);                                                       \
+        if (XP > 2) { gx2 = load_x(blk, 2); gx3 = load_x(blk, 3); }                             \
+        if (XP > 4) { gx4 = load_x(blk, 4); gx5 = load_x(blk, 5); gx6 = load_x(blk, 6); gx7 = load_x(blk, 7); } \
+        gc0 = load_c(blk, 0);                                                                   \
+        if (CP > 1) gc1 = load_c(blk, 1);                                                       \
+        if (CP > 2) { gc2 = load_c(blk, 2); gc3 = load_c(blk, 3); }                             \
+    } while (0)
+#define VSOM_C3_STORE(slot)                                                                     \
+    do {                                                                                        \
+        store_x(slot, 0, gx0);                                                                  \
+        if (XP > 1) store_x(slot, 1, gx1);                                                      \
+        if (XP > 2) { store_x(slot, 2, gx2); store_x(slot, 3, gx3); }                           \
+        if (XP > 4) { store_x(slot, 4, gx4); store_x(slot, 5, gx5); store_x(slot, 6, gx6); store_x(slot, 7, gx7); } \
+        store_c(slot, 0, gc0);                                                                  \
+        if (CP > 1) store_c(slot, 1, gc1);                                                      \
+        if (CP > 2) { store_c(slot, 2, gc2); store_c(slot, 3, gc3); }                           \
+    } while (0)
+
+    vsom_f2 M = {0.f, 0.f}, S = {0.f, 0.f};               // :843-844
+    const vsom_f2 big = {0x1.0p100f, 0x1.0p100f};
+    auto one = [&](vsom_f2 xv, float c, float w) {        // the same operations as update_chain2_kernel's
+        const vsom_f2 cc = {c, c}, ww = {w, w};
+        vsom_f2 dl = xv - M;
+        if (MEDIAN) {
+            const vsom_f2 t = dl * big;
+            const vsom_f2 pp = vsom_pk_mul_clamp(t, big), nn = vsom_pk_mul_negclamp(t, big);
+            M = __builtin_elementwise_fma(cc, pp, M);
+            M = __builtin_elementwise_fma(-cc, nn, M);
+            S = __builtin_elementwise_fma(ww, pp, S);
+            S = __builtin_elementwise_fma(ww, nn, S);
+        } else if (FMA) {
+            M = __builtin_elementwise_fma(cc, dl, M);
+            S = __builtin_elementwise_fma(ww * dl, dl, S);
+        } else {
+            const vsom_f2 t = cc * dl;
+            M = M + t;
+            vsom_f2 q = ww * dl;
+            q = q * dl;
+            S = S + q;
+        }
+    };
+
+    // blocks past the end are clamped re-reads of the last rows (loaded and stored, never consumed): the
+    // pipeline has no conditional loads
+    VSOM_C3_LOAD(0);
+    VSOM_C3_STORE(0);
+    VSOM_C3_LOAD(1);
+    VSOM_C3_STORE(1);
+    __syncthreads();
+    for (int blk = 0; blk < nblocks; ++blk) {
+        const int slot = blk % 3;
+        VSOM_C3_LOAD(blk + 2);                            // in flight while this block is consumed
+        const int nt = B - blk * CT < CT ? B - blk * CT : CT;
+        constexpr int U = 8;                              // operands of U samples read from LDS before use
+        int t = 0;
+        for (; t + U <= nt; t += U) {
+            vsom_f2 xv[U];
+            float4 cv[U / 2];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                xv[u] = *reinterpret_cast<const vsom_f2 *>(&xs[slot][t + u][2 * lp]);
+#pragma unroll
+            for (int u = 0; u < U / 2; ++u)
+                cv[u] = cs[slot][(t >> 1) + u][lnode];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                one(xv[u], (u & 1) ? cv[u >> 1].z : cv[u >> 1].x, (u & 1) ? cv[u >> 1].w : cv[u >> 1].y);
+        }
+        for (; t < nt; ++t) {
+            const float4 cv = cs[slot][t >> 1][lnode];
+            one(*reinterpret_cast<const vsom_f2 *>(&xs[slot][t][2 * lp]), (t & 1) ? cv.z : cv.x, (t & 1) ? cv.w : cv.y);
+        }
+        VSOM_C3_STORE((blk + 2) % 3);                     // slot (blk+2)%3 was last read in iteration blk-1
+        __syncthreads();
+    }
+    if (valid) {
+        const size_t node = (size_t)(n0 + nl);
+        const float Wf = weight[node];
+        map[node * pitch + d] = M.x;                      // :870
+        sigma[node * pitch + d] = sqrtf(S.x / Wf);        // :873
+        if (d + 1 < D) {
+            map[node * pitch + d + 1] = M.y;
+            sigma[node * pitch + d + 1] = sqrtf(S.y / Wf);
+        }
+    }
+}
+
+#undef VSOM_C3_LOAD
+#undef VSOM_C3_STORE
+
 // CLR: lane = node, RP pairs per lane; model = [A | B] (Transformation.cpp:107-142)
 template <int RP>
 __global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict__ XP,
@@ -1131,12 +1283,34 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 const unsigned PL = 1u << pl_log2, npairs = (c->D + 1) / 2;
                 dim3 grid2((unsigned)((nloc + (256 / PL) - 1) / (256 / PL)), (npairs + PL - 1) / PL);
                 constexpr int NG = 4;
-                auto kern2 = c->transform == VSOM_MEDIAN ? update_chain2_kernel<true, U, NG, false>
-                             : (c->update_mode == VSOM_UPDATE_FMA ? update_chain2_kernel<false, U, NG, true>
-                                                                  : update_chain2_kernel<false, U, NG, false>);
+                const bool med = c->transform == VSOM_MEDIAN, fma = c->update_mode == VSOM_UPDATE_FMA;
+                static int chain3_env = -1;                    // VSOM_CHAIN3=0: the register-ring kernel (development)
+                if (chain3_env < 0) {
+                    const char *e = std::getenv("VSOM_CHAIN3");
+                    chain3_env = e && e[0] == '0' ? 0 : 1;
+                }
+                const void *k3 = nullptr;                      // operands staged through LDS: 8..64 dim pairs per row
+#define VSOM_K3(P) (med ? (const void *)update_chain3_kernel<true, false, P> \
+                        : (fma ? (const void *)update_chain3_kernel<false, true, P> : (const void *)update_chain3_kernel<false, false, P>))
+                if (chain3_env && pl_log2 >= 3 && pl_log2 <= 6)
+                    k3 = pl_log2 == 3 ? VSOM_K3(3) : pl_log2 == 4 ? VSOM_K3(4) : pl_log2 == 5 ? VSOM_K3(5) : VSOM_K3(6);
+#undef VSOM_K3
+                if (k3) {
+                    const float *xs_ = c->Xs;
+                    const float2 *cw_ = c->cw;
+                    int ildx = (int)c->xpitch, ildn = (int)ldn, iB = (int)c->B, in0 = (int)n0, inl = (int)nloc, iD = (int)c->D,
+                        ipitch = (int)c->pitch;
+                    float *map_ = c->map, *sg_ = c->sigma;
+                    const float *wt_ = c->weight;
+                    void *args[] = {&xs_, &ildx, &cw_, &ildn, &iB, &in0, &inl, &iD, &map_, &sg_, &ipitch, &wt_};
+                    VSOM_HIP_CHECK(hipLaunchKernel(k3, grid2, dim3(256), args, 0, c->stream));
+                } else {
+                auto kern2 = med ? update_chain2_kernel<true, U, NG, false>
+                                 : (fma ? update_chain2_kernel<false, U, NG, true> : update_chain2_kernel<false, U, NG, false>);
                 hipLaunchKernelGGL(kern2, grid2, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->cw, (int)ldn,
                                    (int)c->B, (int)n0, (int)nloc, (int)c->D, pl_log2, c->map, c->sigma,
                                    (int)c->pitch, c->weight);
+                }
             } else {
             dim3 grid((unsigned)((nloc + (256 / DL) - 1) / (256 / DL)), (c->D + DL - 1) / DL);
             auto kern = c->transform == VSOM_MEDIAN ? update_chain_kernel<true, U, false>
