@@ -104,6 +104,20 @@ def test_batch_training_on_a_preloaded_dataset(dumps):
     assert beq(dump["mse"], np.array(mse, np.float32))
 
 
+def test_online_then_batch_on_the_same_map(dumps):
+    """two online epochs, then two batch-map epochs (with a group: member 0 trained alone, replicas re-synchronised)"""
+    d, _, _ = dumps
+    rows = make_rows(50, 9, 12345)
+    o = po.OracleSom(10, 10, 9, po.STANDARD)
+    o.random_initialize(13, 1.0)
+    mse1 = o.train_online(rows, [0, 20, 40, 50], 2, 0.05, 0.1, 4.0, 0.3, po.EXPONENTIAL)
+    done, mse2 = o.train_batch(rows, [0, 20, 40, 50], 2, 5.0, 0.2, nthreads=2)
+    assert done == 2
+    dump = read_dump(os.path.join(d, "online_then_batch.bin"))
+    check_state(dump, o, with_S=True)
+    assert beq(dump["mse"], np.concatenate([mse1, mse2]).astype(np.float32))
+
+
 def test_online_training_through_cpp_api(dumps):
     d, _, _ = dumps
     rows = make_rows(50, 9, 12345)

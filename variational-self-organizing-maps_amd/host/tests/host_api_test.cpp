@@ -169,6 +169,20 @@ int main(int argc, char **argv)
         som.train(ds, 3, 0.0, 0.0, 6.0, 0.2, Som::WeigthDecayFunction::BatchMap);
         dump(out + "/batch_preloaded.bin", som, som.getMetrics().MeanSquaredError);
     }
+    // ---- online epochs, then batch-map epochs on the SAME map (with several devices the online path trains
+    //      member 0 only and the other members take its state over before the sharded epochs) ----
+    {
+        ArrayDataLoader loader(rows.data(), NROWS, J, CHUNK);
+        DataSet ds(loader);
+        Som som{W, H, ds, Transformation::Standard(loader.getNames())};
+        som.randomInitialize(13, 1);
+        som.train(ds, 2, 0.05, 0.1, 4.0, 0.3, Som::WeigthDecayFunction::Exponential);
+        auto mse = som.getMetrics().MeanSquaredError;
+        som.train(ds, 2, 0.0, 0.0, 5.0, 0.2, Som::WeigthDecayFunction::BatchMap);
+        for (float v : som.getMetrics().MeanSquaredError)
+            mse.push_back(v);
+        dump(out + "/online_then_batch.bin", som, mse);
+    }
     // ---- online, exponential decay, median estimator ----
     {
         ArrayDataLoader loader(rows.data(), NROWS, J, CHUNK);
