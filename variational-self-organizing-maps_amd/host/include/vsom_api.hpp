@@ -483,6 +483,9 @@ public:
     // devices the batch-map training runs on: {} = all visible (or the list in VSOM_DEVICES), one entry =
     // single GPU, several = sample/node-sharded epochs through vsom_group_* (vsom_host.cpp, training_devices)
     static void setDevices(const std::vector<int> &devices);
+    // arithmetic of the Standard update chains of Soms created afterwards: false = strict, bit-identical to
+    // the reference (default); true = contracted (fused multiply-adds, results within 1e-5: vsom_hip.h)
+    static void setContractedArithmetic(bool on);
     vsom_ctx *context() const noexcept { return ctx; }
     vsom_group *group() const noexcept { return grp; }
 

@@ -461,6 +461,19 @@ void Som::setDevices(const std::vector<int> &devices)
     g_devices_set = true;
 }
 
+// Arithmetic of the Standard update chains for the Soms created from now on: strict (default: bit-identical
+// to the reference) or contracted (include/vsom_hip.h, VSOM_UPDATE_FMA: within the 1e-5 tolerance, a third
+// fewer instructions).  VSOM_UPDATE_MODE=contracted in the environment selects it without a code change.
+static int g_update_mode = -1;
+void Som::setContractedArithmetic(bool on) { g_update_mode = on ? VSOM_UPDATE_FMA : VSOM_UPDATE_STRICT; }
+static int update_mode()
+{
+    if (g_update_mode >= 0)
+        return g_update_mode;
+    const char *e = std::getenv("VSOM_UPDATE_MODE");
+    return e && (std::string(e) == "contracted" || std::string(e) == "fma") ? VSOM_UPDATE_FMA : VSOM_UPDATE_STRICT;
+}
+
 static std::vector<int> training_devices(size_t nodes)
 {
     if (g_devices_set)
@@ -504,9 +517,11 @@ void Som::createContext()
               "vsom_group_create");
         ctx = vsom_group_ctx(grp, 0);     // searches, getters and the online path use member 0 (the state is replicated)
         replicasStale = false;
+        check(vsom_group_set_update_mode(grp, update_mode()), "vsom_group_set_update_mode");
         return;
     }
     check(vsom_create(&ctx, devs[0], (uint32_t)width, (uint32_t)height, (uint32_t)inLen, kind), "vsom_create");
+    check(vsom_set_update_mode(ctx, update_mode()), "vsom_set_update_mode");
 }
 
 void Som::destroyContext()
