@@ -22,9 +22,12 @@
 
 typedef unsigned long long u64;
 
-// lane = node update kernels yield ceil(N/64)*ceil(D/16) wavefronts; at or below this many the
-// (node, dim)-per-lane chain kernel is used instead (1024 SIMDs on the chip)
-#define VSOM_CHAIN_MAX_WAVES 256
+// lane = node update kernels yield ceil(N/64)*ceil(D/14) wavefronts; at or below this many the
+// (node, dim pair)-per-lane chain kernels are used instead (1024 SIMDs on the chip).  While every wavefront
+// has a SIMD to itself the assembly kernels take ~0.12 us per sample whatever the map, the LDS-staged chain
+// kernel ~2.2e-13 s per (node, dim, sample): they meet near N*D = 4e5 (tools/exp/chain_crossover.py:
+// 4096 x 128: 0.99 vs 1.12 ms at B = 8192; 4096 x 64: ~2 vs 0.75 ms at B = 16384)
+#define VSOM_CHAIN_MAX_WAVES 448
 
 #define VSOM_TK 32          // K-chunk of the tile kernels; row pitches are multiples of it
 

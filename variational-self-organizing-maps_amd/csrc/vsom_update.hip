@@ -1134,6 +1134,20 @@ __global__ void zero_weight_kernel(float *__restrict__ weight, int n0, int nloc)
         weight[n0 + i] = 0.f;
 }
 
+// lane = node assembly kernels need wavefronts: ceil(nodes/64) * ceil(D/14) of them for 1024 SIMDs.  Below
+// this many the chain kernels (lane = (node, dim pair), operands through LDS) are faster although they pay
+// an LDS read per operand where the assembly kernels take x from SGPRs (measured crossover, DESIGN.md
+// section 4; VSOM_CHAIN_MAX_WAVES overrides, development)
+static size_t vsom_chain_max_waves()
+{
+    static long v = -1;
+    if (v < 0) {
+        const char *e = std::getenv("VSOM_CHAIN_MAX_WAVES");
+        v = e ? std::atol(e) : VSOM_CHAIN_MAX_WAVES;
+    }
+    return (size_t)v;
+}
+
 int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
 {
     if (n1 <= n0)
@@ -1261,8 +1275,8 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                                    (int)c->part_len, (int)c->part_pitch, nsl, pbase, c->map, c->sigma,
                                    (int)c->pitch, c->weight);
             }
-        } else if ((size_t)gx * ((c->D + 15) / 16) <= VSOM_CHAIN_MAX_WAVES && c->use_chain) {
-            // lane = node would leave most SIMDs idle: one lane per (node, dim) chain instead
+        } else if ((size_t)gx * ((c->D + 13) / 14) <= vsom_chain_max_waves() && c->use_chain) {
+            // lane = node would leave most SIMDs idle: one lane per (node, dim pair) chain instead
             int dl_log2 = 0;
             while ((1u << dl_log2) < c->D && dl_log2 < 6)
                 ++dl_log2;
@@ -1275,7 +1289,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 const char *e = std::getenv("VSOM_CHAIN2");
                 chain2_env = e ? (e[0] == '1' ? 1 : 0) : 2;
             }
-            const bool chain2 = chain2_env == 2 ? ((size_t)nloc * c->D <= (size_t)2 * 1024 * 64 && c->D >= 8) : chain2_env == 1;
+            const bool chain2 = chain2_env != 0;   // VSOM_CHAIN2=0: r1's one-dim-per-lane kernel (development)
             if (chain2) {
                 int pl_log2 = 0;                               // dim pairs per node row of the workgroup
                 while ((2u << pl_log2) < c->D && pl_log2 < 6)
