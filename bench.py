@@ -324,7 +324,7 @@ def main():
     dt, timing = timed(args.warmup, args.steps)
 
     other = None
-    if not args.no_other_arith and not online:
+    if not args.no_other_arith and not online and capi.has_contracted(tr):   # Median / CLR have one arithmetic
         other_name = "strict" if args.arith == "contracted" else "contracted"
         ctx.set_update_mode(mode_of[other_name])
         dto, tmo = timed(2, args.steps)
