@@ -12,6 +12,8 @@ for spec in sys.argv[1:]:
     X = gen.mnist_like(B, 3, D)
     ctx = vsom_amd.Context(W, W, D)
     ctx.set_state(map=init)
+    if os.environ.get("VSOM_SIM_FMA"):
+        ctx.set_update_mode(1)
     ctx.upload_chunk(X)
     ctx.batch_phase1_async(0, min(B, 4096), True)
     ctx.batch_finish_async()
