@@ -12,23 +12,33 @@ GPU, the rank's own samples already resident in HBM when the timed region starts
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1 (weak scaling): every rank OWNS 4096 samples of the 4096*N-sample chunk.  Inside the timed
-step the chunk is replicated with an RCCL all-gather of X (the node-sharded phase 2 reads every
-sample), phase 1 runs on the rank's samples, lastBMU / ||residual||^2 are all-gathered, phase 2
-runs on the rank's 16384/N nodes and the new map rows are all-gathered
-(variational-self-organizing-maps_amd/dist.py).  When WORLD_SIZE is unset and --gpus N > 1 this
-script starts the N ranks itself (python -m torch.distributed.run as a child process, before
-anything in this process touches the GPU) and exits with the child's status.
+N > 1: BASELINE.json's config 3 is "128x128 map, batch=4096 sharded across 8 GPUs", so `value` is
+the STRONG split -- the 4096-sample chunk of the step is shared out, rank r OWNS rows [4096 r/N,
+4096 (r+1)/N) -- and `scaling` says "strong".  (One chunk of 4096*N samples would be a different
+algorithmic step: every chunk OVERWRITES the map with its own weighted mean, Som.cpp:870.)  The weak
+variant (every rank owns 4096 samples of a 4096*N chunk) is timed in the same run and reported as
+`weak_scaling`; --scaling weak makes it the `value`.  Inside the timed step the chunk is replicated
+with an all-gather of X (the node-sharded phase 2 reads every sample), phase 1 runs on the rank's
+samples, lastBMU / ||residual||^2 are all-gathered, phase 2 runs on the rank's 16384/N nodes and
+the new map rows are all-gathered (variational-self-organizing-maps_amd/dist.py; `backend` names the
+transport, `rccl_ranks` counts ranks only when it is RCCL).  When WORLD_SIZE is unset and --gpus
+N > 1 this script starts the N ranks itself (python -m torch.distributed.run as a child process,
+before anything in this process touches the GPU) and exits with the child's status.
+--group times the other multi-GPU front end instead: ONE process, vsom_group_batch_epoch_async over
+the N devices (csrc/vsom_group.hip -- what a C++ caller of Som::train gets with VSOM_DEVICES set).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel of
 the configuration, HIP-event time on the stream it runs on) and `cpu_baseline` (the CPU oracle
 timed on this box's host cores on a bounded sample of the same workload).
 
-Arithmetic of the update chains (--arith): `contracted` (default; M = fma(c,d,M), S = fma(w*d,d,S):
-within the 1e-5 relative fp32 tolerance BASELINE.json's north_star states -- measured <= 4e-7
-element-wise, tests/test_gpu_fma_mode.py -- with BMU indices, bmuHits, MSE and weightMap
-bit-exact) or `strict` (one rounding per fp32 operation: map / sigmaMap bit-identical to the
-reference's SSE2 arithmetic).  The other mode is timed in the same run and reported beside it.
+Arithmetic of the update chains (--arith, include/vsom_hip.h vsom_update_mode): `strict` (default, and the
+library's default: one rounding per fp32 operation, everything bit-identical to the reference's SSE2
+arithmetic over whole schedules -- what `value` is quoted on), `sigma` (only S = fma(w*d,d,S) contracted:
+map, BMU indices, bmuHits, MSE, weightMap still bit-identical over whole schedules, sigmaMap within 1e-5
+relative; tests/test_gpu_fma_schedule.py) or `contracted` (M = fma(c,d,M) too: within 1e-5 for ONE epoch
+from a given map, but a schedule leaves the reference's trajectory -- profiles/r3_fma_schedule.jsonl -- so
+it is a throughput figure, not a parity mode).  The other two are timed in the same run and reported
+beside the headline (`other_arithmetics`).
 """
 import argparse
 import json
@@ -75,10 +85,17 @@ def parse():
     ap.add_argument("--dim", type=int, default=None, help="sample length J (overrides the config)")
     ap.add_argument("--chunk", type=int, default=None, help="samples per GPU per step (overrides the config)")
     ap.add_argument("--sigma", type=float, default=None)
-    ap.add_argument("--strong", action="store_true", help="fixed total chunk (strong scaling)")
+    ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto",
+                    help="N > 1: what `value` is quoted on.  auto = strong (BASELINE config 3: the 4096-sample chunk "
+                         "sharded across the GPUs); the other split is timed too and reported beside it")
+    ap.add_argument("--strong", action="store_true", help="alias of --scaling strong")
+    ap.add_argument("--no-other-scaling", action="store_true", help="skip the second (other-split) timed run at N > 1")
+    ap.add_argument("--group", action="store_true",
+                    help="N > 1 in ONE process through vsom_group_* (csrc/vsom_group.hip) instead of one process per "
+                         "GPU over torch.distributed; with --share-device every member uses device 0 (rehearsal)")
     ap.add_argument("--local", action="store_true", help="time the later-epoch (findLocalBmu) pass")
-    ap.add_argument("--arith", choices=["contracted", "strict"], default="contracted",
-                    help="arithmetic of the update chains for `value` (the other one is reported beside it)")
+    ap.add_argument("--arith", choices=["strict", "sigma", "contracted"], default="strict",
+                    help="arithmetic of the update chains for `value` (the others are reported beside it)")
     ap.add_argument("--no-other-arith", action="store_true", help="skip the second (other-arithmetic) timed run")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -97,6 +114,10 @@ def parse():
         if getattr(args, k) is not None:
             cfg[k] = getattr(args, k)
     args.cfg = cfg
+    if args.strong:
+        args.scaling = "strong"
+    if args.scaling == "auto":
+        args.scaling = "strong"
     return args
 
 
@@ -117,6 +138,11 @@ def self_launch(args):
 def make_data(cfg, n, seed):
     import gen
     if cfg["data"] == "mnist":
+        d = os.environ.get("VSOM_MNIST_DIR")
+        if d:       # the real training images when the IDX files are at hand (none in the build image)
+            x = gen.mnist_idx(d, n, offset=(seed - 3) * n, dim=cfg["dim"])
+            if x is not None:
+                return x
         return gen.mnist_like(n, seed=seed, dim=cfg["dim"])
     if cfg["data"] == "blobs":
         return gen.blobs(n, cfg["dim"], 8, 1, seed, sigma=1.0)
@@ -200,8 +226,20 @@ def profile_traffic(key):
     return None, None
 
 
+ARITH_MODES = ("strict", "sigma", "contracted")
+ARITH_TEXT = {
+    "strict": "strict (library default; everything bit-identical to the CPU oracle over whole schedules)",
+    "sigma": ("sigma-contracted (S = fma(w*d,d,S) only: map / BMU indices / bmuHits / MSE / weightMap bit-identical over "
+              "whole schedules, sigmaMap within 1e-5 relative: tests/test_gpu_fma_schedule.py)"),
+    "contracted": ("contracted (M and S chains fused: within 1e-5 for ONE epoch from a given map; a multi-epoch schedule "
+                   "leaves the reference's trajectory, profiles/r3_fma_schedule.jsonl -- throughput figure, not a parity mode)"),
+}
+
+
 def main():
     args = parse()
+    if args.group:
+        return main_group(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
@@ -216,6 +254,7 @@ def main():
     import vsom_amd
     from vsom_amd import capi
     import importlib
+    import gen
     vdist = importlib.import_module("variational-self-organizing-maps_amd.dist")
 
     if not torch.cuda.is_available():
@@ -224,7 +263,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
+        backend = args.backend
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -233,12 +274,8 @@ def main():
     W = H = cfg["map"]
     J = cfg["dim"]
     tr = cfg["transform"]
-    Bper = cfg["chunk"]
     sigma = cfg["sigma"]
     sharded = world > 1 and not online           # the online path is strictly sequential: replicas only
-    if args.strong and sharded:
-        Bper = Bper // world
-    Bglob = Bper * world if sharded else Bper
 
     stream = torch.cuda.Stream(device=dev)
     ctx = vsom_amd.Context(W, H, J, tr, device=local_rank)
@@ -249,28 +286,48 @@ def main():
     trainer = vdist.ShardedBatchTrainer(eng, rank if sharded else 0, world if sharded else 1)
     is_first = not args.local
 
-    # synthetic data: rank r owns rows [r*Bper, (r+1)*Bper) of every chunk -- generated with a
-    # per-(chunk, rank) seed, so no rank ever holds another rank's rows before the all-gather
-    own_host = [make_data(cfg, Bper, seed=3 + i + 1000 * (rank if sharded else 0)) for i in range(args.nchunks)]
-    own = [torch.from_numpy(c).to(dev) for c in own_host]
-    full = torch.empty((Bglob, J), dtype=torch.float32, device=dev) if sharded else None
+    # synthetic data.  Chunk i of the job is the same 4096-row matrix whatever N is: strong scaling
+    # gives rank r rows [lo_r, hi_r) of it (generated whole from the chunk's seed, then sliced: 50 ms of host work
+    # per chunk, outside every timed region); weak scaling gives every rank its own chunk-sized matrix (seed per
+    # (chunk, rank)), i.e. a 4096*N-row step.  No rank holds another rank's rows before the all-gather.
+    Bcfg = cfg["chunk"]
+
+    class Split:
+        def __init__(self, kind):
+            self.kind = kind
+            if not sharded:
+                self.Bper, self.Bglob, self.lo = Bcfg, Bcfg, 0
+                self.own_host = [make_data(cfg, Bcfg, seed=3 + i) for i in range(args.nchunks)]
+            elif kind == "strong":
+                lo, hi = vdist.shard_bounds(Bcfg, world, rank)
+                if Bcfg % world:
+                    raise SystemExit("--scaling strong needs the chunk to divide by the number of GPUs")
+                self.Bper, self.Bglob, self.lo = hi - lo, Bcfg, lo
+                self.own_host = [np.ascontiguousarray(make_data(cfg, Bcfg, seed=3 + i)[lo:hi]) for i in range(args.nchunks)]
+            else:
+                self.Bper, self.Bglob, self.lo = Bcfg, Bcfg * world, Bcfg * rank
+                self.own_host = [make_data(cfg, Bcfg, seed=3 + i + 1000 * rank) for i in range(args.nchunks)]
+            self.own = [torch.from_numpy(c).to(dev) for c in self.own_host]
+            self.full = torch.empty((self.Bglob, J), dtype=torch.float32, device=dev) if sharded else None
+
+    split = Split(args.scaling if sharded else "single")
     torch.cuda.synchronize()
 
     pinned = None
     if args.host_chunks != "off":
         if world != 1 or online:
             raise SystemExit("--host-chunks is a single-GPU batch measurement")
-        pinned = [capi.PinnedBuffer(c.shape) for c in own_host]
-        for pb, c in zip(pinned, own_host):
+        pinned = [capi.PinnedBuffer(c.shape) for c in split.own_host]
+        for pb, c in zip(pinned, split.own_host):
             pb.array[...] = c
         if args.host_chunks == "overlap":
             ctx.prefetch_chunk(pinned[0].array)
 
-    def step(i):
+    def step(sp, i):
         with torch.cuda.stream(stream):
             if online:
                 # Som::trainBasicSom's sample loop over one staged chunk (Som.cpp:1159-1171)
-                eng.load_chunk_device(own[i % len(own)])
+                eng.load_chunk_device(sp.own[i % len(sp.own)])
                 check = capi.lib().vsom_train_online_chunk(ctx._h, 0.1, float(sigma), capi.EXPONENTIAL, None)
                 if check:
                     raise RuntimeError(capi.lib().vsom_last_error().decode())
@@ -282,18 +339,18 @@ def main():
                 ctx.commit_chunk()                                   # chunk i (copied during step i-1)
                 eng._bind_chunk()
             elif sharded:
-                # chunk replication: every rank contributes its Bper rows (RCCL all-gather over xGMI)
-                dist.all_gather_into_tensor(full, own[i % len(own)])
-                eng.load_chunk_device(full)
+                # chunk replication: every rank contributes its own rows (all-gather over xGMI)
+                dist.all_gather_into_tensor(sp.full, sp.own[i % len(sp.own)])
+                eng.load_chunk_device(sp.full)
             else:
-                eng.load_chunk_device(own[i % len(own)])   # staging + lastBMU reset (DataSet.cpp:118-160)
+                eng.load_chunk_device(sp.own[i % len(sp.own)])   # staging + lastBMU reset (DataSet.cpp:118-160)
             trainer.epoch(sigma, is_first)
             if args.host_chunks == "overlap":
                 ctx.prefetch_chunk(pinned[(i + 1) % len(pinned)].array)   # H2D of chunk i+1 beside this epoch
 
-    def timed(nwarm, nsteps):
+    def timed(sp, nwarm, nsteps):
         for i in range(nwarm):
-            step(i)
+            step(sp, i)
         trainer.flush()
         torch.cuda.synchronize()
         ctx.get_timing(reset=True)
@@ -303,7 +360,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(nsteps):
-            step(nwarm + i)
+            step(sp, nwarm + i)
         trainer.flush()
         torch.cuda.synchronize()
         if world > 1:
@@ -318,34 +375,46 @@ def main():
             dt = float(t.item())
         return dt, tm
 
-    # the library applies the contracted mode to the chains that have one (vsom_hip.h, vsom_update_mode)
-    mode_of = {"contracted": capi.UPDATE_FMA, "strict": capi.UPDATE_STRICT}
+    # the library applies the contracted modes to the chains that have one (vsom_hip.h, vsom_update_mode)
+    mode_of = {"contracted": capi.UPDATE_FMA, "strict": capi.UPDATE_STRICT, "sigma": capi.UPDATE_FMA_SIGMA}
     ctx.set_update_mode(mode_of[args.arith])
-    dt, timing = timed(args.warmup, args.steps)
-
-    other = None
-    if not args.no_other_arith and not online and capi.has_contracted(tr):   # Median / CLR have one arithmetic
-        other_name = "strict" if args.arith == "contracted" else "contracted"
-        ctx.set_update_mode(mode_of[other_name])
-        dto, tmo = timed(2, args.steps)
-        ctx.set_update_mode(mode_of[args.arith])
-        other = (other_name, dto, tmo)
-
-    rccl_ranks = 1
-    if world > 1:
-        one = torch.ones(1, dtype=torch.int32, device=dev)
-        dist.all_reduce(one)
-        rccl_ranks = int(one.item())
-
+    dt, timing = timed(split, args.warmup, args.steps)
     mse = float(ctx.get_mse())
     sl_stats = ctx.shortlist_stats() if not online else None
+
+    others = []
+    if not args.no_other_arith and not online and capi.has_contracted(tr):   # Median / CLR have one arithmetic
+        for name in ARITH_MODES:
+            if name == args.arith:
+                continue
+            ctx.set_update_mode(mode_of[name])
+            dto, tmo = timed(split, 2, args.steps)
+            others.append((name, dto, tmo))
+        ctx.set_update_mode(mode_of[args.arith])
+
+    other_split = None
+    if sharded and not args.no_other_scaling:
+        sp2 = Split("weak" if args.scaling == "strong" else "strong")
+        torch.cuda.synchronize()
+        dt2, tm2 = timed(sp2, 2, args.steps)
+        other_split = (sp2, dt2, tm2)
+
+    # how many ranks really took part in a collective -- and over what: only the nccl backend is RCCL
+    coll_ranks = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        coll_ranks = int(one.item())
+
     if rank == 0:
         N = W * H
         n_nodes_rank = vdist.shard_bounds(N, world, 0)[1] if sharded else N
         steps = args.steps
-        units = Bglob if sharded else Bper * world      # replicas: every rank processes its own chunk
 
-        def roofline_for(tm):
+        def units_of(sp):
+            return sp.Bglob if sharded else sp.Bper * world      # replicas: every rank processes its own chunk
+
+        def roofline_for(tm, sp):
             if online:
                 # HBM / Infinity-Cache bound: per sample a scan of the map (4*N*D B) + the window's
                 # read-modify-write of M, S, sigma (20*k*D B), k = window nodes  
@@ -353,7 +422,7 @@ def main():
                 k = side * side
                 bytes_sample = 4.0 * N * D + 20.0 * k * D
                 t_ms, cnt = tm["online"]
-                per_sample_s = t_ms / 1e3 / max(steps * Bper, 1)
+                per_sample_s = t_ms / 1e3 / max(steps * sp.Bper, 1)
                 ach = bytes_sample / per_sample_s / 1e9 if per_sample_s > 0 else 0.0
                 return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBPS, 4),
@@ -368,52 +437,59 @@ def main():
             # Standard / Median; CLR: 15 flop per (node, parameter pair, sample) -- the operation count of
             # Transformation.cpp:107-142 + Som.cpp:861-867 (SURVEY rounds it to 16)
             if tr == capi.CLR:
-                flops = 15.0 * n_nodes_rank * (D // 2) * Bglob
+                flops = 15.0 * n_nodes_rank * (D // 2) * sp.Bglob
             else:
-                flops = 6.0 * n_nodes_rank * D * Bglob
+                flops = 6.0 * n_nodes_rank * D * sp.Bglob
             ach = flops / upd_avg_s / 1e12 if upd_avg_s > 0 else 0.0
-            kern = {capi.STANDARD: "vsom_update_{std,fma}_rd14/16_gfx950 (phase-2 mean/sigma^2 chains, hand-scheduled)",
+            kern = {capi.STANDARD: "vsom_update_{std,sfma,fma}_rd14/16_gfx950 (phase-2 mean/sigma^2 chains, hand-scheduled)",
                     capi.MEDIAN: "update chain kernel, median stepper (phase-2 chains)",
                     capi.CLR: "vsom_update_clr_rp8_gfx950 (phase-2 CLR chains, hand-scheduled)"}[tr]
             return {"bound": "valu_fp32", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / FP32_PEAK_TFLOPS, 4), "kernel": kern,
                     "note": ("fp32 VALU-bound chains priced against the fp32 dense peak the vector and matrix pipes "
                              "share (157.3 TFLOP/s counts an FMA as 2 flop); of the 6 algorithmic flop per element "
-                             "4 fit into 2 FMAs, so contracted arithmetic is capped at 0.75 and strict (no FMA) at 0.5"),
+                             "strict arithmetic (no FMA) can reach 0.5 of it, sigma-contracted 0.6, contracted 0.75.  "
+                             "`achieved` counts ALL D columns as work: columns that are zero in every row of the chunk "
+                             "are retired exactly (column_occupancy), so the fraction can exceed the issue cap"),
                     "avg_launch_ms": round(upd_avg_s * 1e3, 4),
                     "algorithmic_flop_per_launch": flops}
 
-        roof = roofline_for(timing)
-        traffic, tsrc = profile_traffic(args.config if args.arith == "contracted" else args.config + "_strict")
+        roof = roofline_for(timing, split)
+        traffic, tsrc = profile_traffic(args.config + {"strict": "_strict", "sigma": "_sigma", "contracted": ""}[args.arith])
         roof["traffic"] = traffic
         roof["traffic_source"] = tsrc
-        arith = "n/a (online path has no contracted mode)" if online else (
-            "contracted (fma; map/sigmaMap within 1e-5 relative of the reference, everything else bit-exact)"
-            if args.arith == "contracted" else "strict (bit-identical to the CPU oracle)")
-        if not online and tr != capi.STANDARD and args.arith == "contracted" and not capi.has_contracted(tr):
-            arith = "strict (this transformation has no contracted chain kernel)"
+        arith = "n/a (online path has no contracted mode)" if online else ARITH_TEXT[args.arith]
+        if not online and args.arith != "strict" and not capi.has_contracted(tr):
+            arith = "strict (this transformation has ONE arithmetic, bit-identical in every mode)"
+        live, cols = gen.column_occupancy(split.own_host[0])
         out = {
             "metric": METRIC if args.config == "c3" else "training samples/sec per epoch (BMU+update)",
-            "value": round(steps * units / dt, 3),
+            "value": round(steps * units_of(split) / dt, 3),
             "unit": "samples/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(dt / steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak",
+            "scaling": split.kind if sharded else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "update_arithmetic": arith,
-            "rccl_ranks": rccl_ranks,
+            "backend": ({"nccl": "nccl (RCCL)", "gloo": "gloo (CPU rehearsal of the N > 1 flow, not RCCL)"}[backend]
+                        if backend else "none (1 GPU)"),
+            "collective_ranks": coll_ranks,
+            "rccl_ranks": coll_ranks if backend == "nccl" else (1 if world == 1 else 0),
             "config": {"workload": (f"{cfg['name']}, "
                                     + ("trainBasicSom sample loop (trainSingle per sample)" if online else
                                        f"trainBatchSomEpoch({'findBmu' if is_first else 'findLocalBmu'} + update)")
-                                    + f", chunk B={Bper}/GPU ({Bglob if sharded else Bper} per step and "
+                                    + f", chunk B={split.Bper}/GPU ({split.Bglob if sharded else split.Bper} per step and "
                                     + ("replica" if not sharded and world > 1 else "job") + f"), sigma={sigma}"),
                        "baseline_config": args.config,
-                       "map": [W, H], "dim": J, "depth": D, "chunk_per_gpu": Bper,
-                       "chunk_total": Bglob if sharded else Bper * world,
-                       "parallelism": (f"{world} GPU: phase 1 sample-sharded, phase 2 node-sharded, RCCL all-gathers of "
+                       "map": [W, H], "dim": J, "depth": D, "chunk_per_gpu": split.Bper,
+                       "chunk_total": split.Bglob if sharded else split.Bper * world,
+                       "column_occupancy": {"live": live, "columns": cols,
+                                            "note": "columns with a non-zero in the rank-0 rows of chunk 0 (tests/gen.py: "
+                                                    "661 of 784 per 4096 rows, MNIST-like; real MNIST when VSOM_MNIST_DIR is set)"},
+                       "parallelism": (f"{world} GPU: phase 1 sample-sharded, phase 2 node-sharded, all-gathers of "
                                        "X / lastBMU / sqres / map rows inside the step" if sharded else
                                        (f"{world} independent replicas (the online path is sequential in samples)"
                                         if world > 1 else "1 GPU"))},
@@ -422,22 +498,118 @@ def main():
             "mse_last": mse,
             "bmu_shortlist_last": sl_stats,
         }
-        if other is not None:
-            oname, dto, tmo = other
-            ro = roofline_for(tmo)
-            out["other_arithmetic"] = {
-                "arithmetic": oname,
-                "note": ("strict = one rounding per fp32 operation, map/sigmaMap bit-identical to the CPU oracle "
-                         "(tests -m gpu); contracted = fma chains, within 1e-5 relative (tests/test_gpu_fma_mode.py)"),
-                "value": round(steps * units / dto, 3), "ms_per_step": round(dto / steps * 1e3, 4),
-                "update_avg_launch_ms": ro.get("avg_launch_ms"), "update_achieved_tflops": ro.get("achieved"),
-                "update_frac_of_peak": ro.get("frac")}
+        if others:
+            out["other_arithmetics"] = []
+            for oname, dto, tmo in others:
+                ro = roofline_for(tmo, split)
+                out["other_arithmetics"].append({
+                    "arithmetic": oname, "note": ARITH_TEXT[oname],
+                    "value": round(steps * units_of(split) / dto, 3), "ms_per_step": round(dto / steps * 1e3, 4),
+                    "update_avg_launch_ms": ro.get("avg_launch_ms"), "update_achieved_tflops": ro.get("achieved"),
+                    "update_frac_of_peak": ro.get("frac")})
+        if other_split is not None:
+            sp2, dt2, tm2 = other_split
+            out[sp2.kind + "_scaling"] = {
+                "scaling": sp2.kind, "value": round(steps * units_of(sp2) / dt2, 3), "unit": "samples/s",
+                "ms_per_step": round(dt2 / steps * 1e3, 4), "chunk_per_gpu": sp2.Bper, "chunk_total": sp2.Bglob,
+                "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in tm2.items()},
+                "note": ("every rank owns a full 4096-row chunk: one step is a 4096*N-row trainBatchSomEpoch, a different "
+                         "algorithmic step from BASELINE config 3 (each chunk overwrites the map, Som.cpp:870)"
+                         if sp2.kind == "weak" else "the 4096-row chunk of BASELINE config 3 shared out over the ranks")}
         if not args.no_cpu and world == 1:   # the CPU leg runs at N=1 only (contract)
-            out["cpu_baseline"] = cpu_baseline(args, own_host[0][:Bper], init_map, online=online)
+            out["cpu_baseline"] = cpu_baseline(args, split.own_host[0][:split.Bper], init_map, online=online)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main_group(args):
+    """--group: ONE process, N devices, the C ABI's vsom_group_* entry points (csrc/vsom_group.hip): what the C++
+    mirror's Som::train(BatchMap) runs when VSOM_DEVICES names several GPUs.  Strong split by construction (the
+    group shards the chunk it is handed); member r's own rows are resident on device r before the timed region
+    and vsom_group_set_chunk_device all-gathers them inside it."""
+    import torch
+    import vsom_amd
+    from vsom_amd import capi
+    import gen
+    cfg = args.cfg
+    if args.config == "online":
+        raise SystemExit("--group: the online path does not shard (replicas only)")
+    n = max(1, args.gpus)
+    visible = capi.device_count()
+    if visible < 1:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback in the product path)")
+    devices = [0] * n if args.share_device else list(range(n))
+    if not args.share_device and n > visible:
+        raise SystemExit(f"--group --gpus {n}: only {visible} device(s) visible (add --share-device to rehearse on one)")
+    W = H = cfg["map"]
+    J, tr, sigma, B = cfg["dim"], cfg["transform"], cfg["sigma"], cfg["chunk"]
+    grp = capi.Group(W, H, J, tr, devices=devices)
+    D = grp.depth
+    init_map = make_map(cfg, D)
+    grp.set_state(map=init_map)
+    c0 = grp.member(0)
+    mode_of = {"contracted": capi.UPDATE_FMA, "strict": capi.UPDATE_STRICT, "sigma": capi.UPDATE_FMA_SIGMA}
+    grp.set_update_mode(mode_of[args.arith])
+    chunks = [make_data(cfg, B, seed=3 + i) for i in range(args.nchunks)]
+    bounds = [((B * r) // n, (B * (r + 1)) // n) for r in range(n)]
+    own = [[torch.from_numpy(np.ascontiguousarray(c[lo:hi])).to(torch.device("cuda", devices[r]))
+            for r, (lo, hi) in enumerate(bounds)] for c in chunks]
+    for d in set(devices):
+        torch.cuda.synchronize(d)
+    is_first = not args.local
+
+    def step(i):
+        rows = own[i % len(own)]
+        grp.set_chunk_device([t.data_ptr() for t in rows], B)
+        grp.batch_epoch_async(sigma, is_first)
+
+    def timed(nwarm, nsteps):
+        for i in range(nwarm):
+            step(i)
+        grp.synchronize()
+        c0.get_timing(reset=True)
+        c0.enable_timing(True)
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            step(nwarm + i)
+        grp.synchronize()
+        dt = time.perf_counter() - t0
+        tm = c0.get_timing(reset=True)
+        c0.enable_timing(False)
+        return dt, tm
+
+    dt, tm = timed(args.warmup, args.steps)
+    steps = args.steps
+    upd_ms, upd_cnt = tm["update"]
+    upd_avg_s = upd_ms / max(upd_cnt, 1) / 1e3
+    n_nodes0 = (W * H) // n
+    flops = (15.0 * n_nodes0 * (D // 2) * B) if tr == capi.CLR else (6.0 * n_nodes0 * D * B)
+    ach = flops / upd_avg_s / 1e12 if upd_avg_s > 0 else 0.0
+    live, cols = gen.column_occupancy(chunks[0])
+    out = {
+        "metric": METRIC if args.config == "c3" else "training samples/sec per epoch (BMU+update)",
+        "value": round(steps * B / dt, 3), "unit": "samples/s", "n_gpus": n, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "update_arithmetic": ARITH_TEXT[args.arith],
+        "front_end": "vsom_group_* (one process, csrc/vsom_group.hip)",
+        "backend": {"rccl": "rccl (ncclCommInitAll, in-process)", "peer": "peer copies (hipMemcpyAsync device-to-device"
+                    + (", every member on device 0: rehearsal" if args.share_device else "") + ")"}[grp.transport],
+        "rccl_ranks": n if grp.transport == "rccl" else 0,
+        "config": {"workload": f"{cfg['name']}, trainBatchSomEpoch({'findBmu' if is_first else 'findLocalBmu'} + update), "
+                               f"chunk B={B} per step shared out over {n} member(s), sigma={sigma}",
+                   "baseline_config": args.config, "map": [W, H], "dim": J, "depth": D, "chunk_per_gpu": B // n,
+                   "chunk_total": B, "column_occupancy": {"live": live, "columns": cols},
+                   "parallelism": f"{n} member(s): phase 1 sample-sharded, phase 2 node-sharded, gathers inside the step"},
+        "roofline": {"bound": "valu_fp32", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / FP32_PEAK_TFLOPS, 4), "kernel": "member 0's phase-2 chain kernel",
+                     "avg_launch_ms": round(upd_avg_s * 1e3, 4), "algorithmic_flop_per_launch": flops, "traffic": None},
+        "kernel_ms_per_step_member0": {k: round(v[0] / steps, 4) for k, v in tm.items()},
+        "mse_last": float(grp.get_mse()),
+    }
+    print(json.dumps(out), flush=True)
+    grp.close()
 
 
 if __name__ == "__main__":

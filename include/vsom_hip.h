@@ -67,13 +67,25 @@ typedef enum vsom_bmu_mode {
 typedef enum vsom_update_mode {
     VSOM_UPDATE_STRICT = 0, /* one rounding per fp32 operation: bit-identical to the reference's SSE2
                                build (default)                                                    */
-    VSOM_UPDATE_FMA = 1     /* contracted Standard chains: M = fma(c,d,M), S = fma(w*d,d,S) (1/3 fewer VALU
-                               ops).  map / sigmaMap then differ from the reference by rounding only:
-                               |err| <= 1e-5 * max(|ref|, scale of the chain's operands) (measured 1e-7; pure
-                               element-wise <= 4e-7 on the MNIST workloads), while BMU indices, bmuHits, MSE
-                               and weightMap stay bit-exact.  Median and CLR have ONE arithmetic, bit-identical
-                               to the reference, in both modes: the Median chains' fused operations are exact,
-                               and the CLR recurrence amplifies rounding differences beyond the tolerance.  */
+    VSOM_UPDATE_FMA = 1,    /* contracted Standard chains: M = fma(c,d,M), S = fma(w*d,d,S) (1/3 fewer VALU
+                               ops).  After ONE epoch from a given map, map / sigmaMap differ from the reference by
+                               rounding only: |err| <= 1e-5 * max(|ref|, scale of the chain's operands) (measured
+                               1e-7; pure element-wise <= 4e-7 on the MNIST workloads), BMU indices, bmuHits, MSE
+                               and weightMap bit-exact.  NOT a schedule-level guarantee: the next search runs on
+                               the perturbed map, near-ties flip, and a multi-epoch trainBatchSom leaves the
+                               reference's trajectory within the first epochs (measured: profiles/
+                               r3_fma_schedule.jsonl -- C3, 2 chunks: 5 of 8192 BMUs differ in epoch 0, 24 % by
+                               epoch 9).  Use for single passes / throughput studies only.                  */
+    VSOM_UPDATE_FMA_SIGMA = 2 /* only the variance accumulation contracted: t = c*d, M = M + t as the reference
+                               rounds them, S = fma(w*d, d, S) (1/6 fewer VALU ops).  map is BIT-IDENTICAL, and so
+                               are lastBMU, bmuHits, MSE and weightMap of every later epoch of a schedule -- no
+                               training step reads sigmaMap (Transformation.cpp:7-8,45-46,82: the built-in
+                               Comparers ignore the dispersion); sigmaMap is a sum of non-negative terms and stays
+                               within 1e-5 relative, element by element (measured 3e-7;
+                               tests/test_gpu_fma_schedule.py).
+                               Median and CLR have ONE arithmetic, bit-identical to the reference, in every mode:
+                               the Median chains' fused operations are exact, and the CLR recurrence amplifies
+                               rounding differences beyond the tolerance.                                    */
 } vsom_update_mode;
 
 /* selectors for vsom_device_ptr / vsom_get_timing */
@@ -247,6 +259,9 @@ int vsom_group_upload_chunk(vsom_group *g, const float *x_host, size_t B);
 int vsom_group_prefetch_chunk(vsom_group *g, const float *x_host, size_t B);
 int vsom_group_prefetch_wait(vsom_group *g);
 int vsom_group_commit_chunk(vsom_group *g);
+/* the same for a chunk already resident in HBM: rows_dev[r] = member r's own rows [B*r/n, B*(r+1)/n) on ITS
+ * device; all-gather of the rows, staging, lastBMU := 0 -- asynchronous on the members' streams */
+int vsom_group_set_chunk_device(vsom_group *g, const void *const *rows_dev /*[n]*/, size_t B);
 int vsom_group_set_last_bmu(vsom_group *g, const uint64_t *in_host);
 int vsom_group_get_last_bmu(vsom_group *g, uint64_t *out_host);
 /* Som::trainBatchSomEpoch (Som.cpp:756-879) over the group */

@@ -30,17 +30,36 @@ def test_single_gpu_line_small_shape():
     r = d["roofline"]
     assert r["bound"] == "valu_fp32" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
-    assert d["other_arithmetic"]["arithmetic"] == "strict" and d["update_arithmetic"].startswith("contracted")
+    # `value` is quoted on the library's default arithmetic; the two contracted modes are timed beside it
+    assert d["update_arithmetic"].startswith("strict") and d["backend"].startswith("none")
+    assert [o["arithmetic"] for o in d["other_arithmetics"]] == ["sigma", "contracted"]
+    assert all(o["value"] > 0 for o in d["other_arithmetics"])
+    occ = d["config"]["column_occupancy"]
+    assert 0 < occ["live"] <= occ["columns"] == 784
     assert "workload" in d["config"] and "model" not in d["config"]
 
 
 def test_self_launch_two_ranks_on_one_device():
     d = _run("--gpus", "2", "--backend", "gloo", "--share-device", "--map", "32", "--chunk", "256", "--steps", "2",
              "--warmup", "1", "--no-cpu", "--no-other-arith")
-    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["rccl_ranks"] == 2
-    assert d["config"]["chunk_total"] == 512 and d["config"]["chunk_per_gpu"] == 256 and d["scaling"] == "weak"
+    # gloo is NOT RCCL: the line says so and counts no RCCL rank
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["rccl_ranks"] == 0 and d["collective_ranks"] == 2
+    assert d["backend"].startswith("gloo")
+    # N > 1 quotes BASELINE config 3's split: the chunk of the step shared out over the ranks (strong) ...
+    assert d["config"]["chunk_total"] == 256 and d["config"]["chunk_per_gpu"] == 128 and d["scaling"] == "strong"
+    # ... and the weak variant (every rank owns a whole chunk) beside it
+    w = d["weak_scaling"]
+    assert w["chunk_total"] == 512 and w["chunk_per_gpu"] == 256 and w["value"] > 0
     assert "cpu_baseline" not in d                      # the CPU leg runs at N = 1 only
     assert d["value"] > 0 and d["roofline"]["avg_launch_ms"] > 0
+
+
+def test_group_front_end_line():
+    """--group: one process, vsom_group_* (three members rehearsed on device 0 with the peer transport)"""
+    d = _run("--group", "--gpus", "3", "--share-device", "--map", "32", "--chunk", "384", "--steps", "2", "--warmup", "1")
+    assert KEYS <= set(d) and d["n_gpus"] == 3 and d["scaling"] == "strong" and d["rccl_ranks"] == 0
+    assert d["backend"].startswith("peer") and d["front_end"].startswith("vsom_group")
+    assert d["config"]["chunk_total"] == 384 and d["config"]["chunk_per_gpu"] == 128 and d["value"] > 0
 
 
 def test_online_line_is_bandwidth_priced():

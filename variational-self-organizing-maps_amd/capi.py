@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libvsom_hip.so")
 STANDARD, MEDIAN, CLR = 0, 1, 2
 EXPONENTIAL, INVERSE_PROPORTIONAL, BATCHMAP = 0, 1, 2
 BMU_AUTO, BMU_EXACT, BMU_SHORTLIST = 0, 1, 2
-UPDATE_STRICT, UPDATE_FMA = 0, 1
+UPDATE_STRICT, UPDATE_FMA, UPDATE_FMA_SIGMA = 0, 1, 2
 BUF_MAP, BUF_SIGMA, BUF_S, BUF_WEIGHT, BUF_HITS, BUF_LASTBMU, BUF_SQRES, BUF_CHUNK = range(8)
 T_STAGE, T_BMU, T_FINISH, T_CW, T_UPDATE, T_ONLINE, T_SIGMA, T_COUNT = range(8)
 TIMER_NAMES = ["stage", "bmu", "finish", "cw", "update", "online", "sigma"]
@@ -36,7 +36,7 @@ SYMBOLS = [
     "vsom_group_create", "vsom_group_destroy", "vsom_group_size", "vsom_group_ctx", "vsom_group_transport",
     "vsom_group_synchronize", "vsom_group_set_state", "vsom_group_get_state", "vsom_group_set_update_mode",
     "vsom_group_set_bmu_mode", "vsom_group_upload_chunk", "vsom_group_prefetch_chunk", "vsom_group_prefetch_wait",
-    "vsom_group_commit_chunk", "vsom_group_set_last_bmu", "vsom_group_get_last_bmu",
+    "vsom_group_commit_chunk", "vsom_group_set_chunk_device", "vsom_group_set_last_bmu", "vsom_group_get_last_bmu",
     "vsom_group_batch_epoch_async", "vsom_group_batch_epoch", "vsom_group_get_mse",
 ]
 
@@ -141,6 +141,7 @@ def lib():
     L.vsom_group_prefetch_chunk.argtypes = [vp, fp, C.c_size_t]
     L.vsom_group_prefetch_wait.argtypes = [vp]
     L.vsom_group_commit_chunk.argtypes = [vp]
+    L.vsom_group_set_chunk_device.argtypes = [vp, C.POINTER(vp), C.c_size_t]
     L.vsom_group_set_last_bmu.argtypes = [vp, u64p]
     L.vsom_group_get_last_bmu.argtypes = [vp, u64p]
     L.vsom_group_batch_epoch_async.argtypes = [vp, C.c_double, C.c_int]
@@ -423,6 +424,8 @@ class Group:
 
     def __init__(self, width, height, in_len, transform=STANDARD, ndev=0, devices=None):
         self._h = C.c_void_p()
+        self._members = []
+        self.size = None
         devs = None
         if devices is not None:
             ndev = len(devices)
@@ -436,13 +439,26 @@ class Group:
         self.depth, self.n_nodes = c0.depth, c0.n_nodes
 
     def member(self, rank):
+        """Borrowed Context of one member for the single-context calls (searches, getters).  The group is
+        synchronised first (include/vsom_hip.h requires it), the returned object keeps the group alive, and
+        Group.close() invalidates it -- a call on it afterwards raises instead of touching freed memory."""
+        if not self._h:
+            raise VsomError("group is closed")
         h = lib().vsom_group_ctx(self._h, int(rank))
         if not h:
             raise VsomError("rank out of range")
-        return Context(self.width, self.height, self.in_len, self.transform, _borrowed=h)
+        if getattr(self, "size", None) is not None:     # (not yet during __init__)
+            check(lib().vsom_group_synchronize(self._h))
+        c = Context(self.width, self.height, self.in_len, self.transform, _borrowed=h)
+        c._group = self
+        self._members.append(c)
+        return c
 
     def close(self):
         if self._h:
+            for c in self._members:
+                c._h = C.c_void_p()                       # borrowed handles die with the group
+            self._members = []
             lib().vsom_group_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -499,6 +515,13 @@ class Group:
 
     def commit_chunk(self):
         check(lib().vsom_group_commit_chunk(self._h))
+
+    def set_chunk_device(self, rows_dev, B):
+        """rows_dev[r] = device pointer (int) of member r's own rows [B*r/n, B*(r+1)/n) on its device"""
+        assert len(rows_dev) == self.size
+        arr = (C.c_void_p * self.size)(*[C.c_void_p(int(p) or None) for p in rows_dev])
+        self._B = int(B)
+        check(lib().vsom_group_set_chunk_device(self._h, arr, int(B)))
 
     def set_last_bmu(self, idx):
         idx = np.ascontiguousarray(idx, dtype=np.uint64)

@@ -354,7 +354,7 @@ int vsom_get_shortlist_stats(vsom_ctx *c, uint32_t *out)
 
 int vsom_set_update_mode(vsom_ctx *c, int mode)
 {
-    if (!c || (mode != VSOM_UPDATE_STRICT && mode != VSOM_UPDATE_FMA))
+    if (!c || (mode != VSOM_UPDATE_STRICT && mode != VSOM_UPDATE_FMA && mode != VSOM_UPDATE_FMA_SIGMA))
         return vsom_fail(VSOM_ERR_INVALID, "bad update mode");
     c->update_mode = mode;
     return VSOM_OK;

@@ -425,6 +425,51 @@ int vsom_group_commit_chunk(vsom_group *g)
     return VSOM_OK;
 }
 
+// DataSet::loadNextDataFromStream for a chunk that already lives in HBM: rows_dev[r] = member r's OWN rows
+// [B*r/n, B*(r+1)/n) on its device (contiguous, J floats each); the other rows arrive by all-gather over
+// xGMI, then every member stages the whole chunk (lastBMU := 0).  Asynchronous on the members' streams; the
+// caller's buffers may be reused after vsom_group_synchronize (or the next call that synchronises).
+int vsom_group_set_chunk_device(vsom_group *g, const void *const *rows_dev, size_t B)
+{
+    if (!g || (B > 0 && !rows_dev))
+        return vsom_fail(VSOM_ERR_INVALID, "null group / rows_dev");
+    const int n = g->n;
+    std::vector<char *> base(n);
+    for (int r = 0; r < n; ++r) {
+        vsom_ctx *c = g->ctx[r];
+        VSOM_HIP_CHECK(hipSetDevice(g->dev[r]));
+        const size_t need = B * c->J;
+        if (need > c->Xraw_cap) {
+            VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (c->Xraw)
+                (void)hipFree(c->Xraw);
+            c->Xraw = nullptr;
+            c->Xraw_cap = 0;
+            VSOM_HIP_CHECK(hipMalloc(&c->Xraw, need * 4));
+            c->Xraw_cap = need;
+        }
+        size_t lo, hi;
+        shard(B, n, r, lo, hi);
+        if (hi > lo) {
+            if (!rows_dev[r])
+                return vsom_fail(VSOM_ERR_INVALID, "rows_dev[r] is null");
+            VSOM_HIP_CHECK(hipMemcpyAsync(c->Xraw + lo * c->J, rows_dev[r], (hi - lo) * (size_t)c->J * 4,
+                                          hipMemcpyDeviceToDevice, c->stream));
+        }
+        base[r] = (char *)c->Xraw;
+    }
+    auto st = main_streams(g);
+    int rc = gather_rows(g, base, (size_t)g->ctx[0]->J * 4, B, st);   // chunk replication over xGMI
+    if (rc)
+        return rc;
+    for (int r = 0; r < n; ++r) {
+        VSOM_HIP_CHECK(hipSetDevice(g->dev[r]));
+        if ((rc = vsom_set_chunk_device(g->ctx[r], g->ctx[r]->Xraw, B)))
+            return rc;
+    }
+    return VSOM_OK;
+}
+
 int vsom_group_upload_chunk(vsom_group *g, const float *x_host, size_t B)
 {
     int rc = vsom_group_prefetch_chunk(g, x_host, B);

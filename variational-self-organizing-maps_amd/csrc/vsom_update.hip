@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ X
 // segment, (c,w) a same-address broadcast), 256/DL nodes per workgroup, blockIdx.y = dim slice.
 // Loads of the next U samples are issued before the current U are consumed.  Same fp32 operation
 // sequence per chain as update_kernel, so the results are bit-identical.
-template <bool MEDIAN, int U, bool FMA>
+template <bool MEDIAN, int U, int FMA>
 __global__ __launch_bounds__(256) void update_chain_kernel(const float *__restrict__ Xs, int ldx,
                                                            const float2 *__restrict__ cw, int ldn, int B,
                                                            int n0, int nloc, int D, int dl_log2,
@@ -502,8 +502,12 @@ __global__ __launch_bounds__(256) void update_chain_kernel(const float *__restri
             float dl = x[u] - M;            // Stepper (Transformation.cpp:12 / :50)
             if (MEDIAN)
                 dl = vsom_sign(dl);
-            if (FMA) {                      // opt-in contracted arithmetic (VSOM_UPDATE_FMA)
+            if (FMA == 1) {                 // opt-in contracted arithmetic (VSOM_UPDATE_FMA)
                 M = __builtin_fmaf(c, dl, M);
+                S = __builtin_fmaf(w * dl, dl, S);
+            } else if (FMA == 2 && !MEDIAN) {   // VSOM_UPDATE_FMA_SIGMA: the mean chain strict, only S contracted
+                float t = c * dl;
+                M = M + t;
                 S = __builtin_fmaf(w * dl, dl, S);
             } else {
                 float t = c * dl;
@@ -535,8 +539,12 @@ __global__ __launch_bounds__(256) void update_chain_kernel(const float *__restri
         float dl = xp[(size_t)j * ldx] - M;
         if (MEDIAN)
             dl = vsom_sign(dl);
-        if (FMA) {
+        if (FMA == 1) {
             M = __builtin_fmaf(v.x, dl, M);
+            S = __builtin_fmaf(v.y * dl, dl, S);
+        } else if (FMA == 2 && !MEDIAN) {
+            float t = v.x * dl;
+            M = M + t;
             S = __builtin_fmaf(v.y * dl, dl, S);
         } else {
             float t = v.x * dl;
@@ -580,7 +588,7 @@ __device__ __forceinline__ vsom_f2 vsom_pk_mul_negclamp(vsom_f2 a, vsom_f2 b)
     return r;
 }
 
-template <bool MEDIAN, int U, int NG, bool FMA>
+template <bool MEDIAN, int U, int NG, int FMA>
 __global__ __launch_bounds__(256, 1) void update_chain2_kernel(const float *__restrict__ Xs, int ldx,
                                                                const float2 *__restrict__ cw, int ldn, int B,
                                                                int n0, int nloc, int D, int dl_log2,
@@ -628,8 +636,12 @@ __global__ __launch_bounds__(256, 1) void update_chain2_kernel(const float *__re
             M = __builtin_elementwise_fma(-cc, nn, M);
             S = __builtin_elementwise_fma(ww, pp, S);  // (:867)
             S = __builtin_elementwise_fma(ww, nn, S);
-        } else if (FMA) {
+        } else if (FMA == 1) {
             M = __builtin_elementwise_fma(cc, dl, M);
+            S = __builtin_elementwise_fma(ww * dl, dl, S);
+        } else if (FMA == 2) {                         // VSOM_UPDATE_FMA_SIGMA: mean chain strict
+            const vsom_f2 t = cc * dl;
+            M = M + t;
             S = __builtin_elementwise_fma(ww * dl, dl, S);
         } else {
             const vsom_f2 t = cc * dl;
@@ -687,7 +699,7 @@ __global__ __launch_bounds__(256, 1) void update_chain2_kernel(const float *__re
 // PL = 1 << PLOG dim pairs) fetch each block of CT samples with 16-byte loads that touch every byte once
 // (x: CT rows of PL pairs; (c,w): CT/2 pair rows of NW nodes), two blocks ahead of the one being consumed
 // (registers -> LDS ring of three), and the chains read their operands from LDS as broadcasts.
-template <bool MEDIAN, bool FMA, int PLOG>
+template <bool MEDIAN, int FMA, int PLOG>
 __global__ __launch_bounds__(256, 1) void update_chain3_kernel(const float *__restrict__ Xs, int ldx,
                                                                const float2 *__restrict__ cw, int ldn, int B,
                                                                int n0, int nloc, int D,
@@ -772,8 +784,12 @@ __global__ __launch_bounds__(256, 1) void update_chain3_kernel(const float *__re
             M = __builtin_elementwise_fma(-cc, nn, M);
             S = __builtin_elementwise_fma(ww, pp, S);
             S = __builtin_elementwise_fma(ww, nn, S);
-        } else if (FMA) {
+        } else if (FMA == 1) {
             M = __builtin_elementwise_fma(cc, dl, M);
+            S = __builtin_elementwise_fma(ww * dl, dl, S);
+        } else if (FMA == 2) {                         // VSOM_UPDATE_FMA_SIGMA: mean chain strict
+            const vsom_f2 t = cc * dl;
+            M = M + t;
             S = __builtin_elementwise_fma(ww * dl, dl, S);
         } else {
             const vsom_f2 t = cc * dl;
@@ -1035,11 +1051,13 @@ int vsom_load_asm_module(vsom_ctx *c)
         return VSOM_OK;
     hipModule_t mod;
     VSOM_HIP_CHECK(hipModuleLoadData(&mod, vsom_update_hsaco));
-    hipFunction_t f16, f14, m16, m14, fclr, d16, d14;
+    hipFunction_t f16, f14, m16, m14, fclr, d16, d14, sf16, sf14;
     VSOM_HIP_CHECK(hipModuleGetFunction(&f16, mod, "vsom_update_std_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&f14, mod, "vsom_update_std_rd14_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&m16, mod, "vsom_update_fma_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&m14, mod, "vsom_update_fma_rd14_gfx950"));
+    VSOM_HIP_CHECK(hipModuleGetFunction(&sf16, mod, "vsom_update_sfma_rd16_gfx950"));
+    VSOM_HIP_CHECK(hipModuleGetFunction(&sf14, mod, "vsom_update_sfma_rd14_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&fclr, mod, "vsom_update_clr_rp8_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&d16, mod, "vsom_update_med_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&d14, mod, "vsom_update_med_rd14_gfx950"));
@@ -1048,6 +1066,8 @@ int vsom_load_asm_module(vsom_ctx *c)
     c->upd_fn14 = f14;
     c->upd_fma16 = m16;
     c->upd_fma14 = m14;
+    c->upd_sfma16 = sf16;
+    c->upd_sfma14 = sf14;
     c->upd_clr8 = fclr;
     c->upd_med16 = d16;
     c->upd_med14 = d14;
@@ -1297,15 +1317,17 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 const unsigned PL = 1u << pl_log2, npairs = (c->D + 1) / 2;
                 dim3 grid2((unsigned)((nloc + (256 / PL) - 1) / (256 / PL)), (npairs + PL - 1) / PL);
                 constexpr int NG = 4;
-                const bool med = c->transform == VSOM_MEDIAN, fma = c->update_mode == VSOM_UPDATE_FMA;
+                const bool med = c->transform == VSOM_MEDIAN, fma = c->update_mode == VSOM_UPDATE_FMA,
+                           sfma = c->update_mode == VSOM_UPDATE_FMA_SIGMA;
                 static int chain3_env = -1;                    // VSOM_CHAIN3=0: the register-ring kernel (development)
                 if (chain3_env < 0) {
                     const char *e = std::getenv("VSOM_CHAIN3");
                     chain3_env = e && e[0] == '0' ? 0 : 1;
                 }
                 const void *k3 = nullptr;                      // operands staged through LDS: 8..64 dim pairs per row
-#define VSOM_K3(P) (med ? (const void *)update_chain3_kernel<true, false, P> \
-                        : (fma ? (const void *)update_chain3_kernel<false, true, P> : (const void *)update_chain3_kernel<false, false, P>))
+#define VSOM_K3(P) (med ? (const void *)update_chain3_kernel<true, 0, P> \
+                        : (fma ? (const void *)update_chain3_kernel<false, 1, P>                    \
+                               : (sfma ? (const void *)update_chain3_kernel<false, 2, P> : (const void *)update_chain3_kernel<false, 0, P>)))
                 if (chain3_env && pl_log2 >= 3 && pl_log2 <= 6)
                     k3 = pl_log2 == 3 ? VSOM_K3(3) : pl_log2 == 4 ? VSOM_K3(4) : pl_log2 == 5 ? VSOM_K3(5) : VSOM_K3(6);
 #undef VSOM_K3
@@ -1319,17 +1341,19 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     void *args[] = {&xs_, &ildx, &cw_, &ildn, &iB, &in0, &inl, &iD, &map_, &sg_, &ipitch, &wt_};
                     VSOM_HIP_CHECK(hipLaunchKernel(k3, grid2, dim3(256), args, 0, c->stream));
                 } else {
-                auto kern2 = med ? update_chain2_kernel<true, U, NG, false>
-                                 : (fma ? update_chain2_kernel<false, U, NG, true> : update_chain2_kernel<false, U, NG, false>);
+                auto kern2 = med ? update_chain2_kernel<true, U, NG, 0>
+                                 : (fma ? update_chain2_kernel<false, U, NG, 1>
+                                        : (sfma ? update_chain2_kernel<false, U, NG, 2> : update_chain2_kernel<false, U, NG, 0>));
                 hipLaunchKernelGGL(kern2, grid2, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->cw, (int)ldn,
                                    (int)c->B, (int)n0, (int)nloc, (int)c->D, pl_log2, c->map, c->sigma,
                                    (int)c->pitch, c->weight);
                 }
             } else {
             dim3 grid((unsigned)((nloc + (256 / DL) - 1) / (256 / DL)), (c->D + DL - 1) / DL);
-            auto kern = c->transform == VSOM_MEDIAN ? update_chain_kernel<true, U, false>
-                        : (c->update_mode == VSOM_UPDATE_FMA ? update_chain_kernel<false, U, true>
-                                                             : update_chain_kernel<false, U, false>);
+            auto kern = c->transform == VSOM_MEDIAN ? update_chain_kernel<true, U, 0>
+                        : (c->update_mode == VSOM_UPDATE_FMA ? update_chain_kernel<false, U, 1>
+                           : (c->update_mode == VSOM_UPDATE_FMA_SIGMA ? update_chain_kernel<false, U, 2>
+                                                                      : update_chain_kernel<false, U, 0>));
             hipLaunchKernelGGL(kern, grid, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->cw, (int)ldn,
                                (int)c->B, (int)n0, (int)nloc, (int)c->D, dl_log2, c->map, c->sigma,
                                (int)c->pitch, c->weight);
@@ -1346,10 +1370,10 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     return rc;
                 unsigned n16 = 0, n14 = 0;
                 vsom_update_split(c->D, c->pitch < c->xpitch ? c->pitch : c->xpitch, n16, n14);
-                const bool fma = c->update_mode == VSOM_UPDATE_FMA;
-                const bool med = c->transform == VSOM_MEDIAN;     // its FMAs are exact: one kernel for both modes
-                void *const fn16 = med ? c->upd_med16 : (fma ? c->upd_fma16 : c->upd_fn16);
-                void *const fn14 = med ? c->upd_med14 : (fma ? c->upd_fma14 : c->upd_fn14);
+                const bool fma = c->update_mode == VSOM_UPDATE_FMA, sfma = c->update_mode == VSOM_UPDATE_FMA_SIGMA;
+                const bool med = c->transform == VSOM_MEDIAN;     // its FMAs are exact: one kernel for all modes
+                void *const fn16 = med ? c->upd_med16 : (fma ? c->upd_fma16 : (sfma ? c->upd_sfma16 : c->upd_fn16));
+                void *const fn14 = med ? c->upd_med14 : (fma ? c->upd_fma14 : (sfma ? c->upd_sfma14 : c->upd_fn14));
                 auto launch = [&](void *fn, unsigned nsl, unsigned col0, hipStream_t st) -> int {
                     UpdAsmArgs a;
                     a.xs = c->Xs + col0;

@@ -480,12 +480,16 @@ public:
     void setState(const float *map, const float *sigma, const float *S, const float *weight, const uint64_t *hits);
     void getState(float *map, float *sigma, float *S, float *weight, uint64_t *hits) const;
     static void setDefaultDevice(int device);
-    // devices the batch-map training runs on: {} = all visible (or the list in VSOM_DEVICES), one entry =
-    // single GPU, several = sample/node-sharded epochs through vsom_group_* (vsom_host.cpp, training_devices)
+    // devices the batch-map training runs on (opt-in; default: the default device alone): {} = the list in
+    // VSOM_DEVICES or the default device, one entry = single GPU, several = sample/node-sharded epochs through
+    // vsom_group_* (vsom_host.cpp, training_devices)
     static void setDevices(const std::vector<int> &devices);
     // arithmetic of the Standard update chains of Soms created afterwards: false = strict, bit-identical to
     // the reference (default); true = contracted (fused multiply-adds, results within 1e-5: vsom_hip.h)
     static void setContractedArithmetic(bool on);
+    // any vsom_update_mode of include/vsom_hip.h (0 strict, 1 contracted, 2 only the sigma^2 accumulation
+    // contracted: map and BMUs stay bit-identical over whole schedules)
+    static void setUpdateArithmetic(int mode);
     vsom_ctx *context() const noexcept { return ctx; }
     vsom_group *group() const noexcept { return grp; }
 
@@ -494,6 +498,8 @@ private:
     vsom_group *grp = nullptr;        // set when the Som trains on more than one GPU; owns ctx then
     bool replicasStale = false;       // member 0 was trained alone (online path): the others lag behind
     void destroyContext();
+    void copyStateFrom(const Som &other);
+    void joinGroup() const;
     void syncReplicas();
     size_t inLen = 0;                 // J: sample length (depth = transform.Length(J))
     mutable bool hostStale = true;    // host mirrors below are out of date
@@ -506,6 +512,8 @@ private:
     double hostDist(size_t pos, const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const Eigen::VectorXf &weights) const;
     size_t hostFindBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const Eigen::VectorXf &weights) const;
     size_t hostFindLocalBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, size_t start, const Eigen::VectorXf &weights) const;
+    size_t hostFindRestrictedBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, size_t minBmuHits, const Eigen::VectorXf &weights) const;
+    double hostDistRaw(size_t pos, const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const Eigen::VectorXf &weights) const;
     float hostBatchEpoch(DataSet &dataset, double currentSigma, bool isFirst);
     void hostTrainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, double sigmaDecay, bool updateUMatrixAfterEpoch);
     TrainingReturnValue hostTrainSingle(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const Eigen::VectorXf &weights,

@@ -62,6 +62,42 @@ float packet_order_square_sum(const Vec &r)
     return s;
 }
 
+// a.dot(b) in the same packet order (Som.cpp:156: two different vectors)
+float packet_order_dot(const Vec &a, const Vec &b)
+{
+    const size_t n = (size_t)a.size();
+    if (n == 0)
+        return 0.f;
+    auto pr = [&](size_t i) { return a[(Eigen::Index)i] * b[(Eigen::Index)i]; };
+    const size_t whole = n & ~size_t{3}, pairs = n & ~size_t{7};
+    if (whole == 0) {
+        float s = pr(0);
+        for (size_t i = 1; i < n; ++i)
+            s = s + pr(i);
+        return s;
+    }
+    float lane[2][4];
+    for (size_t k = 0; k < 4; ++k)
+        lane[0][k] = pr(k);
+    if (whole > 4) {
+        for (size_t k = 0; k < 4; ++k)
+            lane[1][k] = pr(4 + k);
+        for (size_t base = 8; base < pairs; base += 8)
+            for (size_t half = 0; half < 2; ++half)
+                for (size_t k = 0; k < 4; ++k)
+                    lane[half][k] = lane[half][k] + pr(base + 4 * half + k);
+        for (size_t k = 0; k < 4; ++k)
+            lane[0][k] = lane[0][k] + lane[1][k];
+        if (whole > pairs)
+            for (size_t k = 0; k < 4; ++k)
+                lane[0][k] = lane[0][k] + pr(pairs + k);
+    }
+    float s = (lane[0][0] + lane[0][2]) + (lane[0][1] + lane[0][3]);
+    for (size_t i = whole; i < n; ++i)
+        s = s + pr(i);
+    return s;
+}
+
 Vec row(const std::vector<float> &a, size_t node, size_t depth)
 {
     Vec v((Eigen::Index)depth);
@@ -220,8 +256,6 @@ float Som::hostBatchEpoch(DataSet &dataset, double currentSigma, bool isFirst)
 // Som.cpp:716-754
 void Som::hostTrainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, double sigmaDecay, bool updateUMatrixAfterEpoch)
 {
-    if (updateUMatrixAfterEpoch)
-        throw std::runtime_error("updateUMatrix needs a built-in Transformation (device path)");
     metrics = Som::Metrics(numberOfEpochs);
     for (size_t i = 0; i < numberOfEpochs; ++i) {
         std::cout << "Training VSOM epoch " << i << "/" << numberOfEpochs << '\n';
@@ -241,6 +275,8 @@ void Som::hostTrainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0,
             metrics.MeanSquaredError[i] = mse;
         }
         data.resetStreamLoadPosition();
+        if (updateUMatrixAfterEpoch)
+            updateUMatrix(data.getWeights());        // :751-752 / :1183-1184
     }
 }
 
@@ -297,8 +333,6 @@ Som::TrainingReturnValue Som::hostTrainSingle(const Vec &v, const Vec &valid, co
 void Som::hostTrainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, double etaDecay, double sigma0, double sigmaDecay,
                             WeigthDecayFunction fn, bool updateUMatrixAfterEpoch)
 {
-    if (updateUMatrixAfterEpoch)
-        throw std::runtime_error("updateUMatrix needs a built-in Transformation (device path)");
     metrics = Som::Metrics(numberOfEpochs);
     const Vec weights = data.getWeights();
     for (size_t i = 0; i < numberOfEpochs; ++i) {
@@ -325,6 +359,43 @@ void Som::hostTrainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, d
             metrics.MeanSquaredError[i] = mse;
         }
         data.resetStreamLoadPosition();
+        if (updateUMatrixAfterEpoch)
+            updateUMatrix(data.getWeights());        // :751-752 / :1183-1184
     }
     std::cout << "\rTraining SOM:100%\n";
+}
+
+// ---- consumers of the search outside the training loop, with the caller's hooks ----
+// Som.cpp:313-332: node 0 seeds the search whatever its hit count; a later node replaces it only when it is
+// strictly closer AND has at least minBmuHits hits
+size_t Som::hostFindRestrictedBmu(const Vec &v, const Vec &valid, size_t minBmuHits, const Vec &weights) const
+{
+    hostEnsure();
+    double minDist = hostDist(0, v, valid, weights);
+    size_t minIndex = 0;
+    for (size_t i = 0; i < width * height; ++i) {
+        const double d = hostDist(i, v, valid, weights);
+        if (d < minDist && hHits[i] >= minBmuHits) {
+            minDist = d;
+            minIndex = i;
+        }
+    }
+    return minIndex;
+}
+
+// Som.cpp:143-157: sigma-normalised raw distance; no hook is involved (the reference computes M - v itself)
+double Som::hostDistRaw(size_t pos, const Vec &v, const Vec &valid, const Vec &weights) const
+{
+    hostEnsure();
+    Vec a((Eigen::Index)depth), b((Eigen::Index)depth);
+    for (size_t d = 0; d < depth; ++d) {
+        const float s = hSigma[pos * depth + d];
+        const float sM = s < 0.00001f ? 0.00001f : s;                       // :150
+        const float diff = hMap[pos * depth + d] - v[(Eigen::Index)d];
+        const float validWeight = valid[(Eigen::Index)d] * weights[(Eigen::Index)d];   // :153
+        a[(Eigen::Index)d] = diff / sM;
+        const float t = diff * validWeight;
+        b[(Eigen::Index)d] = t / sM;
+    }
+    return (double)packet_order_dot(a, b);                                   // :156
 }

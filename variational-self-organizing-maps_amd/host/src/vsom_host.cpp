@@ -447,12 +447,13 @@ void DataSet::shuffle() {}
 static int g_default_device = 0;
 void Som::setDefaultDevice(int device) { g_default_device = device; }
 
-// Devices a Som trains on.  Nothing named: every visible device for maps of at least 1024 nodes, the
-// default device otherwise; VSOM_DEVICES="0,1,2,3" (or Som::setDevices) names them whatever the map size;
-// a single entry keeps the single-GPU path.  More than one entry makes the batch-map training members run through the
-// vsom_group_* entry points (phase 1 sample-sharded, phase 2 node-sharded, all-gathers over xGMI).
-// A list that repeats a device rehearses that flow on one GPU (the library then copies between the
-// members instead of calling RCCL, include/vsom_hip.h).
+// Devices a Som trains on.  Nothing named: the default device, i.e. the single-GPU path.  Several GPUs are
+// OPT-IN: VSOM_DEVICES="0,1,2,3" (or Som::setDevices) names them, and more than one entry makes the batch-map
+// training members run through the vsom_group_* entry points (phase 1 sample-sharded, phase 2 node-sharded,
+// all-gathers over xGMI).  A list that repeats a device rehearses that flow on one GPU (the library then
+// copies between the members instead of calling RCCL, include/vsom_hip.h).  Rounds 1-2 grouped every visible
+// GPU by default; the RCCL transport of a group has not run on N > 1 real devices yet,
+// so a caller who never asked for several GPUs no longer gets it.
 static std::vector<int> g_devices;
 static bool g_devices_set = false;
 void Som::setDevices(const std::vector<int> &devices)
@@ -461,17 +462,31 @@ void Som::setDevices(const std::vector<int> &devices)
     g_devices_set = true;
 }
 
-// Arithmetic of the Standard update chains for the Soms created from now on: strict (default: bit-identical
-// to the reference) or contracted (include/vsom_hip.h, VSOM_UPDATE_FMA: within the 1e-5 tolerance, a third
-// fewer instructions).  VSOM_UPDATE_MODE=contracted in the environment selects it without a code change.
+// Arithmetic of the Standard update chains for the Soms created from now on (include/vsom_hip.h,
+// vsom_update_mode): strict (default: everything bit-identical to the reference); sigma-contracted
+// (VSOM_UPDATE_FMA_SIGMA: map / BMUs / MSE bit-identical over whole schedules, sigmaMap within 1e-5, a sixth
+// fewer instructions); contracted (VSOM_UPDATE_FMA: one-epoch tolerance only -- a schedule drifts off the
+// reference's trajectory).  VSOM_UPDATE_MODE=strict|sigma|contracted in the environment selects it without a
+// code change.
 static int g_update_mode = -1;
 void Som::setContractedArithmetic(bool on) { g_update_mode = on ? VSOM_UPDATE_FMA : VSOM_UPDATE_STRICT; }
+void Som::setUpdateArithmetic(int mode)
+{
+    if (mode != VSOM_UPDATE_STRICT && mode != VSOM_UPDATE_FMA && mode != VSOM_UPDATE_FMA_SIGMA)
+        throw std::invalid_argument("Som::setUpdateArithmetic: unknown vsom_update_mode");
+    g_update_mode = mode;
+}
 static int update_mode()
 {
     if (g_update_mode >= 0)
         return g_update_mode;
     const char *e = std::getenv("VSOM_UPDATE_MODE");
-    return e && (std::string(e) == "contracted" || std::string(e) == "fma") ? VSOM_UPDATE_FMA : VSOM_UPDATE_STRICT;
+    const std::string m = e ? e : "";
+    if (m == "contracted" || m == "fma")
+        return VSOM_UPDATE_FMA;
+    if (m == "sigma" || m == "fma_sigma" || m == "sigma_contracted")
+        return VSOM_UPDATE_FMA_SIGMA;
+    return VSOM_UPDATE_STRICT;
 }
 
 static std::vector<int> training_devices(size_t nodes)
@@ -488,14 +503,8 @@ static std::vector<int> training_devices(size_t nodes)
         if (!out.empty())
             return out;
     }
-    // nothing named: every visible device, but only for maps that have work to shard -- below 1024 nodes a
-    // node shard is a handful of wavefronts (and a group costs an RCCL communicator per Som)
-    const int n = vsom_device_count();
-    if (n <= 1 || nodes < 1024)
-        return {g_default_device};
-    for (int d = 0; d < n; ++d)
-        out.push_back(d);
-    return out;
+    (void)nodes;
+    return {g_default_device};   // nothing named: one GPU (several are opt-in, see above)
 }
 
 static void check(int rc, const char *what)
@@ -546,6 +555,15 @@ void Som::syncReplicas()
     check(vsom_get_state(ctx, m.data(), s.data(), S.data(), w.data(), hh.data()), "vsom_get_state");
     check(vsom_group_set_state(grp, m.data(), s.data(), S.data(), w.data(), hh.data()), "vsom_group_set_state");
     replicasStale = false;
+}
+
+// Under a group the sigmaMap / weightMap rows of the other shards are gathered on a second stream and only
+// joined before the next phase 2 (csrc/vsom_group.hip, deferred gathers): every read of member 0's sigma or
+// weight between asynchronous epochs -- U-matrix, raw distances, state getters -- joins them first.
+void Som::joinGroup() const
+{
+    if (grp)
+        check(vsom_group_synchronize(grp), "vsom_group_synchronize");
 }
 
 void Som::requireDevicePath(const char *what) const
@@ -625,14 +643,23 @@ Som::Som(const Som &som)
       width{som.width}, depth{som.depth}, inLen{som.inLen}
 {
     createContext();
-    if (ctx && som.ctx) {
-        const size_t N = width * height;
-        std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
-        std::vector<uint64_t> hh(N);
-        som.getState(m.data(), s.data(), S.data(), w.data(), hh.data());
-        setState(m.data(), s.data(), S.data(), w.data(), hh.data());
-    }
+    copyStateFrom(som);
     _isTraining.store(som._isTraining.load());
+}
+
+// the reference's implicit copy takes the whole model (SOM.hpp:56-61); here the state lives on the device, or
+// -- custom std::function hooks, ctx == nullptr -- in the host arrays: getState / setState handle both
+void Som::copyStateFrom(const Som &other)
+{
+    if ((ctx == nullptr) != (other.ctx == nullptr))
+        return;
+    const size_t N = width * height;
+    std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
+    std::vector<uint64_t> hh(N);
+    other.getState(m.data(), s.data(), S.data(), w.data(), hh.data());
+    setState(m.data(), s.data(), S.data(), w.data(), hh.data());
+    if (!ctx)
+        hostStale = false;       // the host arrays ARE the state: nothing to refresh from
 }
 
 Som &Som::operator=(const Som &other)
@@ -647,15 +674,10 @@ Som &Som::operator=(const Som &other)
     depth = other.depth;
     inLen = other.inLen;
     createContext();
-    if (ctx && other.ctx) {
-        const size_t N = width * height;
-        std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
-        std::vector<uint64_t> hh(N);
-        other.getState(m.data(), s.data(), S.data(), w.data(), hh.data());
-        setState(m.data(), s.data(), S.data(), w.data(), hh.data());
-    }
-    _isTraining.store(other._isTraining.load());
     hostStale = true;
+    hMap.clear(); hSigma.clear(); hS.clear(); hWeight.clear(); hHits.clear();
+    copyStateFrom(other);
+    _isTraining.store(other._isTraining.load());
     return *this;
 }
 
@@ -691,6 +713,7 @@ void Som::getState(float *map, float *sigma, float *S, float *weight, uint64_t *
         if (hits) std::copy(hHits.begin(), hHits.end(), hits);
         return;
     }
+    joinGroup();
     check(vsom_get_state(ctx, map, sigma, S, weight, hits), "vsom_get_state");
 }
 
@@ -703,8 +726,10 @@ void Som::refreshHost() const
     hSigma.assign(N * depth, 0.f);
     hWeight.assign(N, 0.f);
     hHits.assign(N, 0);
-    if (ctx)
+    if (ctx) {
+        joinGroup();
         check(vsom_get_state(ctx, hMap.data(), hSigma.data(), nullptr, hWeight.data(), hHits.data()), "vsom_get_state");
+    }
     hostStale = false;
 }
 
@@ -1186,6 +1211,7 @@ std::vector<double> Som::findRestrictedBmd(const Eigen::VectorXf &v, const Eigen
 double Som::euclidianWeightedDistRaw(const size_t &pos, const Eigen::VectorXf &v, const Eigen::VectorXf &,
                                      const Eigen::VectorXf &) const
 {
+    joinGroup();
     stageOne(v);
     uint64_t node = pos, row = 0;
     float d = 0.f;
@@ -1197,6 +1223,7 @@ double Som::euclidianWeightedDistRaw(const size_t &pos, const Eigen::VectorXf &v
 void Som::updateUMatrix(const Eigen::VectorXf &)
 {
     requireDevicePath("updateUMatrix");
+    joinGroup();   // raw_dist_kernel reads sigma of every node: the deferred sigmaMap gather must have landed
     // neighbour offsets in the order the reference adds them for an interior node (:1017-1024):
     // W, E, S(i+1), N(i-1), NW(i-1,j-1), SW(i+1,j-1), NE(i-1,j+1), SE(i+1,j+1)
     static const int DI[8] = {0, 0, 1, -1, -1, 1, -1, 1};
