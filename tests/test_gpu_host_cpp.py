@@ -204,9 +204,9 @@ def test_mnist_loader_to_batch_training_end_to_end(tmp_path):
 
 def test_custom_transformation_trains_on_the_host_without_a_device_context(dumps):
     """caller-supplied hooks: no device context, training on the host (tests/test_host_custom.py holds that
-    path to the oracle), consumers outside training throw"""
+    path and its consumers -- U-matrix, evaluate, ... -- to the oracle)"""
     _, out, err = dumps
-    assert "custom_transformation_host_path=1 consumers_throw=1 kind=-1" in out, out + err
+    assert "custom_transformation_host_path=1 consumers_run=1 kind=-1" in out, out + err
 
 
 def test_next_rows_restricted_bmu_bmd_umatrix_evaluate(dumps):

@@ -46,3 +46,29 @@ def test_restricted_bmu_rowdist_rawdist(W, H, J, tr):
         exp = np.array([o.dist_raw(int(n), X[int(r)]) for n, r in zip(nodes[:100], rows)], np.float32)
         assert (raw.view(np.uint32) == exp.view(np.uint32)).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("W,H,J,tr", [(9, 7, 13, 0), (6, 5, 5, 2), (12, 12, 32, 1)])
+def test_python_mirror_update_umatrix(W, H, J, tr):
+    """Som::updateUMatrix (Som.cpp:999-1111) of the Python mirror: raw distances on the device, the 3/5/8
+    neighbour combination on the host, against the oracle's restatement -- also after every epoch of
+    trainBatchSom(updateUMatrixAfterEpoch=True) (:751-752)"""
+    from vsom_amd import som as vs
+    D = po.length(tr, J)
+    X = gen.correlated(120, J, 5) if tr == 2 else gen.blobs(120, J, 4, 1, 2, sigma=0.4)
+    init = gen.random_map(W * H, D, 17)
+    rs = np.random.RandomState(4)
+    sigma = (rs.rand(W * H, D) * 0.5).astype(np.float32)
+    sigma[rs.rand(W * H, D) < 0.1] = 0.0
+    t = vs.Transformation(tr)
+    s = vs.Som(W, H, D if tr != 2 else D, t)
+    s.setState(map=init, sigma=sigma)
+    o = po.OracleSom(W, H, J, tr)
+    o.set_state(map=init, sigma=sigma)
+    assert (s.updateUMatrix() == o.update_umatrix()).all()
+    ds = vs.ArrayDataSet(X, 60)
+    s.trainBatchSom(ds, 2, 3.0, 0.1, updateUMatrixAfterEpoch=True)
+    o.train_batch(X, [0, 60, 120], 2, 3.0, 0.1, nthreads=4)
+    um, uo = s.getUMatrix(), o.update_umatrix()
+    assert ((um == uo) | (np.isnan(um) & np.isnan(uo))).all()
+    s.close()

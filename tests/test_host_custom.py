@@ -97,6 +97,62 @@ def test_batch_training_with_standard_equivalent_hooks(outdir):
     assert np.float32(float.fromhex(got[2])) == np.float32(dist)
 
 
+def test_consumers_outside_training_with_custom_hooks(outdir):
+    """findRestrictedBmu / findRestrictedBmd / euclidianWeightedDistRaw / updateUMatrix / evaluate /
+    measureSimilarity of a custom-hook Som (Som.cpp:143-157, 313-332, 457-523, 631-714, 999-1111) against the
+    oracle on the map test_batch_training_with_standard_equivalent_hooks trains"""
+    rows = make_rows(50, 9, 12345)
+    o = po.OracleSom(10, 10, 9, po.STANDARD)
+    o.random_initialize(42, 1.0)
+    done, mse = o.train_batch(rows, [0, 20, 40, 50], 5, 10.0, 0.3, nthreads=2)
+    v = rows[7]
+    lines = open(os.path.join(outdir, "custom_consumers.txt")).read().split("\n")
+    a, b, c = [int(t) for t in lines[0].split()]
+    assert (a, b, c) == (o.find_restricted_bmu(v, 1), o.find_restricted_bmu(v, 2), o.find_restricted_bmu(v, 1000))
+    assert c == 0                                          # nothing qualifies: node 0 seeds (Som.cpp:316-317)
+    bmd = np.fromfile(os.path.join(outdir, "custom_bmd.bin"), np.float64)
+    exp = o.find_restricted_bmd(v, 1)
+    assert (bmd == exp).all() or np.allclose(bmd, exp, rtol=1e-15, atol=0)
+    um = np.fromfile(os.path.join(outdir, "custom_umatrix.bin"), np.float64)
+    assert (um == o.update_umatrix()).all()
+    tok = lines[1].split()
+    assert float.fromhex(tok[0]) == o.dist_raw(17, v)
+    err = 0.0                                              # evaluate on all-continuous data (Som.cpp:519)
+    for i in range(50):
+        err += 1.0 / (i + 1.0) * (o.dist(o.find_bmu(rows[i]), rows[i]) - err)
+    assert float.fromhex(tok[1]) == err
+
+    def measure(nsig, minhits):                            # Som.cpp:631-714 restated
+        maxv, maxrow, last, success = np.float32(-99999999.0), 0, False, True
+        i = 0
+        while i < 51:
+            if i == 50:
+                i, last = maxrow, True
+            pos = o.find_restricted_bmu(rows[i], minhits)
+            sg, m = o.sigma[pos], o.map[pos]
+            sM = np.where(sg > np.float32(1e-5), np.float32(1e-5), sg).astype(np.float32)
+            with np.errstate(all="ignore"):
+                delta = ((rows[i] - m) / sM / np.float32(nsig)).astype(np.float32)
+            mn, mx = m - sM * np.float32(nsig), m + sM * np.float32(nsig)
+            for k in range(9):
+                if delta[k] > maxv:
+                    maxv, maxrow = np.float32(abs(delta[k])), i
+                if last and (rows[i][k] < mn[k] or rows[i][k] > mx[k]):
+                    success = False
+            if last:
+                break
+            i += 1
+        return int(success)
+    assert int(tok[2]) == measure(3, 1) and int(tok[3]) == measure(1000000, 1)
+    assert lines[2].strip() == "1"
+    # copies of a trained custom-hook Som carry its state (ADVICE r2: they used to come out zeroed)
+    for name in ("custom_copy.bin", "custom_assigned.bin"):
+        check(read_dump(os.path.join(outdir, name)), o, mse)
+    # Octave text checkpoint round trip (six decimals, Som.cpp:1209-1294)
+    m52, w5 = (float(t) for t in lines[3].split())
+    assert abs(m52 - float(o.map[5, 2])) < 1e-5 and abs(w5 - float(o.weight[5])) < 1e-4 * max(1.0, abs(float(o.weight[5])))
+
+
 def test_batch_training_with_median_equivalent_hooks(outdir):
     rows = make_rows(50, 9, 12345)
     o = po.OracleSom(10, 10, 9, po.MEDIAN)

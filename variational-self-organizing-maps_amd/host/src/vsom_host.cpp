@@ -1174,9 +1174,13 @@ void Som::train(DataSet &data, size_t numberOfEpochs, double eta0, double etaDec
 // runs on the device; the scalar post-processing follows the reference line by line on the host.
 
 // Som.cpp:313-332
-SomIndex Som::findRestrictedBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &, const size_t minBmuHits,
-                                const Eigen::VectorXf &) const
+SomIndex Som::findRestrictedBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, const size_t minBmuHits,
+                                const Eigen::VectorXf &weights) const
 {
+    if (!ctx) {   // caller's hooks: host search (vsom_custom.cpp)
+        const size_t idx = hostFindRestrictedBmu(v, valid, minBmuHits, weights);
+        return SomIndex(idx % width, idx / width);
+    }
     stageOne(v);
     uint64_t idx = 0;
     check(vsom_bmu_restricted_batch(ctx, minBmuHits, &idx, nullptr), "vsom_bmu_restricted_batch");
@@ -1184,14 +1188,20 @@ SomIndex Som::findRestrictedBmu(const Eigen::VectorXf &v, const Eigen::VectorXf 
 }
 
 // Som.cpp:457-487
-std::vector<double> Som::findRestrictedBmd(const Eigen::VectorXf &v, const Eigen::VectorXf &, size_t minBmuHits,
-                                           const Eigen::VectorXf &) const
+std::vector<double> Som::findRestrictedBmd(const Eigen::VectorXf &v, const Eigen::VectorXf &valid, size_t minBmuHits,
+                                           const Eigen::VectorXf &weights) const
 {
-    stageOne(v);
-    refreshHost();
     const size_t N = width * height;
     std::vector<float> d(N);
-    check(vsom_distances_row(ctx, 0, d.data()), "vsom_distances_row");
+    if (!ctx) {   // caller's hooks: the distances through Comparer on the host
+        hostEnsure();
+        for (size_t i = 0; i < N; ++i)
+            d[i] = hHits[i] >= minBmuHits ? (float)hostDist(i, v, valid, weights) : 0.f;
+    } else {
+        stageOne(v);
+        refreshHost();
+        check(vsom_distances_row(ctx, 0, d.data()), "vsom_distances_row");
+    }
     std::vector<double> dist(N, -1);
     double C = 0;
     for (size_t i = 0; i < N; ++i) {
@@ -1208,9 +1218,11 @@ std::vector<double> Som::findRestrictedBmd(const Eigen::VectorXf &v, const Eigen
 }
 
 // Som.cpp:143-157 (the built-in use passes valid = weights = 1; other masks are not supported here)
-double Som::euclidianWeightedDistRaw(const size_t &pos, const Eigen::VectorXf &v, const Eigen::VectorXf &,
-                                     const Eigen::VectorXf &) const
+double Som::euclidianWeightedDistRaw(const size_t &pos, const Eigen::VectorXf &v, const Eigen::VectorXf &valid,
+                                     const Eigen::VectorXf &weights) const
 {
+    if (!ctx)
+        return hostDistRaw(pos, v, valid, weights);
     joinGroup();
     stageOne(v);
     uint64_t node = pos, row = 0;
@@ -1222,8 +1234,8 @@ double Som::euclidianWeightedDistRaw(const size_t &pos, const Eigen::VectorXf &v
 // Som.cpp:999-1111: mean sigma-normalised distance to the 3/5/8 neighbours, diagonals weighted 0.3
 void Som::updateUMatrix(const Eigen::VectorXf &)
 {
-    requireDevicePath("updateUMatrix");
-    joinGroup();   // raw_dist_kernel reads sigma of every node: the deferred sigmaMap gather must have landed
+    if (ctx)
+        joinGroup();   // raw_dist_kernel reads sigma of every node: the deferred sigmaMap gather must have landed
     // neighbour offsets in the order the reference adds them for an interior node (:1017-1024):
     // W, E, S(i+1), N(i-1), NW(i-1,j-1), SW(i+1,j-1), NE(i-1,j+1), SE(i+1,j+1)
     static const int DI[8] = {0, 0, 1, -1, -1, 1, -1, 1};
@@ -1243,7 +1255,12 @@ void Som::updateUMatrix(const Eigen::VectorXf &)
                 nbrs.push_back((size_t)ni * width + (size_t)nj);
             }
     std::vector<float> d(nodes.size());
-    if (!nodes.empty())
+    if (!ctx) {   // caller's hooks: euclidianWeightedDistRaw involves none (Som.cpp:143-157), host arithmetic
+        hostEnsure();
+        const Eigen::VectorXf ones = Eigen::VectorXf::Constant((Eigen::Index)depth, 1.f);   // :1002-1003
+        for (size_t k = 0; k < nodes.size(); ++k)
+            d[k] = (float)hostDistRaw((size_t)nodes[k], row_of(hMap, (size_t)nbrs[k], depth), ones, ones);
+    } else if (!nodes.empty())
         check(vsom_distances_raw(ctx, nodes.data(), nbrs.data(), nodes.size(), 1, d.data()), "vsom_distances_raw");
     const double diagonalFactor = 0.3;
     auto R = [&](size_t n, int k) { return (double)d[(size_t)slot[n * 8 + k]]; };
@@ -1282,16 +1299,29 @@ void Som::updateUMatrix(const Eigen::VectorXf &)
 // in the last bits).
 double Som::evaluate(const DataSet &data) const
 {
-    requireDevicePath("evaluate");
     const size_t n = data.size();
     if (n == 0)
         return 0.0;
-    refreshHost();
-    check(vsom_upload_chunk(ctx, data.contiguous(), n), "vsom_upload_chunk");
     std::vector<uint64_t> bmu(n);
     std::vector<float> dist(n);
-    check(vsom_bmu_batch(ctx, bmu.data(), dist.data()), "vsom_bmu_batch");   // findBmu + euclidianWeightedDist(bmu)
     const Eigen::ArrayXi continuous = data.getContinuous(), binary = data.getBinary();
+    if (!ctx) {   // caller's hooks: findBmu / euclidianWeightedDist per sample with val = validity * continuous (:503-505)
+        hostEnsure();
+        const Eigen::VectorXf w = data.getWeights();
+        for (size_t i = 0; i < n; ++i) {
+            const Eigen::VectorXi validity = data.getValidity(i);
+            Eigen::VectorXf val((Eigen::Index)validity.size());
+            for (Eigen::Index d = 0; d < validity.size(); ++d)
+                val[d] = (float)(validity[d] * continuous[d]);
+            const Eigen::VectorXf x = data.getData(i);
+            bmu[i] = hostFindBmu(x, val, w);
+            dist[i] = (float)hostDist((size_t)bmu[i], x, val, w);
+        }
+    } else {
+        refreshHost();
+        check(vsom_upload_chunk(ctx, data.contiguous(), n), "vsom_upload_chunk");
+        check(vsom_bmu_batch(ctx, bmu.data(), dist.data()), "vsom_bmu_batch");   // findBmu + euclidianWeightedDist(bmu)
+    }
     double error = 0;
     for (size_t i = 0; i < n; i++) {
         const Eigen::VectorXi validity = data.getValidity(i);
@@ -1317,14 +1347,25 @@ double Som::evaluate(const DataSet &data) const
 // Som.cpp:631-714
 int Som::measureSimilarity(const DataSet *data, int numOfSigmas, size_t minBmuHits) const
 {
-    requireDevicePath("measureSimilarity");
     const size_t n = data->size();
     if (n == 0)
         return true;
-    refreshHost();
-    check(vsom_upload_chunk(ctx, data->contiguous(), n), "vsom_upload_chunk");
     std::vector<uint64_t> bmus(n);
-    check(vsom_bmu_restricted_batch(ctx, minBmuHits, bmus.data(), nullptr), "vsom_bmu_restricted_batch");
+    if (!ctx) {   // caller's hooks: findRestrictedBmu per sample on the host (:652)
+        hostEnsure();
+        const Eigen::VectorXf w = data->getWeights();
+        for (size_t i = 0; i < n; ++i) {
+            const Eigen::VectorXi validity = data->getValidity(i);
+            Eigen::VectorXf val((Eigen::Index)validity.size());
+            for (Eigen::Index d = 0; d < validity.size(); ++d)
+                val[d] = (float)validity[d];
+            bmus[i] = hostFindRestrictedBmu(data->getData(i), val, minBmuHits, w);
+        }
+    } else {
+        refreshHost();
+        check(vsom_upload_chunk(ctx, data->contiguous(), n), "vsom_upload_chunk");
+        check(vsom_bmu_restricted_batch(ctx, minBmuHits, bmus.data(), nullptr), "vsom_bmu_restricted_batch");
+    }
     bool success = true;
     float maxValue{-99999999.f};
     size_t maxValueDataSetRow{0};
@@ -1360,7 +1401,6 @@ int Som::measureSimilarity(const DataSet *data, int numOfSigmas, size_t minBmuHi
 // draw of the LAST sample (as the reference does).  Non-deterministic (std::random_device).
 size_t Som::variationalAutoEncoder(const DataSet *data, size_t minBmuHits) const
 {
-    requireDevicePath("variationalAutoEncoder");
     std::random_device rd;
     std::mt19937 gen(rd());
     size_t modelVector{0};
@@ -1377,7 +1417,6 @@ size_t Som::variationalAutoEncoder(const DataSet *data, size_t minBmuHits) const
 // Som.cpp:568-623: prints a logit-approximated normal sample per feature around a drawn model vector
 int Som::autoEncoder(const DataSet *data, size_t minBmuHits) const
 {
-    requireDevicePath("autoEncoder");
     std::srand((unsigned)(time(NULL) + clock()));
     for (size_t i = 0; i < data->size(); i++) {
         Eigen::VectorXf v = data->getData(i);
@@ -1402,7 +1441,6 @@ int Som::autoEncoder(const DataSet *data, size_t minBmuHits) const
 // is this build's lossless alternative.
 void Som::save(const char *fileName) const
 {
-    requireDevicePath("save");
     vsom::Checkpoint c;
     c.width = width;
     c.height = height;
@@ -1421,7 +1459,6 @@ void Som::save(const char *fileName) const
 // and the transformation kind); Som::load recognises it by its magic.
 void Som::saveBinary(const char *fileName) const
 {
-    requireDevicePath("saveBinary");
     const size_t N = width * height;
     std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
     std::vector<uint64_t> hh(N);
@@ -1498,7 +1535,6 @@ void Som::load(const char *fileName)
         return;
     }
     f.close();
-    requireDevicePath("load");
     vsom::Checkpoint c;
     c.width = width;
     c.height = height;

@@ -281,7 +281,7 @@ int main(int argc, char **argv)
         fc.write((const char *)umc.data(), umc.size() * 8);
     }
     // ---- a custom std::function transformation cannot run on the device: that Som lives on the host
-    //      (src/vsom_custom.cpp; CPU test tests/test_host_custom.py), the consumers outside training throw ----
+    //      (src/vsom_custom.cpp; CPU test tests/test_host_custom.py), consumers outside training included ----
     {
         Transformation custom{.Comparer = [](const Eigen::VectorXf &, const Eigen::VectorXf &m, const Eigen::VectorXf &,
                                              const Eigen::VectorXf &) { return m; }};
@@ -291,13 +291,15 @@ int main(int argc, char **argv)
         som.randomInitialize(4, 1);
         som.train(ds, 1, 0.1, 0.1, 3.0, 0.1, Som::WeigthDecayFunction::BatchMap);
         const bool trained = som.getWeigthMap()[0] > 0.f && som.context() == nullptr;
-        bool threw = false;
+        bool ran = true;
         try {
-            som.updateUMatrix(Eigen::VectorXf::Ones(J));
+            som.updateUMatrix(Eigen::VectorXf::Ones(J));     // Som.cpp:999-1111 through the host path
+            ds.loadNextDataFromStream();
+            (void)som.evaluate(ds);
         } catch (const std::exception &e) {
-            threw = true;
+            ran = false;
         }
-        std::cout << "custom_transformation_host_path=" << (trained ? 1 : 0) << " consumers_throw=" << (threw ? 1 : 0)
+        std::cout << "custom_transformation_host_path=" << (trained ? 1 : 0) << " consumers_run=" << (ran ? 1 : 0)
                   << " kind=" << custom.kind() << "\n";
     }
     std::cout << "host_api_test done\n";

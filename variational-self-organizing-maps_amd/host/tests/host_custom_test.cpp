@@ -106,6 +106,36 @@ int main(int argc, char **argv)
         std::ofstream f(out + "/custom_search.txt");
         f << som.getIndex(som.findBmu(v)) << " " << som.getIndex(som.findLocalBmu(v, ones, 37, ones)) << " " << std::hexfloat
           << som.euclidianWeightedDist(som.findBmu(v), v, ones, ones) << "\n";
+        // ---- 2a'. the consumers outside training, through the same hooks (Som.cpp:143-157, 313-332, 457-523,
+        //           631-714, 999-1111): restricted BMU / BMD, raw distance, U-matrix, evaluate, measureSimilarity ----
+        std::ofstream g(out + "/custom_consumers.txt");
+        g << som.getIndex(som.findRestrictedBmu(v, ones, 1, ones)) << " " << som.getIndex(som.findRestrictedBmu(v, ones, 2, ones))
+          << " " << som.getIndex(som.findRestrictedBmu(v, ones, 1000, ones)) << "\n";
+        auto bmd = som.findRestrictedBmd(v, ones, 1, ones);
+        std::ofstream fb(out + "/custom_bmd.bin", std::ios::binary);
+        fb.write((const char *)bmd.data(), bmd.size() * 8);
+        som.updateUMatrix(ones);
+        auto um = som.getUMatrix().getData();
+        std::ofstream fu(out + "/custom_umatrix.bin", std::ios::binary);
+        fu.write((const char *)um.data(), um.size() * 8);
+        ArrayDataLoader whole(rows.data(), NROWS, J);
+        DataSet all(whole);
+        all.loadNextDataFromStream();
+        g << std::hexfloat << som.euclidianWeightedDistRaw(17, v, ones, ones) << " " << som.evaluate(all) << " "
+          << som.measureSimilarity(&all, 3, 1) << " " << som.measureSimilarity(&all, 1000000, 1) << "\n";
+        const size_t drawn = som.variationalAutoEncoder(&all, 1);
+        g << (drawn < W * H ? 1 : 0) << "\n";
+        // a copy of a custom-hook Som carries the trained state (the reference's implicit copy does)
+        Som copy{som};
+        Som assigned{2, 2, 3, likeStandard()};
+        assigned = som;
+        dump(out + "/custom_copy.bin", copy, som.getMetrics().MeanSquaredError);
+        dump(out + "/custom_assigned.bin", assigned, som.getMetrics().MeanSquaredError);
+        // Octave text checkpoint of a custom-hook Som: save -> load into a fresh one
+        som.save((out + "/custom_ckpt.txt").c_str());
+        Som loaded{W, H, J, likeStandard()};
+        loaded.load((out + "/custom_ckpt.txt").c_str());
+        g << std::defaultfloat << loaded.getNeuron(size_t{5})[2] << " " << loaded.getWeigthMap()[5] << "\n";
     }
     {   // ---- 2b. batch map with Median-equivalent hooks ----
         ArrayDataLoader loader(rows.data(), NROWS, J, CHUNK);

@@ -255,14 +255,59 @@ class Som:
         dataset.lastBMU[...] = self.ctx.get_last_bmu()
         return mse
 
-    @staticmethod
-    def _no_umatrix(updateUMatrixAfterEpoch):
-        if updateUMatrixAfterEpoch:
-            raise NotImplementedError("updateUMatrixAfterEpoch: the Python mirror has no updateUMatrix "
-                                      "(Som.cpp:999-1111); the C++ mirror (host/, Som::updateUMatrix) implements it")
+    # ---- U-matrix (Som.cpp:143-157, 999-1111) -------------------------------------------------
+    def updateUMatrix(self, weights=None):
+        """Mean sigma-normalised raw distance of every node to its 3/5/8 neighbours, diagonals weighted 0.3;
+        the distances on the device (vsom_distances_raw), their combination in double on the host in the
+        reference's order of additions."""
+        W, H = self.width, self.height
+        DI = (0, 0, 1, -1, -1, 1, -1, 1)       # W, E, S(i+1), N(i-1), NW, SW, NE, SE  (:1017-1024)
+        DJ = (-1, 1, 0, 0, -1, -1, 1, 1)
+        nodes, nbrs, slot = [], [], {}
+        for i in range(H):
+            for j in range(W):
+                for k in range(8):
+                    ni, nj = i + DI[k], j + DJ[k]
+                    if 0 <= ni < H and 0 <= nj < W:
+                        slot[(i * W + j, k)] = len(nodes)
+                        nodes.append(i * W + j)
+                        nbrs.append(ni * W + nj)
+        d = self.ctx.distances_raw(nodes, nbrs, True).astype(np.float64) if nodes else np.zeros(0)
+        f = 0.3
+        Wk, Ek, Sk, Nk, NWk, SWk, NEk, SEk = range(8)
+        U = np.zeros(W * H, np.float64)
+        for i in range(H):
+            for j in range(W):
+                n = i * W + j
+                R = lambda k: float(d[slot[(n, k)]])   # noqa: E731
+                if 0 < j < W - 1 and 0 < i < H - 1:
+                    u = (R(Wk) + R(Ek) + R(Sk) + R(Nk) + R(NWk) * f + R(SWk) * f + R(NEk) * f + R(SEk) * f) / 8
+                elif i == 0 and 0 < j < W - 1:
+                    u = (R(Wk) + R(Ek) + R(Sk) + R(SWk) * f + R(SEk) * f) / 5
+                elif i == H - 1 and 0 < j < W - 1:
+                    u = (R(Wk) + R(Ek) + R(Nk) + R(NWk) * f + R(NEk) * f) / 5
+                elif j == 0 and 0 < i < H - 1:
+                    u = (R(Ek) + R(Sk) + R(Nk) + R(NEk) * f + R(SEk) * f) / 5
+                elif j == W - 1 and 0 < i < H - 1:
+                    u = (R(Wk) + R(Sk) + R(Nk) + R(NWk) * f + R(SWk) * f) / 5
+                elif j == 0 and i == 0 and W > 1 and H > 1:
+                    u = (R(Ek) + R(Sk) + R(SEk) * f) / 3
+                elif j == W - 1 and i == 0 and W > 1 and H > 1:
+                    u = (R(Wk) + R(Sk) + R(SWk) * f) / 3
+                elif j == 0 and i == H - 1 and W > 1 and H > 1:
+                    u = (R(Ek) + R(Nk) + R(NEk) * f) / 3
+                elif j == W - 1 and i == H - 1 and W > 1 and H > 1:
+                    u = (R(Wk) + R(Nk) + R(NWk) * f) / 3
+                else:
+                    u = 0.0
+                U[n] = u
+        self.uMatrix = U
+        return U
+
+    def getUMatrix(self):
+        return getattr(self, "uMatrix", np.zeros(self.width * self.height, np.float64))
 
     def trainBatchSom(self, data, numberOfEpochs, sigma0, sigmaDecay, updateUMatrixAfterEpoch=False):
-        self._no_umatrix(updateUMatrixAfterEpoch)
         self.metrics = Metrics(numberOfEpochs)                    # :719
         for i in range(numberOfEpochs):
             if self._verbose:
@@ -279,6 +324,8 @@ class Som:
             mse = np.float32(mse / np.float32(count))             # :743
             self.metrics.MeanSquaredError[i] = mse
             data.resetStreamLoadPosition()
+            if updateUMatrixAfterEpoch:
+                self.updateUMatrix(data.getWeights())             # :751-752 / :1183-1184
 
     # ---- online training (Som.cpp:885-947, 1135-1187) ---------------------------------------
     def trainSingle(self, v, valid, weights, eta, sigma, lastBMU, weightDecayFunction):
@@ -287,7 +334,6 @@ class Som:
 
     def trainBasicSom(self, data, numberOfEpochs, eta0, etaDecay, sigma0, sigmaDecay,
                       weightDecayFunction, updateUMatrixAfterEpoch=False):
-        self._no_umatrix(updateUMatrixAfterEpoch)
         self.metrics = Metrics(numberOfEpochs)
         for i in range(numberOfEpochs):
             eta = eta0 * math.exp(-etaDecay * float(i))           # :1145
@@ -306,6 +352,8 @@ class Som:
             mse = np.float32(mse / np.float32(count))             # :1175
             self.metrics.MeanSquaredError[i] = mse
             data.resetStreamLoadPosition()
+            if updateUMatrixAfterEpoch:
+                self.updateUMatrix(data.getWeights())             # :751-752 / :1183-1184
 
     def train(self, data, numberOfEpochs, eta0, etaDecay, sigma0, sigmaDecay, weightDecayFunction,
               updateUMatrixAfterEpoch=False):
