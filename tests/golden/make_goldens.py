@@ -93,6 +93,27 @@ def main():
     online_case("c5_clr_online_exp", 6, 6, 5, po.CLR, gen.correlated(24, 5, 5), gen.random_map(36, 20, 5), 0.01, 2.0, po.EXPONENTIAL)
     # local search + sigma <= 1 online
     online_case("online_local_sigma1", 9, 9, 7, po.STANDARD, gen.blobs(30, 7, 3, 1, 2), gen.random_map(81, 7, 6), 0.05, 1.0, po.EXPONENTIAL)
+    # ---- the quirk list, so that a replay on the real reference (oracle/eigen_crosscheck.cpp)
+    #      pins every convention the oracle only restates ----
+    # Q10: SomIndex divides by HEIGHT (SomIndex.cpp:15-18) -- wrong for W != H; both orientations, local epochs incl.
+    batch_case("q10_nonsquare_9x7_batch", 9, 7, 13, po.STANDARD, gen.blobs(70, 13, 4, 1, 2, sigma=0.3), gen.random_map(63, 13, 8), 4.0, 0.2, 3, 40)
+    batch_case("q10_nonsquare_5x11_median_batch", 5, 11, 10, po.MEDIAN, gen.blobs(60, 10, 4, 3, 5, sigma=0.4), gen.random_map(55, 10, 9), 3.0, 0.15, 3, 60)
+    online_case("q10_nonsquare_7x11_online_exp", 7, 11, 9, po.STANDARD, gen.blobs(36, 9, 3, 1, 2, sigma=0.3), gen.random_map(77, 9, 10), 0.1, 2.5, po.EXPONENTIAL)
+    # Q7: weight underflow -> 0/0 poisons nodes (Som.cpp:857-864): 36x36 map, sigma 2 and 1.64: nodes farther than
+    # ~29 cells from the first sample's BMU start from W = 0 and stay NaN for the epoch
+    batch_case("q7_nan_poison_36x36_batch", 36, 36, 6, po.STANDARD, gen.blobs(40, 6, 3, 1, 2, sigma=0.3), gen.random_map(1296, 6, 11), 2.0, 0.2, 2, 40)
+    # Q1: depth 794 = what MnistDataLoader yields (784 pixels + 10 one-hot, MnistDataLoader.cpp:47-84): 99 packets
+    # of 8 and a two-element tail in Eigen's dot (Som.cpp:140)
+    batch_case("q1_depth794_tail_batch", 6, 5, 794, po.STANDARD, gen.mnist_like(24, 3, 794), gen.random_map(30, 794, 12) * np.float32(100), 2.5, 0.3, 2, 24)
+    # D = 9 + D = 13 are covered above (one packet + tail); D = 3 (< one packet): sequential sum
+    batch_case("q1_depth3_batch", 8, 8, 3, po.STANDARD, gen.blobs(30, 3, 3, 1, 2, sigma=0.3), gen.random_map(64, 3, 13), 3.0, 0.3, 2, 30)
+    # CLR with P = J(J-1)/2 not a multiple of 4 (J = 7: P = 21, one whole packet pair + 5) on a non-square map
+    batch_case("q1_clr_p21_5x4_batch", 5, 4, 7, po.CLR, gen.correlated(40, 7, 5), gen.random_map(20, 42, 14), 2.5, 0.2, 2, 40)
+    online_case("q1_clr_p21_online_inv", 5, 4, 7, po.CLR, gen.correlated(20, 7, 5), gen.random_map(20, 42, 14), 0.01, 2.0, po.INVERSE_PROPORTIONAL)
+    # InverseProportional from the all-zero weight map Construct leaves (Som.cpp:928-936: t = Wt == 0 ? 1 : h/Wt)
+    # on the reference's 20-row fixture is fixture_online_inv above; the same with sigma <= 1 (local search, window
+    # of one node, most weights stay 0):
+    online_case("fixture_online_inv_sigma1", 10, 10, 9, po.STANDARD, fx, gen.random_map(100, 9, 42), 0.001, 1.0, po.INVERSE_PROPORTIONAL)
 
 
 if __name__ == "__main__":
