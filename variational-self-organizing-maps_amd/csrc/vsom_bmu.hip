@@ -56,6 +56,7 @@ __global__ void zero_u64_kernel(u64 *p, size_t n)
 int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B)
 {
     TimerScope ts(c, VSOM_T_STAGE);
+    c->cc_valid = false;
     if (B == 0)
         return VSOM_OK;
     {
@@ -73,7 +74,7 @@ int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B)
     hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream,
                        c->lastbmu, B);
     VSOM_HIP_CHECK(hipGetLastError());
-    return VSOM_OK;
+    return vsom_cc_stage(c);      // live-column record of this chunk (vsom_compact.hip)
 }
 
 static DistArgs make_dist_args(const vsom_ctx *c)
@@ -103,7 +104,12 @@ static DistArgs make_dist_args(const vsom_ctx *c)
 #define TILE 64
 #define LDT 36   // LDS row stride in floats: 16-B aligned, lane rows land on distinct 4-bank slots
 
-template <bool CLR>
+// TI = sample rows per thread: 4 for Standard / Median (64 x 64 tile, 128 accumulators per thread).  The CLR
+// residual needs two more operand arrays (y', B): with 4 x 4 pairs the kernel sat at 256 VGPRs with 46 spilled
+// dwords in the hot loop and no room to prefetch (r2: VALU 54 % busy, 2.3 ms at C5).  CLR therefore takes
+// TI = 2 -- a 32-sample x 64-node tile, 64 accumulators -- which leaves registers for the next K-chunk's loads
+// in flight while the current one is consumed and lets three workgroups share a CU.
+template <bool CLR, int TI>
 __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, int s1, int N,
                                                           u64 *__restrict__ partial, int pstride,
                                                           unsigned char *__restrict__ nan0,
@@ -111,55 +117,62 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
                                                           const unsigned *__restrict__ scount,
                                                           const u64 *__restrict__ hits, u64 min_hits)
 {
+    constexpr int TS = 16 * TI;                 // samples per tile
+    constexpr int NX = TS * 8 / 256;            // float4 of a sample operand per thread and K-chunk (1 or 2)
     // optional indirection: process only the samples listed by the shortlist path
     // (vsom_shortlist.hip); s0/s1 then index the list and workgroups beyond its length exit
     if (scount) {
         const int cnt = (int)*scount;
         s1 = s0 + cnt < s1 ? s0 + cnt : s1;
-        if (s0 + (int)blockIdx.y * TILE >= s1)
+        if (s0 + (int)blockIdx.y * TS >= s1)
             return;
     }
-    __shared__ __attribute__((aligned(16))) float sx[TILE * LDT];
+    __shared__ __attribute__((aligned(16))) float sx[TILE * LDT];   // TS rows used (also the key scratch: 64 x 16 u64 max)
     __shared__ __attribute__((aligned(16))) float sm[TILE * LDT];
-    __shared__ __attribute__((aligned(16))) float sy[CLR ? TILE * LDT : 4];
+    __shared__ __attribute__((aligned(16))) float sy[CLR ? TS * LDT : 4];
     __shared__ __attribute__((aligned(16))) float sb[CLR ? TILE * LDT : 4];
 
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int nbase = blockIdx.x * TILE;
-    const int sbase = s0 + blockIdx.y * TILE;
+    const int sbase = s0 + blockIdx.y * TS;
     const int L = a.L, L8 = L & ~7;
     const int nchunks = (L + VSOM_TK - 1) / VSOM_TK;
 
-    float acc[4][4][8];
+    float acc[TI][4][8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 acc[i][j][k] = 0.f;
 
-    // global -> register staging of one K-chunk (2 float4 per operand and thread).  Standard / Median keep
-    // the NEXT chunk's loads in flight while the current one is consumed (register prefetch: the loads used
-    // to be issued and waited for between the two barriers, with only two wavefronts per SIMD to cover
-    // them); the CLR kernel sits at 256 VGPRs and has no room for the second set.
-    float4 gx[2], gm[2], gy[2], gb[2];
+    // global -> register staging of one K-chunk; the NEXT chunk's loads stay in flight while the current one is
+    // consumed (register prefetch: the loads used to be issued and waited for between the two barriers, with
+    // only two wavefronts per SIMD to cover them)
+    float4 gx[NX], gm[2], gy[NX], gb[2];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NX; ++i) {
             int f = tid + 256 * i;
             int row = f >> 3, c4 = (f & 7) * 4;
-            int s = sbase + row, n = nbase + row;
+            int s = sbase + row;
             gx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            gm[i] = gx[i];
             gy[i] = gx[i];
-            gb[i] = gx[i];
             if (s < s1) {
                 const size_t srow = slist ? (size_t)slist[s - s0] : (size_t)s;
                 gx[i] = *reinterpret_cast<const float4 *>(a.xa + srow * a.ldx + k0 + c4);
                 if (CLR)
                     gy[i] = *reinterpret_cast<const float4 *>(a.xb + srow * a.ldx + k0 + c4);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int f = tid + 256 * i;
+            int row = f >> 3, c4 = (f & 7) * 4;
+            int n = nbase + row;
+            gm[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            gb[i] = gm[i];
             if (n < N) {
                 gm[i] = *reinterpret_cast<const float4 *>(a.ma + (size_t)n * a.ldm + k0 + c4);
                 if (CLR)
@@ -167,48 +180,50 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
             }
         }
     };
-    if (!CLR)
-        gload(0);
+    gload(0);
     int dk = 0;
     for (int ch = 0; ch < nchunks; ++ch, dk += VSOM_TK) {
         if (ch > 0)
             __syncthreads();
-        if (CLR)
-            gload(dk);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            int f = tid + 256 * i;
+            int row = f >> 3, c4 = (f & 7) * 4;
+            *reinterpret_cast<float4 *>(&sx[row * LDT + c4]) = gx[i];
+            if (CLR)
+                *reinterpret_cast<float4 *>(&sy[row * LDT + c4]) = gy[i];
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int f = tid + 256 * i;
             int row = f >> 3, c4 = (f & 7) * 4;
-            *reinterpret_cast<float4 *>(&sx[row * LDT + c4]) = gx[i];
             *reinterpret_cast<float4 *>(&sm[row * LDT + c4]) = gm[i];
-            if (CLR) {
-                *reinterpret_cast<float4 *>(&sy[row * LDT + c4]) = gy[i];
+            if (CLR)
                 *reinterpret_cast<float4 *>(&sb[row * LDT + c4]) = gb[i];
-            }
         }
         __syncthreads();
-        if (!CLR && ch + 1 < nchunks)
+        if (ch + 1 < nchunks)
             gload(dk + VSOM_TK);
 #pragma unroll
         for (int kk = 0; kk < VSOM_TK; kk += 8) {
             if (dk + kk < L8) {   // whole 8-blocks only; the remainder is handled in Eigen's order below
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    float4 xv[4], mv[4], yv[4], bv[4];
+                    float4 xv[TI], mv[4], yv[TI], bv[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        mv[i] = *reinterpret_cast<const float4 *>(&sm[(tx + 16 * i) * LDT + kk + 4 * h]);
+                    for (int j = 0; j < 4; ++j) {
+                        mv[j] = *reinterpret_cast<const float4 *>(&sm[(tx + 16 * j) * LDT + kk + 4 * h]);
                         if (CLR)
-                            bv[i] = *reinterpret_cast<const float4 *>(&sb[(tx + 16 * i) * LDT + kk + 4 * h]);
-                        else
-                            xv[i] = *reinterpret_cast<const float4 *>(&sx[(ty + 16 * i) * LDT + kk + 4 * h]);
+                            bv[j] = *reinterpret_cast<const float4 *>(&sb[(tx + 16 * j) * LDT + kk + 4 * h]);
                     }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (CLR) {   // the CLR kernel is out of registers: the sample operands one row at a time
-                            xv[i] = *reinterpret_cast<const float4 *>(&sx[(ty + 16 * i) * LDT + kk + 4 * h]);
+                    for (int i = 0; i < TI; ++i) {
+                        xv[i] = *reinterpret_cast<const float4 *>(&sx[(ty + 16 * i) * LDT + kk + 4 * h]);
+                        if (CLR)
                             yv[i] = *reinterpret_cast<const float4 *>(&sy[(ty + 16 * i) * LDT + kk + 4 * h]);
-                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < TI; ++i) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float r0 = vsom_resid<CLR>(xv[i].x, CLR ? yv[i].x : 0.f, mv[j].x, CLR ? bv[j].x : 0.f);
@@ -230,9 +245,9 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
     // reduction tree + remainder (the last chunk is still in LDS)
     const int rem = L - L8;
     const int roff = L8 - (nchunks - 1) * VSOM_TK;   // column of element L8 inside the last chunk
-    float dist[4][4];
+    float dist[TI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float q0 = acc[i][j][0] + acc[i][j][4];
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
     // node 0's NaN flag: `cur < NaN` is never true, so a NaN at node 0 pins the BMU to 0 (Som.cpp:293-299)
     if (blockIdx.x == 0 && tx == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TI; ++i) {
             int s = sbase + ty + 16 * i;
             if (s < s1)
                 nan0[slist ? slist[s - s0] : s] = (dist[i][0] != dist[i][0]) ? 1 : 0;
@@ -274,9 +289,9 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
     }
 
     __syncthreads();   // everyone is done with sx before it is reused for the keys
-    u64 *keys = reinterpret_cast<u64 *>(sx);   // 64 samples x 16 tx
+    u64 *keys = reinterpret_cast<u64 *>(sx);   // TS samples x 16 tx
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TI; ++i) {
         u64 kmin = ~0ull;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -289,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
         keys[(ty + 16 * i) * 16 + tx] = kmin;
     }
     __syncthreads();
-    if (tid < TILE) {
+    if (tid < TS) {
         int s = sbase + tid;
         if (s < s1) {
             u64 kmin = ~0ull;
@@ -337,7 +352,8 @@ int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *s
     if (s1 <= s0)
         return VSOM_OK;
     const int ntn = (int)((c->N + TILE - 1) / TILE);
-    const int nts = (int)((s1 - s0 + TILE - 1) / TILE);
+    const int TS = c->transform == VSOM_CLR ? 32 : TILE;      // samples per tile (bmu_tile_kernel<CLR, TI>)
+    const int nts = (int)((s1 - s0 + TS - 1) / TS);
     size_t need = (size_t)ntn * c->Bcap;
     if (need > c->partial_cap) {
         if (c->partial)
@@ -349,10 +365,10 @@ int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *s
     DistArgs a = make_dist_args(c);
     dim3 grid((unsigned)ntn, (unsigned)nts);
     if (c->transform == VSOM_CLR)
-        hipLaunchKernelGGL(bmu_tile_kernel<true>, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
+        hipLaunchKernelGGL((bmu_tile_kernel<true, 2>), grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
                            (int)c->N, c->partial, (int)c->Bcap, c->nan0, slist, scount, hits, min_hits);
     else
-        hipLaunchKernelGGL(bmu_tile_kernel<false>, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
+        hipLaunchKernelGGL((bmu_tile_kernel<false, 4>), grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
                            (int)c->N, c->partial, (int)c->Bcap, c->nan0, slist, scount, hits, min_hits);
     hipLaunchKernelGGL(bmu_reduce_kernel, dim3((unsigned)((s1 - s0 + 255) / 256)), dim3(256), 0,
                        c->stream, c->partial, (int)c->Bcap, ntn, c->nan0, (int)s0, (int)s1, c->lastbmu,

@@ -106,6 +106,20 @@ struct vsom_ctx {
     bool use_tiny = true;           // one-launch epoch for tiny maps (VSOM_NO_TINY=1 disables, debugging)
     int cw_mode = 0;                // 0 role-split kernel, 1 quad kernel, 2 16-lane kernel (VSOM_CW_MODE, debugging)
 
+    // column compaction (vsom_compact.hip): columns that are zero in every row of the chunk are retired exactly
+    unsigned *cc_flags = nullptr;   // [xpitch] live flags
+    int *cc_idx = nullptr;          // [cpitch] live column list, -1 beyond the live count
+    int *cc_inv = nullptr;          // [xpitch] column -> compacted position or -1
+    unsigned *cc_meta = nullptr;    // device: {live columns, live 14-dim slices, live columns rounded up to 32, seq}
+    unsigned *cc_fb = nullptr;      // pinned host mirror: {live columns, seq}
+    unsigned cc_seen = 0;
+    int cc_skip = 0;
+    bool cc_valid = false;          // the staged chunk has a compaction (Xc, cc_idx, cc_meta describe it)
+    uint32_t cpitch = 0;            // row pitch of the compacted matrices
+    float *Xc = nullptr; size_t Xc_cap = 0;      // (Bcap + VSOM_ROW_PAD) x cpitch
+    float *Mc = nullptr;            // N x cpitch: model rows on the live columns (search)
+    float *Uc_map = nullptr, *Uc_S = nullptr;    // N x cpitch: the chains' M and raw S on the live columns
+
     // online path scratch
     float *v_dev = nullptr;         // one sample, padded
     float *v_pinned = nullptr;      // its pinned host staging (+ 16 floats for results)
@@ -156,5 +170,11 @@ int launch_raw_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *vrows_dev, siz
                     float *out_dev);
 int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1);
 int ensure_lut(vsom_ctx *c, double sigma);
+// column compaction (vsom_compact.hip)
+bool vsom_cc_applies(const vsom_ctx *c);
+int vsom_cc_stage(vsom_ctx *c);
+int vsom_cc_gather_map(vsom_ctx *c);
+int vsom_cc_ensure_update_scratch(vsom_ctx *c);
+int vsom_cc_expand(vsom_ctx *c, size_t n0, size_t nloc);
 bool vsom_tiny_applies(const vsom_ctx *c);                        // vsom_tiny.hip
 int launch_tiny_epoch(vsom_ctx *c, double sigma, int is_first);   // whole batch epoch, one workgroup

@@ -111,8 +111,12 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict
                                                          const float *__restrict__ M, int ldm, int N, int Kp,
                                                          const float *__restrict__ nrm,
                                                          float *__restrict__ G, int ldg,
-                                                         float *__restrict__ tmin, int ntm)
+                                                         float *__restrict__ tmin, int ntm,
+                                                         const unsigned *__restrict__ kp_dev)
 {
+    // X / M gathered onto the chunk's live columns (vsom_compact.hip): the contraction length is a device value
+    if (kp_dev)
+        Kp = (int)kp_dev[2];
     __shared__ __attribute__((aligned(16))) float As[GT * GLD];
     __shared__ __attribute__((aligned(16))) float Bs[GT * GLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -529,8 +533,19 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     hipLaunchKernelGGL(sl_norm_kernel, dim3((unsigned)(((size_t)c->N * 16 + 255) / 256)), dim3(256), 0, c->stream,
                        c->map, (int)c->pitch, (int)c->part_pitch, (int)c->N, c->sl_nrm, scal);
     dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
+    if (c->cc_valid) {
+        // columns that are zero in every row of the chunk add exactly 0 to every <x, M>: contract over the live
+        // ones (norms, bound and refinement keep the whole rows)
+        int rc = vsom_cc_gather_map(c);
+        if (rc)
+            return rc;
+        hipLaunchKernelGGL(sl_gemm_kernel, grid, dim3(256), 0, c->stream, c->Xc, (int)c->cpitch, (int)s0, (int)s1,
+                           c->Mc, (int)c->cpitch, (int)c->N, (int)c->cpitch, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm,
+                           (const unsigned *)c->cc_meta);
+    } else
     hipLaunchKernelGGL(sl_gemm_kernel, grid, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, (int)s0, (int)s1,
-                       c->map, (int)c->pitch, (int)c->N, (int)c->xpitch, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm);
+                       c->map, (int)c->pitch, (int)c->N, (int)c->xpitch, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm,
+                       (const unsigned *)nullptr);
     DistArgs a;
     a.xa = c->Xs;
     a.xb = c->Xs;
@@ -737,7 +752,7 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
                        (int)P, c->Xs, (int)c->xpitch, (int)J, c->sl_fs, (int)Kp, (int)P32, (int)s0, (int)s1);
     dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
     hipLaunchKernelGGL(sl_gemm_kernel, grid, dim3(256), 0, c->stream, c->sl_fs, (int)Kp, (int)s0, (int)s1, c->sl_fm, (int)Kp,
-                       (int)c->N, (int)Kp, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm);
+                       (int)c->N, (int)Kp, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, (const unsigned *)nullptr);
     DistArgs a;
     a.xa = c->XP;
     a.xb = c->YP;

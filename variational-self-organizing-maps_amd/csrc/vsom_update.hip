@@ -807,28 +807,54 @@ __global__ __launch_bounds__(256, 1) void update_chain3_kernel(const float *__re
     VSOM_C3_LOAD(1);
     VSOM_C3_STORE(1);
     __syncthreads();
+    // The chains run at ONE wavefront per SIMD (C4: 1024 wavefronts), so nothing hides the LDS round trip of
+    // the operand reads but the wavefront itself: the operands of the NEXT group of U samples are read from LDS
+    // (two register sets used alternately) while the current group's dependent chain executes -- also across
+    // the block boundary: slot (blk+1)%3 was completed and made visible by the barrier that ended the previous
+    // iteration.  r2 read a group, waited for it, then computed: ~150 exposed cycles per 8 samples of a
+    // ~40-cycle-per-sample chain (C4: 0.60 ms).
+    constexpr int U = 8, NGRP = CT / U;
+    vsom_f2 xa[U], xb[U];
+    float4 ca[U / 2], cb[U / 2];
+    auto ldsl = [&](vsom_f2 (&xv)[U], float4 (&cv)[U / 2], int slot, int t) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            xv[u] = *reinterpret_cast<const vsom_f2 *>(&xs[slot][t + u][2 * lp]);
+#pragma unroll
+        for (int u = 0; u < U / 2; ++u)
+            cv[u] = cs[slot][(t >> 1) + u][lnode];
+    };
+    auto steps = [&](const vsom_f2 (&xv)[U], const float4 (&cv)[U / 2]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            one(xv[u], (u & 1) ? cv[u >> 1].z : cv[u >> 1].x, (u & 1) ? cv[u >> 1].w : cv[u >> 1].y);
+    };
+    ldsl(xa, ca, 0, 0);
     for (int blk = 0; blk < nblocks; ++blk) {
-        const int slot = blk % 3;
+        const int slot = blk % 3, nslot = (blk + 1) % 3;
         VSOM_C3_LOAD(blk + 2);                            // in flight while this block is consumed
         const int nt = B - blk * CT < CT ? B - blk * CT : CT;
-        constexpr int U = 8;                              // operands of U samples read from LDS before use
-        int t = 0;
-        for (; t + U <= nt; t += U) {
-            vsom_f2 xv[U];
-            float4 cv[U / 2];
+        if (nt == CT) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                xv[u] = *reinterpret_cast<const vsom_f2 *>(&xs[slot][t + u][2 * lp]);
-#pragma unroll
-            for (int u = 0; u < U / 2; ++u)
-                cv[u] = cs[slot][(t >> 1) + u][lnode];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                one(xv[u], (u & 1) ? cv[u >> 1].z : cv[u >> 1].x, (u & 1) ? cv[u >> 1].w : cv[u >> 1].y);
-        }
-        for (; t < nt; ++t) {
-            const float4 cv = cs[slot][t >> 1][lnode];
-            one(*reinterpret_cast<const vsom_f2 *>(&xs[slot][t][2 * lp]), (t & 1) ? cv.z : cv.x, (t & 1) ? cv.w : cv.y);
+            for (int g = 0; g < NGRP; g += 2) {
+                ldsl(xb, cb, slot, (g + 1) * U);
+                steps(xa, ca);
+                if (g + 2 < NGRP)
+                    ldsl(xa, ca, slot, (g + 2) * U);
+                else
+                    ldsl(xa, ca, nslot, 0);                // first group of the next block
+                steps(xb, cb);
+            }
+        } else {                                          // the last, partial block
+            int t = 0;
+            for (; t + U <= nt; t += U) {
+                ldsl(xa, ca, slot, t);
+                steps(xa, ca);
+            }
+            for (; t < nt; ++t) {
+                const float4 cv = cs[slot][t >> 1][lnode];
+                one(*reinterpret_cast<const vsom_f2 *>(&xs[slot][t][2 * lp]), (t & 1) ? cv.z : cv.x, (t & 1) ? cv.w : cv.y);
+            }
         }
         VSOM_C3_STORE((blk + 2) % 3);                     // slot (blk+2)%3 was last read in iteration blk-1
         __syncthreads();
@@ -1042,7 +1068,7 @@ struct UpdAsmArgs {
     void *map;
     void *sbuf;
     unsigned ldx_bytes, ldn_bytes, B, nloc, nslices, pitch_bytes, n0, ppitch_bytes;   // ppitch: CLR only
-    const void *yp;                                                                   // CLR only (kernarg 72 B)
+    const void *yp;                  // CLR: y' rows; Standard / Median: live-slice record of the compaction or null
 };
 
 int vsom_load_asm_module(vsom_ctx *c)
@@ -1374,22 +1400,28 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 const bool med = c->transform == VSOM_MEDIAN;     // its FMAs are exact: one kernel for all modes
                 void *const fn16 = med ? c->upd_med16 : (fma ? c->upd_fma16 : (sfma ? c->upd_sfma16 : c->upd_fn16));
                 void *const fn14 = med ? c->upd_med14 : (fma ? c->upd_fma14 : (sfma ? c->upd_sfma14 : c->upd_fn14));
+                // column compaction (vsom_compact.hip): the chains of the columns that are zero in every row of
+                // the chunk are retired -- the 14-wide kernel runs on the gathered live columns (device-side
+                // slice count) into dense scratch rows and cc_expand_kernel writes map / sigmaMap back
+                const bool compact = c->cc_valid;
+                if (compact && (rc = vsom_cc_ensure_update_scratch(c)))
+                    return rc;
                 auto launch = [&](void *fn, unsigned nsl, unsigned col0, hipStream_t st) -> int {
                     UpdAsmArgs a;
-                    a.xs = c->Xs + col0;
+                    a.xs = compact ? c->Xc : c->Xs + col0;
                     a.cw2 = c->cw;
-                    a.map = c->map + col0;
-                    a.sbuf = c->sigma + col0;
-                    a.ldx_bytes = c->xpitch * 4u;
+                    a.map = compact ? c->Uc_map : c->map + col0;
+                    a.sbuf = compact ? c->Uc_S : c->sigma + col0;
+                    a.ldx_bytes = (compact ? c->cpitch : c->xpitch) * 4u;
                     a.ldn_bytes = (unsigned)(ldn * 16u);
                     a.B = (unsigned)c->B;
                     a.nloc = (unsigned)nloc;
                     a.nslices = nsl;
-                    a.pitch_bytes = c->pitch * 4u;
+                    a.pitch_bytes = (compact ? c->cpitch : c->pitch) * 4u;
                     a.n0 = (unsigned)n0;
                     a.ppitch_bytes = 0;
-                    a.yp = nullptr;
-                    size_t sz = 64;   // kernarg segment of the Standard kernels (the CLR one takes all 72 bytes)
+                    a.yp = compact ? (const void *)c->cc_meta : nullptr;
+                    size_t sz = sizeof(a);   // 72 bytes
                     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
                                      HIP_LAUNCH_PARAM_END};
                     // XCD-aware grid: x = 8 * slice quads, y = node groups / 8 (see gen_update_asm.py)
@@ -1397,6 +1429,10 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                                                          1, 0, st, nullptr, extra));
                     return VSOM_OK;
                 };
+                if (compact) {
+                    n16 = 0;
+                    n14 = (c->D + 13) / 14;      // upper bound; the kernel reads the live count from cc_meta
+                }
                 if (n16 + n14 > 0) {
                     const bool both = n16 > 0 && n14 > 0;
                     if (both) {   // fork: the 14-wide part beside the 16-wide one
@@ -1414,7 +1450,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                             return rc;
                     }
                     dbase = (int)c->D;
-                    sig_cols = (int)(n16 * 16 + n14 * 14);
+                    sig_cols = compact ? -1 : (int)(n16 * 16 + n14 * 14);
                 }
             }
             const int rest = (int)c->D - dbase;
@@ -1432,6 +1468,11 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
             }
         }
         VSOM_HIP_CHECK(hipGetLastError());
+    }
+    if (sig_cols < 0) {
+        TimerScope ts(c, VSOM_T_SIGMA);
+        if ((rc = vsom_cc_expand(c, n0, nloc)))
+            return rc;
     }
     if (sig_cols > 0) {
         TimerScope ts(c, VSOM_T_SIGMA);
