@@ -221,8 +221,6 @@ def profile_traffic(key):
     ent = t.get(key)
     if isinstance(ent, dict):
         return ent.get("hbm_bytes_per_launch"), f"profiles/traffic.json[{key}] ({ent.get('source', 'rocprofv3 --pmc')})"
-    if key == "c3" and "update_kernel_hbm_bytes_per_launch" in t:
-        return t["update_kernel_hbm_bytes_per_launch"], "profiles/traffic.json (r1 rocprofv3 --pmc passes)"
     return None, None
 
 
@@ -455,7 +453,7 @@ def main():
                     "algorithmic_flop_per_launch": flops}
 
         roof = roofline_for(timing, split)
-        traffic, tsrc = profile_traffic(args.config + {"strict": "_strict", "sigma": "_sigma", "contracted": ""}[args.arith])
+        traffic, tsrc = profile_traffic(f"{args.config}_{args.arith}")
         roof["traffic"] = traffic
         roof["traffic_source"] = tsrc
         arith = "n/a (online path has no contracted mode)" if online else ARITH_TEXT[args.arith]

@@ -126,6 +126,12 @@ int vsom_set_stream(vsom_ctx *ctx, void *hip_stream);
 int vsom_synchronize(vsom_ctx *ctx);
 int vsom_set_bmu_mode(vsom_ctx *ctx, int mode);
 int vsom_set_update_mode(vsom_ctx *ctx, int mode);
+/* Exact retirement of the sample columns that are zero in every row of a chunk (csrc/vsom_compact.hip: their
+ * chains stay 0 -- or NaN for a node whose first weight is 0/0 -- and they add nothing to the search's
+ * contraction; MNIST has ~120 such columns per 4096-image chunk).  Results are bit-identical with it on or off.
+ * Chunks of at least min_rows rows use it (default 1024: below that the passes cost more than they save);
+ * min_rows < 0 switches it off. */
+int vsom_set_column_compaction(vsom_ctx *ctx, long min_rows);
 /* diagnostics of the last MFMA-shortlist search (synchronises): out[0] = samples that had to be
  * redone by the exact-order kernel, out[1] = shortlisted candidates in total, out[2] = samples
  * searched, out[3] = number of shortlist searches so far */

@@ -41,6 +41,7 @@ def _check_epoch(ctx, orc, X, sigma, first, tag):
 
 def _pair(W, H, J, tr, init):
     ctx = vsom_amd.Context(W, H, J, tr)
+    ctx.set_column_compaction(1)        # the library's default threshold is 1024 rows: these chunks are smaller
     orc = po.OracleSom(W, H, J, tr)
     ctx.set_state(map=init)
     orc.set_state(map=init)
@@ -126,6 +127,30 @@ def test_live_set_changes_between_chunks_and_dense_chunks_pause_the_passes():
     ctx.close()
 
 
+def test_default_threshold_and_switch():
+    """chunks below 1024 rows are left alone by default, larger ones are compacted; either way and with the
+    feature switched off the results are the same bits"""
+    W = H = 40
+    init = gen.random_map(W * H, 784, 42) * np.float32(100)
+    X = gen.mnist_like(1100, 3, 784)
+    ref = None
+    for setting in (None, -1, 1):
+        ctx = vsom_amd.Context(W, H, 784, po.STANDARD)
+        if setting is not None:
+            ctx.set_column_compaction(setting)
+        ctx.set_state(map=init)
+        for Xc in (X, X[:300]):
+            ctx.upload_chunk(Xc)
+            ctx.batch_epoch(9.0, True)
+        st = ctx.get_state(S=False)
+        if ref is None:
+            ref = st
+        else:
+            for k in ("map", "sigma", "weight", "hits"):
+                assert _same(st[k], ref[k]), (setting, k)
+        ctx.close()
+
+
 def test_group_of_three_on_data_with_dead_columns():
     """node shards: every member runs the compacted chains on its third of the nodes"""
     W, H, J, B = 48, 45, 784, 240
@@ -134,6 +159,8 @@ def test_group_of_three_on_data_with_dead_columns():
     orc = po.OracleSom(W, H, J, po.STANDARD)
     orc.set_state(map=init)
     grp = capi.Group(W, H, J, capi.STANDARD, devices=[0, 0, 0])
+    for r in range(3):
+        grp.member(r).set_column_compaction(1)
     grp.set_state(map=init)
     for e, sigma in enumerate((8.0, 6.5, 2.0)):
         lb = np.zeros(B, np.uint64)

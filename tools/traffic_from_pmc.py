@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from the committed rocprofv3 PMC summaries (profiles/r2_<cfg>_pmc.txt, written by
+"""profiles/traffic.json from the committed rocprofv3 PMC summaries (profiles/r<N>_<cfg>_pmc.txt, written by
 tools/collect_profiles.sh + tools/pmc_summary.py): HBM-side bytes per launch of each configuration's dominant
 kernel = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes).  The factor 2 is the gfx950 correction of
 MI355X_MICROARCH.md ("FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read",
@@ -13,9 +13,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
-KERNEL = {"c3": r"vsom_update_fma_rd14_gfx950", "c3_strict": r"vsom_update_std_rd14_gfx950",
-          "c2": r"vsom_update_fma_rd14_gfx950", "c4": r"update_chain_kernel", "c5": r"vsom_update_clr_rp8_gfx950",
-          "online": r"online_window_kernel"}
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r3"
+# key = "<bench.py --config>_<--arith>" (what bench.py looks up); value = (summary tag, dominant kernel)
+KERNEL = {"c3_strict": ("c3", r"vsom_update_std_rd14_gfx950"), "c3_sigma": ("c3_sigma", r"vsom_update_sfma_rd14_gfx950"),
+          "c3_contracted": ("c3_contracted", r"vsom_update_fma_rd14_gfx950"),
+          "c2_strict": ("c2", r"vsom_update_std_rd14_gfx950"), "c4_strict": ("c4", r"update_chain3_kernel"),
+          "c5_strict": ("c5", r"vsom_update_clr_rp8_gfx950"), "online_strict": ("online", r"online_window_kernel")}
 
 
 def counters(path, kernel):
@@ -31,8 +34,8 @@ def counters(path, kernel):
 
 
 out = {"_doc": __doc__.strip().replace("\n", " ")}
-for cfg, kern in KERNEL.items():
-    p = os.path.join(PROF, f"r2_{cfg}_pmc.txt")
+for cfg, (tag, kern) in KERNEL.items():
+    p = os.path.join(PROF, f"{ROUND}_{tag}_pmc.txt")
     if not os.path.exists(p):
         continue
     v = counters(p, kern)
@@ -40,7 +43,7 @@ for cfg, kern in KERNEL.items():
         continue
     ent = {"kernel": kern, "fetch_size_kib": v["FETCH_SIZE"], "write_size_kib": v["WRITE_SIZE"],
            "hbm_bytes_per_launch": int(round((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0)),
-           "source": f"profiles/r2_{cfg}_pmc.txt, separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE"}
+           "source": f"profiles/{ROUND}_{tag}_pmc.txt, separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE"}
     if "TCC_HIT" in v and "TCC_MISS" in v:
         ent["l2_hit_rate"] = round(v["TCC_HIT"] / (v["TCC_HIT"] + v["TCC_MISS"]), 4)
     out[cfg] = ent

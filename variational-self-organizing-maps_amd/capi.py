@@ -24,7 +24,7 @@ TIMER_NAMES = ["stage", "bmu", "finish", "cw", "update", "online", "sigma"]
 # every symbol include/vsom_hip.h declares (tests/test_capi_symbols.py checks the header too)
 SYMBOLS = [
     "vsom_last_error", "vsom_device_count", "vsom_create", "vsom_destroy", "vsom_set_stream",
-    "vsom_synchronize", "vsom_set_bmu_mode", "vsom_set_update_mode", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
+    "vsom_synchronize", "vsom_set_bmu_mode", "vsom_set_update_mode", "vsom_set_column_compaction", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
     "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_host_alloc", "vsom_host_free",
     "vsom_prefetch_chunk", "vsom_prefetch_wait", "vsom_commit_chunk", "vsom_get_last_bmu",
     "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_find_bmu", "vsom_bmu_local_batch",
@@ -84,6 +84,7 @@ def lib():
     L.vsom_synchronize.argtypes = [vp]
     L.vsom_set_bmu_mode.argtypes = [vp, C.c_int]
     L.vsom_set_update_mode.argtypes = [vp, C.c_int]
+    L.vsom_set_column_compaction.argtypes = [vp, C.c_long]
     L.vsom_get_shortlist_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
     for name in ("vsom_depth", "vsom_nodes", "vsom_residual_len", "vsom_pitch", "vsom_chunk_pitch"):
         getattr(L, name).argtypes = [vp]
@@ -243,6 +244,10 @@ class Context:
 
     def set_update_mode(self, mode):
         check(lib().vsom_set_update_mode(self._h, int(mode)))
+
+    def set_column_compaction(self, min_rows):
+        """chunks of at least min_rows rows retire their all-zero columns (default 1024; < 0: off)"""
+        check(lib().vsom_set_column_compaction(self._h, int(min_rows)))
 
     def shortlist_stats(self):
         out = (C.c_uint32 * 4)()

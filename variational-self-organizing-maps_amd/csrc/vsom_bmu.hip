@@ -408,13 +408,22 @@ int launch_bmu_full(vsom_ctx *c, size_t s0, size_t s1)
         // had to be redone exactly the shortlist does not pay on this map -- skip it for a while
         if (c->sl_fb) {
             volatile unsigned *fb = c->sl_fb;
-            unsigned redo = fb[0], rows = fb[2];
+            unsigned redo = fb[0], rows = fb[2], seq = fb[3];
+            if (seq != c->sl_seq_seen) {             // the verdict of a shortlist search not looked at yet
+                c->sl_seq_seen = seq;
+                if (rows > 0 && redo * 4u > rows) {
+                    // a map on which the shortlist does not prune tends to stay that way (C5: after a batch epoch
+                    // on strongly correlated data every node is a candidate for every sample, epoch after epoch):
+                    // pause for 8 searches, and twice as long after every further failed probe (up to 128) -- a
+                    // failed probe costs the contraction AND the exact search (C5: 0.65 + 1.35 ms)
+                    c->sl_skip = 8 << (c->sl_fail_streak < 4 ? c->sl_fail_streak : 4);
+                    ++c->sl_fail_streak;
+                } else {
+                    c->sl_fail_streak = 0;
+                }
+            }
             if (c->sl_skip > 0) {
                 --c->sl_skip;
-                want = false;
-            } else if (rows > 0 && redo * 4u > rows) {
-                c->sl_skip = 8;
-                fb[0] = 0;   // re-probe after the pause
                 want = false;
             }
         }

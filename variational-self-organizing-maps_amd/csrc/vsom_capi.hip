@@ -355,6 +355,15 @@ int vsom_get_shortlist_stats(vsom_ctx *c, uint32_t *out)
     return VSOM_OK;
 }
 
+int vsom_set_column_compaction(vsom_ctx *c, long min_rows)
+{
+    if (!c)
+        return vsom_fail(VSOM_ERR_INVALID, "null context");
+    c->cc_min_rows = min_rows;
+    c->cc_skip = 0;
+    return VSOM_OK;
+}
+
 int vsom_set_update_mode(vsom_ctx *c, int mode)
 {
     if (!c || (mode != VSOM_UPDATE_STRICT && mode != VSOM_UPDATE_FMA && mode != VSOM_UPDATE_FMA_SIGMA))

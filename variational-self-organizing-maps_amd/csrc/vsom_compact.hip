@@ -193,12 +193,15 @@ static int cc_ensure(vsom_ctx *c)
 int vsom_cc_stage(vsom_ctx *c)
 {
     c->cc_valid = false;
-    if (!vsom_cc_applies(c) || c->B == 0)
+    // small chunks: the passes (and the model-row gather / expansion around them) cost more than a few retired
+    // slices of a short chain save; vsom_set_column_compaction moves the threshold
+    if (!vsom_cc_applies(c) || c->B == 0 || c->cc_min_rows < 0 || (long)c->B < c->cc_min_rows)
         return VSOM_OK;
     // feedback of earlier chunks (pinned memory, read without synchronising: stale values only delay the decision)
-    if (c->cc_fb && c->cc_fb[1] != c->cc_seen) {
-        c->cc_seen = c->cc_fb[1];
-        const unsigned kc = c->cc_fb[0];
+    volatile unsigned *fb = c->cc_fb;
+    if (fb && fb[1] != c->cc_seen) {
+        c->cc_seen = fb[1];
+        const unsigned kc = fb[0];
         if (kc + 14 > c->D)          // not even one 14-dim slice to retire
             c->cc_skip = 8;
     }

@@ -89,6 +89,8 @@ struct vsom_ctx {
     float *sl_fs = nullptr, *sl_fm = nullptr;      // CLR shortlist: sample / node feature rows (vsom_shortlist.hip)
     size_t sl_fs_cap = 0, sl_fm_cap = 0;           // bytes
     int sl_skip = 0;
+    unsigned sl_seq_seen = 0;       // feedback sequence number already acted on
+    int sl_fail_streak = 0;         // consecutive probes that had to redo most samples exactly
 
     // neighbourhood
     float2 *cw = nullptr; size_t cw_cap = 0;
@@ -114,6 +116,7 @@ struct vsom_ctx {
     unsigned *cc_fb = nullptr;      // pinned host mirror: {live columns, seq}
     unsigned cc_seen = 0;
     int cc_skip = 0;
+    long cc_min_rows = 1024;        // chunks with fewer rows are not compacted (< 0: never)
     bool cc_valid = false;          // the staged chunk has a compaction (Xc, cc_idx, cc_meta describe it)
     uint32_t cpitch = 0;            // row pitch of the compacted matrices
     float *Xc = nullptr; size_t Xc_cap = 0;      // (Bcap + VSOM_ROW_PAD) x cpitch

@@ -692,6 +692,60 @@ __global__ __launch_bounds__(256, 1) void update_chain2_kernel(const float *__re
     }
 }
 
+// StandardMedianEstimator steps of EIGHT consecutive samples for one lane's packed (dim, dim+1) chains, as one
+// hand-scheduled block (update_chain3_kernel runs ONE wavefront per SIMD, where a single wavefront issues an
+// instruction every ~5.3 cycles and a dependent one after ~10 -- tools/exp/pk_latency_bench.hip -- so what counts is
+// the depth of the per-sample dependency chain and having no bubbles in it; hipcc's version of this loop carried
+// a 5-deep chain plus s_nop / v_mov padding around the clamp instructions: ~72 cycles per sample).
+// Per sample (Transformation.cpp:50, Som.cpp:861-867):   s = sign(x - M) ; M = M + c*s ; S = S + (w*s)*s.
+//   t  = fma(M, -2^24, x*2^24)          the sign of t IS the sign of x - M: the scaling by 2^24 is exact, the fused
+//                                       difference rounds once and never to zero (|x - M| >= 2^-149 -> |t| >= 2^-125),
+//                                       NaN stays NaN, +-inf keeps its sign; x*2^24 is computed off the chain (by the
+//                                       pass that stages the block in LDS) and may overflow to +-inf
+//                                       only for |x| >= 2^104, where sign(x - M) = sign(x) because the median walk
+//                                       keeps |M| <= sum of c <= B; M*2^24 cannot overflow for the same reason
+//   p  = clamp(t * 2^127), n = clamp(-t * 2^127)     [t > 0], [t < 0] as 1.0 / 0.0 (DX10_CLAMP off: NaN passes)
+//   M  = fma(c, p, M) ; M = fma(-c, n, M) ; S = fma(w, p, S) ; S = fma(w, n, S)
+//                                       exact products, one of p / n is zero: every fma rounds where the reference's
+//                                       separate multiply and add round (gen_update_asm.py, compute_median)
+// -> a 4-deep chain (t, p|n, M, M) with the three other operations in its shadows: 7 instructions per sample.
+// cwK = {c, w} of sample K (op_sel picks the half), xK the sample's two values times 2^24.
+#define VSOM_MED_STEP(XS, CW)                                                                    \
+    "v_pk_fma_f32 %[t], %[M], %[k24], " XS " neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"                   \
+    "v_pk_mul_f32 %[p], %[t], %[k127] clamp\n\t"                                                  \
+    "v_pk_mul_f32 %[n], %[t], %[k127] neg_lo:[1,0] neg_hi:[1,0] clamp\n\t"                        \
+    "v_pk_fma_f32 %[M], " CW ", %[p], %[M] op_sel_hi:[0,1,1]\n\t"                                 \
+    "v_pk_fma_f32 %[S], " CW ", %[p], %[S] op_sel:[1,0,0]\n\t"                                    \
+    "v_pk_fma_f32 %[M], " CW ", %[n], %[M] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"   \
+    "v_pk_fma_f32 %[S], " CW ", %[n], %[S] op_sel:[1,0,0]\n\t"
+
+// xs[] = the samples' values ALREADY scaled by 2^24 (the staging pass of update_chain3_kernel multiplies once per
+// value and workgroup instead of once per value and node row)
+__device__ __forceinline__ void vsom_median_steps8(vsom_f2 &M, vsom_f2 &S, const vsom_f2 (&xs)[8], const float4 (&cv)[4])
+{
+    const vsom_f2 k24 = {0x1.0p24f, 0x1.0p24f}, k127 = {0x1.0p127f, 0x1.0p127f};
+    const vsom_f2 c0 = {cv[0].x, cv[0].y}, c1 = {cv[0].z, cv[0].w}, c2 = {cv[1].x, cv[1].y}, c3 = {cv[1].z, cv[1].w},
+                  c4 = {cv[2].x, cv[2].y}, c5 = {cv[2].z, cv[2].w}, c6 = {cv[3].x, cv[3].y}, c7 = {cv[3].z, cv[3].w};
+    vsom_f2 t, p, n;
+    asm volatile(VSOM_MED_STEP("%[x0]", "%[c0]") VSOM_MED_STEP("%[x1]", "%[c1]") VSOM_MED_STEP("%[x2]", "%[c2]")
+                 VSOM_MED_STEP("%[x3]", "%[c3]") VSOM_MED_STEP("%[x4]", "%[c4]") VSOM_MED_STEP("%[x5]", "%[c5]")
+                 VSOM_MED_STEP("%[x6]", "%[c6]") VSOM_MED_STEP("%[x7]", "%[c7]")
+                 : [M] "+v"(M), [S] "+v"(S), [t] "=&v"(t), [p] "=&v"(p), [n] "=&v"(n)
+                 : [x0] "v"(xs[0]), [x1] "v"(xs[1]), [x2] "v"(xs[2]), [x3] "v"(xs[3]), [x4] "v"(xs[4]), [x5] "v"(xs[5]),
+                   [x6] "v"(xs[6]), [x7] "v"(xs[7]), [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [c3] "v"(c3), [c4] "v"(c4),
+                   [c5] "v"(c5), [c6] "v"(c6), [c7] "v"(c7), [k24] "s"(k24), [k127] "s"(k127));
+}
+
+// one sample of the same (chunk tails)
+__device__ __forceinline__ void vsom_median_step1(vsom_f2 &M, vsom_f2 &S, vsom_f2 xs, vsom_f2 cw)
+{
+    const vsom_f2 k24 = {0x1.0p24f, 0x1.0p24f}, k127 = {0x1.0p127f, 0x1.0p127f};
+    vsom_f2 t, p, n;
+    asm volatile(VSOM_MED_STEP("%[x0]", "%[c0]")
+                 : [M] "+v"(M), [S] "+v"(S), [t] "=&v"(t), [p] "=&v"(p), [n] "=&v"(n)
+                 : [x0] "v"(xs), [c0] "v"(cw), [k24] "s"(k24), [k127] "s"(k127));
+}
+
 // update_chain2_kernel with the operands staged ONCE per workgroup through LDS.  In chain2 every wavefront
 // issues, per sample, a 512-byte x load and half a 1-KB (c,w) load whose lanes mostly repeat addresses --
 // the vector-memory pipe processes every lane's address and return slot, and that, not arithmetic, bounded
@@ -743,6 +797,12 @@ __global__ __launch_bounds__(256, 1) void update_chain3_kernel(const float *__re
     };
     auto store_x = [&](int slot, int i, float4 v) {
         const int piece = tid + 256 * i;
+        if (MEDIAN) {   // the Median chains consume x * 2^24 (vsom_median_steps8): scaled once here, exactly
+            v.x = v.x * 0x1.0p24f;
+            v.y = v.y * 0x1.0p24f;
+            v.z = v.z * 0x1.0p24f;
+            v.w = v.w * 0x1.0p24f;
+        }
         *reinterpret_cast<float4 *>(&xs[slot][piece / (PL / 2)][4 * (piece % (PL / 2))]) = v;
     };
     auto store_c = [&](int slot, int i, float4 v) {
@@ -773,17 +833,11 @@ __global__ __launch_bounds__(256, 1) void update_chain3_kernel(const float *__re
     } while (0)
 
     vsom_f2 M = {0.f, 0.f}, S = {0.f, 0.f};               // :843-844
-    const vsom_f2 big = {0x1.0p100f, 0x1.0p100f};
-    auto one = [&](vsom_f2 xv, float c, float w) {        // the same operations as update_chain2_kernel's
-        const vsom_f2 cc = {c, c}, ww = {w, w};
+    auto one = [&](vsom_f2 xv, float c, float w) {        // Standard; the same operations as update_chain2_kernel's
+        const vsom_f2 cc = {c, c}, ww = {w, w};           // (Median: vsom_median_steps8 / vsom_median_step1 on x * 2^24)
         vsom_f2 dl = xv - M;
         if (MEDIAN) {
-            const vsom_f2 t = dl * big;
-            const vsom_f2 pp = vsom_pk_mul_clamp(t, big), nn = vsom_pk_mul_negclamp(t, big);
-            M = __builtin_elementwise_fma(cc, pp, M);
-            M = __builtin_elementwise_fma(-cc, nn, M);
-            S = __builtin_elementwise_fma(ww, pp, S);
-            S = __builtin_elementwise_fma(ww, nn, S);
+            __builtin_trap();                             // never called: xs holds scaled values
         } else if (FMA == 1) {
             M = __builtin_elementwise_fma(cc, dl, M);
             S = __builtin_elementwise_fma(ww * dl, dl, S);
@@ -825,6 +879,10 @@ __global__ __launch_bounds__(256, 1) void update_chain3_kernel(const float *__re
             cv[u] = cs[slot][(t >> 1) + u][lnode];
     };
     auto steps = [&](const vsom_f2 (&xv)[U], const float4 (&cv)[U / 2]) {
+        if (MEDIAN) {
+            vsom_median_steps8(M, S, xv, cv);              // hand-scheduled: 4-deep chain, 8 instructions per sample
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u)
             one(xv[u], (u & 1) ? cv[u >> 1].z : cv[u >> 1].x, (u & 1) ? cv[u >> 1].w : cv[u >> 1].y);
@@ -853,7 +911,13 @@ __global__ __launch_bounds__(256, 1) void update_chain3_kernel(const float *__re
             }
             for (; t < nt; ++t) {
                 const float4 cv = cs[slot][t >> 1][lnode];
-                one(*reinterpret_cast<const vsom_f2 *>(&xs[slot][t][2 * lp]), (t & 1) ? cv.z : cv.x, (t & 1) ? cv.w : cv.y);
+                const vsom_f2 xv = *reinterpret_cast<const vsom_f2 *>(&xs[slot][t][2 * lp]);
+                if (MEDIAN) {
+                    const vsom_f2 cw1 = {(t & 1) ? cv.z : cv.x, (t & 1) ? cv.w : cv.y};
+                    vsom_median_step1(M, S, xv, cw1);
+                } else {
+                    one(xv, (t & 1) ? cv.z : cv.x, (t & 1) ? cv.w : cv.y);
+                }
             }
         }
         VSOM_C3_STORE((blk + 2) % 3);                     // slot (blk+2)%3 was last read in iteration blk-1
