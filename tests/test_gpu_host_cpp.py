@@ -264,3 +264,17 @@ def test_next_rows_restricted_bmu_bmd_umatrix_evaluate(dumps):
     oc.sigma[...] = (0.25 + 0.01 * (np.arange(20 * 12) % 7)).astype(np.float32).reshape(20, 12)
     umc = np.fromfile(os.path.join(d, "umatrix_clr.bin"), np.float64)
     assert (umc == oc.update_umatrix()).all()
+
+
+def test_umatrix_after_every_epoch_matches_the_final_state(dumps):
+    """train(..., BatchMap, updateUMatrixAfterEpoch = true) (Som.cpp:751-752): the U-matrix left behind is that of
+    the last epoch's map and sigmaMap -- also under a group, whose deferred sigmaMap gather updateUMatrix has
+    to join first (r2 advisor finding)"""
+    d, _, _ = dumps
+    rows = make_rows(50, 9, 12345)
+    o = po.OracleSom(10, 10, 9)
+    o.random_initialize(33, 1.0)
+    o.train_batch(rows, [0, 20, 40, 50], 3, 5.0, 0.2, nthreads=2)
+    check_state(read_dump(os.path.join(d, "umatrix_after_epoch_state.bin")), o)
+    um = np.fromfile(os.path.join(d, "umatrix_after_epoch.bin"), np.float64)
+    assert (um == o.update_umatrix()).all()

@@ -280,6 +280,19 @@ int main(int argc, char **argv)
         std::ofstream fc(out + "/umatrix_clr.bin", std::ios::binary);
         fc.write((const char *)umc.data(), umc.size() * 8);
     }
+    // ---- updateUMatrixAfterEpoch (Som.cpp:751-752): the U-matrix of the LAST epoch's map.  Under a group the
+    //      sigmaMap rows of the other shards arrive on a second stream: updateUMatrix must join them first ----
+    {
+        ArrayDataLoader loader(rows.data(), NROWS, J, CHUNK);
+        DataSet ds(loader);
+        Som som{W, H, ds, Transformation::Standard(loader.getNames())};
+        som.randomInitialize(33, 1);
+        som.train(ds, 3, 0.0, 0.0, 5.0, 0.2, Som::WeigthDecayFunction::BatchMap, true);
+        auto um = som.getUMatrix().getData();
+        std::ofstream fu(out + "/umatrix_after_epoch.bin", std::ios::binary);
+        fu.write((const char *)um.data(), um.size() * 8);
+        dump(out + "/umatrix_after_epoch_state.bin", som, {});
+    }
     // ---- a custom std::function transformation cannot run on the device: that Som lives on the host
     //      (src/vsom_custom.cpp; CPU test tests/test_host_custom.py), consumers outside training included ----
     {
