@@ -128,7 +128,12 @@ def test_random_shape_assembly_update(name, W, H, J, B, sigma, seed, tr):
         X[rs.rand(B, J) < 0.002] = -np.inf
         X[rs.rand(B, J) < 0.002] = np.nan
         init[rs.rand(*init.shape) < 0.05] = 0.0
+    # columns that are zero in EVERY row (two cases in three): the library retires their chains and their share of
+    # the search's contraction exactly (csrc/vsom_compact.hip; threshold lowered to 1 row: these chunks are short)
+    frac = [0.0, 0.25, 0.6][seed % 3]
+    X[:, rs.rand(J) < frac] = 0.0
     ctx = vsom_amd.Context(W, H, J, tr)
+    ctx.set_column_compaction(1)
     orc = po.OracleSom(W, H, J, tr)
     ctx.set_state(map=init)
     orc.set_state(map=init)

@@ -82,3 +82,29 @@ def test_neighbourhood_table_symmetry():
             a = po.neighbourhood_weight(cx, cy, bx, by, s)
             b = po.neighbourhood_weight(abs(cx - bx), abs(cy - by), 0, 0, s)
             assert a == b
+
+
+def test_mnist_like_statistics_and_idx_reader(tmp_path):
+    """tests/gen.py: the MNIST-like generator has MNIST's first-order statistics and column occupancy (what
+    bench.py's `column_occupancy` reports and the dead-column retirement of csrc/vsom_compact.hip feeds on), and
+    the IDX reader (bench.py with VSOM_MNIST_DIR) parses the big-endian headers of mnist_reader_common.hpp:24-78"""
+    import gen
+    X = gen.mnist_like(4096, 3, 784)
+    live, cols = gen.column_occupancy(X)
+    assert cols == 784 and 600 <= live <= 720                 # real MNIST: 717 of 784 over 60000 images
+    assert 0.15 < float((X > 0).mean()) < 0.23 and 28.0 < float(X.mean()) < 38.0
+    assert X.min() == 0.0 and X.max() <= 255.0 and (X == np.floor(X)).all()
+    assert gen.column_occupancy(gen.mnist_like_window(512, 3, 784))[0] <= 400
+    Y = gen.mnist_like(50, 3, 794)
+    assert Y.shape == (50, 794) and (Y[:, 784:].sum(axis=1) == 1).all()
+    # IDX files
+    imgs = (np.random.RandomState(0).rand(100, 784) * 255).astype(np.uint8)
+    labs = (np.arange(100) % 10).astype(np.uint8)
+    with open(tmp_path / "train-images-idx3-ubyte", "wb") as f:
+        f.write((0x803).to_bytes(4, "big") + (100).to_bytes(4, "big") + (28).to_bytes(4, "big") + (28).to_bytes(4, "big") + imgs.tobytes())
+    with open(tmp_path / "train-labels-idx1-ubyte", "wb") as f:
+        f.write((0x801).to_bytes(4, "big") + (100).to_bytes(4, "big") + labs.tobytes())
+    x = gen.mnist_idx(str(tmp_path), 10, 95, 794)
+    assert x.shape == (10, 794) and (x[:, :784] == imgs[(95 + np.arange(10)) % 100]).all()
+    assert (x[:, 784:].argmax(axis=1) == labs[(95 + np.arange(10)) % 100]).all()
+    assert gen.mnist_idx(str(tmp_path / "nowhere"), 10) is None

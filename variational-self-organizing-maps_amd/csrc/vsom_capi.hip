@@ -244,6 +244,8 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
         c->cw_mode = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);
     if (const char *e = std::getenv("VSOM_NO_TINY"))
         c->use_tiny = !(e[0] == '1');
+    if (const char *e = std::getenv("VSOM_COMPACT_MIN_ROWS"))     // development: initial vsom_set_column_compaction
+        c->cc_min_rows = std::atol(e);
     if (const char *e = std::getenv("VSOM_NO_CHAIN"))
         c->use_chain = !(e[0] == '1');  // debugging aid: lane = node update kernel on small maps too
 
