@@ -151,6 +151,35 @@ def test_default_threshold_and_switch():
         ctx.close()
 
 
+@pytest.mark.parametrize("mode", [capi.UPDATE_STRICT, capi.UPDATE_FMA_SIGMA, capi.UPDATE_FMA], ids=["strict", "sigma", "contracted"])
+def test_zero_slice_form_is_exact_in_every_arithmetic(mode):
+    """42 % of the (sample, 14-column slice) blocks of an MNIST-like chunk's live columns are all zero; the chain
+    kernels then take a form without the subtraction (delta = -M; gen_update_asm.py, compute_zero_x).  It is exact
+    in each of the three arithmetics: with the passes on (mask present) and off (plain kernels) the same mode
+    gives the same bits -- and strict equals the oracle (the other tests of this file)."""
+    W = H = 48
+    X = gen.mnist_like(2000, 6, 784)
+    X[7] = 0.0
+    X[100:140, :] = 0.0                                     # a run of all-zero samples
+    X[300, 200:260] = -0.0
+    init = gen.random_map(W * H, 784, 42) * np.float32(100)
+    out = []
+    for setting in (1, -1):
+        ctx = vsom_amd.Context(W, H, 784, po.STANDARD)
+        ctx.set_column_compaction(setting)
+        ctx.set_update_mode(mode)
+        ctx.set_state(map=init)
+        for first, Xc in ((True, X), (False, X[:1037]), (True, X[5:1994])):      # tails of 5 and 5 samples too
+            ctx.upload_chunk(Xc)
+            ctx.batch_epoch(7.0, first)
+        out.append((ctx.get_state(S=False), ctx.get_last_bmu()))
+        ctx.close()
+    (a, la), (b, lb) = out
+    assert _same(la, lb)
+    for k in ("map", "sigma", "weight", "hits"):
+        assert _same(a[k], b[k]), k
+
+
 def test_group_of_three_on_data_with_dead_columns():
     """node shards: every member runs the compacted chains on its third of the nodes"""
     W, H, J, B = 48, 45, 784, 240

@@ -90,6 +90,46 @@ __global__ __launch_bounds__(1024) void cc_scan_kernel(const unsigned *__restric
     }
 }
 
+// Zero-slice mask for the strict chain kernels' fast path (gen_update_asm.py, compute_zero_x): bit j of word
+// zmask[q * ldz + i] says that the 14 values of slice q (compacted columns [14 q, 14 q + 14)) of sample 32 i + j
+// are all zero (+0 or -0; NaN / inf / anything else is not).  One workgroup = 32 rows x CC_ZQ slices: a thread
+// tests one (row, slice) block -- 56 contiguous, 8-byte aligned bytes; consecutive threads read consecutive
+// slices of a row -- and thread q then assembles the 32-sample word of its slice.  Words past the chunk stay
+// zero (the kernels read two words ahead).
+#define CC_ZQ 16
+__global__ __launch_bounds__(256) void cc_zmask_kernel(const float *__restrict__ xc, int ldc, int B, int nslices_max,
+                                                       const unsigned *__restrict__ meta, unsigned *__restrict__ zmask, int ldz)
+{
+    __shared__ unsigned char zero[32][CC_ZQ];
+    const int nsl = (int)meta[1] < nslices_max ? (int)meta[1] : nslices_max;
+    const int q0 = blockIdx.y * CC_ZQ, r0 = blockIdx.x * 32;
+    if (q0 >= nsl)
+        return;                                            // block-uniform
+    for (int t = threadIdx.x; t < 32 * CC_ZQ; t += 256) {
+        const int rr = t / CC_ZQ, q = q0 + t % CC_ZQ, r = r0 + rr;
+        bool z = false;
+        if (r < B && q < nsl) {
+            const float2 *p = reinterpret_cast<const float2 *>(xc + (size_t)r * ldc + 14 * q);
+            float2 v[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                v[u] = p[u];
+            z = true;
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+                z = z && (v[u].x == 0.f) && (v[u].y == 0.f);
+        }
+        zero[rr][t % CC_ZQ] = z ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < CC_ZQ && q0 + (int)threadIdx.x < nsl) {
+        unsigned word = 0u;
+        for (int j = 0; j < 32; ++j)
+            word |= (unsigned)zero[j][threadIdx.x] << j;
+        zmask[(size_t)(q0 + threadIdx.x) * ldz + blockIdx.x] = word;
+    }
+}
+
 // dst[row][k] = src[row][idx[k]] for k < Kc, 0 up to the pitch: one workgroup per row
 __global__ __launch_bounds__(256) void cc_gather_rows_kernel(const float *__restrict__ src, int lds_, float *__restrict__ dst,
                                                              int ldd, const int *__restrict__ idx, int nrows)
@@ -149,6 +189,16 @@ static bool cc_env_enabled()
     return v != 0;
 }
 
+static bool cc_zero_path_enabled()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = std::getenv("VSOM_NO_ZERO_PATH");     // development: time the chains without the fast path
+        v = (e && e[0] == '1') ? 0 : 1;
+    }
+    return v != 0;
+}
+
 // whether this context's shapes can use the compaction at all
 bool vsom_cc_applies(const vsom_ctx *c)
 {
@@ -193,6 +243,7 @@ static int cc_ensure(vsom_ctx *c)
 int vsom_cc_stage(vsom_ctx *c)
 {
     c->cc_valid = false;
+    c->cc_zmask_valid = false;
     // small chunks: the passes (and the model-row gather / expansion around them) cost more than a few retired
     // slices of a short chain save; vsom_set_column_compaction moves the threshold
     if (!vsom_cc_applies(c) || c->B == 0 || c->cc_min_rows < 0 || (long)c->B < c->cc_min_rows)
@@ -219,8 +270,37 @@ int vsom_cc_stage(vsom_ctx *c)
                        c->cc_inv, c->cc_meta, c->cc_fb);
     hipLaunchKernelGGL(cc_gather_rows_kernel, dim3((unsigned)c->B), dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->Xc,
                        (int)c->cpitch, c->cc_idx, (int)c->B);
+    c->cc_zmask_valid = false;        // built on demand by vsom_cc_ensure_zmask
     VSOM_HIP_CHECK(hipGetLastError());
     c->cc_valid = true;
+    return VSOM_OK;
+}
+
+// zero-slice mask of the gathered chunk, built once per chunk when a strict Standard phase 2 asks for it (the
+// sigma-contracted and contracted chains are one instruction shorter already and measured no gain from the
+// branch: update at C3 3.99 -> 4.02 and 3.39 -> 3.55 ms; strict 4.82 -> 4.59 ms)
+int vsom_cc_ensure_zmask(vsom_ctx *c)
+{
+    if (c->cc_zmask_valid)
+        return VSOM_OK;
+    if (!c->cc_valid || !cc_zero_path_enabled())
+        return VSOM_OK;
+    const size_t nslm = (c->D + 13) / 14, ldz = (c->B + 31) / 32 + 2, need = nslm * ldz;
+    if (need > c->cc_zmask_cap) {
+        if (c->cc_zmask) {
+            VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+            VSOM_HIP_CHECK(hipFree(c->cc_zmask));
+        }
+        c->cc_zmask = nullptr;
+        c->cc_zmask_cap = 0;
+        VSOM_HIP_CHECK(hipMalloc(&c->cc_zmask, need * 4));
+        c->cc_zmask_cap = need;
+    }
+    VSOM_HIP_CHECK(hipMemsetAsync(c->cc_zmask, 0, need * 4, c->stream));
+    hipLaunchKernelGGL(cc_zmask_kernel, dim3((unsigned)((c->B + 31) / 32), (unsigned)((nslm + CC_ZQ - 1) / CC_ZQ)), dim3(256), 0,
+                       c->stream, c->Xc, (int)c->cpitch, (int)c->B, (int)nslm, c->cc_meta, c->cc_zmask, (int)ldz);
+    VSOM_HIP_CHECK(hipGetLastError());
+    c->cc_zmask_valid = true;
     return VSOM_OK;
 }
 

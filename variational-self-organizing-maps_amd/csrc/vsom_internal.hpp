@@ -122,6 +122,8 @@ struct vsom_ctx {
     float *Xc = nullptr; size_t Xc_cap = 0;      // (Bcap + VSOM_ROW_PAD) x cpitch
     float *Mc = nullptr;            // N x cpitch: model rows on the live columns (search)
     float *Uc_map = nullptr, *Uc_S = nullptr;    // N x cpitch: the chains' M and raw S on the live columns
+    unsigned *cc_zmask = nullptr; size_t cc_zmask_cap = 0;   // [slice][ceil(B/32)+2] all-zero (sample, slice) bits
+    bool cc_zmask_valid = false;
 
     // online path scratch
     float *v_dev = nullptr;         // one sample, padded
@@ -177,6 +179,7 @@ int ensure_lut(vsom_ctx *c, double sigma);
 bool vsom_cc_applies(const vsom_ctx *c);
 int vsom_cc_stage(vsom_ctx *c);
 int vsom_cc_gather_map(vsom_ctx *c);
+int vsom_cc_ensure_zmask(vsom_ctx *c);
 int vsom_cc_ensure_update_scratch(vsom_ctx *c);
 int vsom_cc_expand(vsom_ctx *c, size_t n0, size_t nloc);
 bool vsom_tiny_applies(const vsom_ctx *c);                        // vsom_tiny.hip

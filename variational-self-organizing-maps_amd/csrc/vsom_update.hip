@@ -1133,6 +1133,7 @@ struct UpdAsmArgs {
     void *sbuf;
     unsigned ldx_bytes, ldn_bytes, B, nloc, nslices, pitch_bytes, n0, ppitch_bytes;   // ppitch: CLR only
     const void *yp;                  // CLR: y' rows; Standard / Median: live-slice record of the compaction or null
+    const void *zmask;               // Standard family: all-zero (sample, slice) bit mask or null (kernarg 80 B)
 };
 
 int vsom_load_asm_module(vsom_ctx *c)
@@ -1140,6 +1141,9 @@ int vsom_load_asm_module(vsom_ctx *c)
     if (c->upd_module)
         return VSOM_OK;
     hipModule_t mod;
+    if (const char *alt = std::getenv("VSOM_ASM_HSACO")) {   // development: time a variant code object (tools/exp)
+        VSOM_HIP_CHECK(hipModuleLoad(&mod, alt));
+    } else
     VSOM_HIP_CHECK(hipModuleLoadData(&mod, vsom_update_hsaco));
     hipFunction_t f16, f14, m16, m14, fclr, d16, d14, sf16, sf14;
     VSOM_HIP_CHECK(hipModuleGetFunction(&f16, mod, "vsom_update_std_rd16_gfx950"));
@@ -1367,7 +1371,8 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     a.n0 = (unsigned)n0;
                     a.ppitch_bytes = c->part_pitch * 4u;
                     a.yp = c->YP;
-                    size_t sz = sizeof(a);
+                    a.zmask = nullptr;
+                    size_t sz = 72;          // kernarg segment of the CLR kernel
                     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
                                      HIP_LAUNCH_PARAM_END};
                     VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)c->upd_clr8, 8 * ((nfull + 3) / 4), (gx + 7) / 8, 1,
@@ -1470,6 +1475,10 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 const bool compact = c->cc_valid;
                 if (compact && (rc = vsom_cc_ensure_update_scratch(c)))
                     return rc;
+                // strict Standard chains: (sample, slice) blocks that are all zero take the 5-operation form
+                const bool zpath = compact && c->transform == VSOM_STANDARD && c->update_mode == VSOM_UPDATE_STRICT;
+                if (zpath && (rc = vsom_cc_ensure_zmask(c)))
+                    return rc;
                 auto launch = [&](void *fn, unsigned nsl, unsigned col0, hipStream_t st) -> int {
                     UpdAsmArgs a;
                     a.xs = compact ? c->Xc : c->Xs + col0;
@@ -1485,7 +1494,8 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     a.n0 = (unsigned)n0;
                     a.ppitch_bytes = 0;
                     a.yp = compact ? (const void *)c->cc_meta : nullptr;
-                    size_t sz = sizeof(a);   // 72 bytes
+                    a.zmask = zpath && c->cc_zmask_valid ? (const void *)c->cc_zmask : nullptr;
+                    size_t sz = med ? 72 : 80;   // kernarg segments of the Median / Standard-family kernels
                     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
                                      HIP_LAUNCH_PARAM_END};
                     // XCD-aware grid: x = 8 * slice quads, y = node groups / 8 (see gen_update_asm.py)
