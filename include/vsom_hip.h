@@ -76,8 +76,8 @@ typedef enum vsom_update_mode {
                                reference's trajectory within the first epochs (measured: profiles/
                                r3_fma_schedule.jsonl -- C3, 2 chunks: 5 of 8192 BMUs differ in epoch 0, 24 % by
                                epoch 9).  Use for single passes / throughput studies only.                  */
-    VSOM_UPDATE_FMA_SIGMA = 2 /* only the variance accumulation contracted: t = c*d, M = M + t as the reference
-                               rounds them, S = fma(w*d, d, S) (1/6 fewer VALU ops).  map is BIT-IDENTICAL, and so
+    VSOM_UPDATE_FMA_SIGMA = 2 /* only the variance accumulation (Som.cpp:867) contracted: t = c*d, M = M + t (Som.cpp:864)
+                               as the reference rounds them, S = fma(w*d, d, S) (1/6 fewer VALU ops).  map is BIT-IDENTICAL, and so
                                are lastBMU, bmuHits, MSE and weightMap of every later epoch of a schedule -- no
                                training step reads sigmaMap (Transformation.cpp:7-8,45-46,82: the built-in
                                Comparers ignore the dispersion); sigmaMap is a sum of non-negative terms and stays
@@ -126,7 +126,8 @@ int vsom_set_stream(vsom_ctx *ctx, void *hip_stream);
 int vsom_synchronize(vsom_ctx *ctx);
 int vsom_set_bmu_mode(vsom_ctx *ctx, int mode);
 int vsom_set_update_mode(vsom_ctx *ctx, int mode);
-/* Exact retirement of the sample columns that are zero in every row of a chunk (csrc/vsom_compact.hip: their
+/* [MI355X build; no counterpart in the reference, whose phase 2 walks every column: Som.cpp:840-875]
+ * Exact retirement of the sample columns that are zero in every row of a chunk (csrc/vsom_compact.hip: their
  * chains stay 0 -- or NaN for a node whose first weight is 0/0 -- and they add nothing to the search's
  * contraction; MNIST has ~120 such columns per 4096-image chunk).  Results are bit-identical with it on or off.
  * Chunks of at least min_rows rows use it (default 1024: below that the passes cost more than they save);
@@ -265,7 +266,7 @@ int vsom_group_upload_chunk(vsom_group *g, const float *x_host, size_t B);
 int vsom_group_prefetch_chunk(vsom_group *g, const float *x_host, size_t B);
 int vsom_group_prefetch_wait(vsom_group *g);
 int vsom_group_commit_chunk(vsom_group *g);
-/* the same for a chunk already resident in HBM: rows_dev[r] = member r's own rows [B*r/n, B*(r+1)/n) on ITS
+/* DataSet::loadNextDataFromStream (DataSet.cpp:118-160) for a chunk already resident in HBM: rows_dev[r] = member r's own rows [B*r/n, B*(r+1)/n) on ITS
  * device; all-gather of the rows, staging, lastBMU := 0 -- asynchronous on the members' streams */
 int vsom_group_set_chunk_device(vsom_group *g, const void *const *rows_dev /*[n]*/, size_t B);
 int vsom_group_set_last_bmu(vsom_group *g, const uint64_t *in_host);
