@@ -1499,8 +1499,15 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
                                      HIP_LAUNCH_PARAM_END};
                     // XCD-aware grid: x = 8 * slice quads, y = node groups / 8 (see gen_update_asm.py)
+                    // development: VSOM_UPD_WG_CAP=k reserves (unused) LDS so that a CU holds at most k workgroups
+                    static int wg_cap = -1;
+                    if (wg_cap < 0) {
+                        const char *e = std::getenv("VSOM_UPD_WG_CAP");
+                        wg_cap = e ? std::atoi(e) : 0;
+                    }
+                    const unsigned lds_reserve = wg_cap > 0 ? (unsigned)((160 * 1024 / wg_cap) & ~1023) : 0u;
                     VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, 8 * ((nsl + 3) / 4), (gx + 7) / 8, 1, 256, 1,
-                                                         1, 0, st, nullptr, extra));
+                                                         1, lds_reserve, st, nullptr, extra));
                     return VSOM_OK;
                 };
                 if (compact) {
