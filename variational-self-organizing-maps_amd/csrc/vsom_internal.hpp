@@ -101,7 +101,7 @@ struct vsom_ctx {
 
     // hand-scheduled update kernel (code object loaded with hipModuleLoadData)
     void *upd_module = nullptr, *upd_fn16 = nullptr, *upd_fn14 = nullptr, *upd_fma16 = nullptr, *upd_fma14 = nullptr,
-         *upd_clr8 = nullptr, *upd_med16 = nullptr, *upd_med14 = nullptr, *upd_sfma16 = nullptr, *upd_sfma14 = nullptr;
+         *upd_clr8 = nullptr, *upd_med16 = nullptr, *upd_med14 = nullptr, *upd_sfma16 = nullptr, *upd_sfma14 = nullptr, *upd_lds14[4] = {nullptr, nullptr, nullptr, nullptr}, *upd_lds16[4] = {nullptr, nullptr, nullptr, nullptr};
     int update_mode = VSOM_UPDATE_STRICT;
     bool use_asm = true;
     bool use_chain = true;

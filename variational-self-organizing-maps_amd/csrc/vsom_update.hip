@@ -1126,6 +1126,8 @@ static void vsom_update_split(unsigned D, unsigned limit, unsigned &n16, unsigne
         n16 = s16;
 }
 
+#define VSOM_UPD_LDS_DEFAULT 1
+
 struct UpdAsmArgs {
     const void *xs;
     const void *cw2;
@@ -1145,13 +1147,20 @@ int vsom_load_asm_module(vsom_ctx *c)
         VSOM_HIP_CHECK(hipModuleLoad(&mod, alt));
     } else
     VSOM_HIP_CHECK(hipModuleLoadData(&mod, vsom_update_hsaco));
-    hipFunction_t f16, f14, m16, m14, fclr, d16, d14, sf16, sf14;
+    hipFunction_t f16, f14, m16, m14, fclr, d16, d14, sf16, sf14, l14[4], l16[4];
     VSOM_HIP_CHECK(hipModuleGetFunction(&f16, mod, "vsom_update_std_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&f14, mod, "vsom_update_std_rd14_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&m16, mod, "vsom_update_fma_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&m14, mod, "vsom_update_fma_rd14_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&sf16, mod, "vsom_update_sfma_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&sf14, mod, "vsom_update_sfma_rd14_gfx950"));
+    static const char *const lds_names[4] = {"std", "fma", "sfma", "med"};
+    for (int i = 0; i < 4; ++i) {
+        const std::string n14 = std::string("vsom_update_") + lds_names[i] + "_rd14_lds_gfx950",
+                          n16 = std::string("vsom_update_") + lds_names[i] + "_rd16_lds_gfx950";
+        VSOM_HIP_CHECK(hipModuleGetFunction(&l14[i], mod, n14.c_str()));
+        VSOM_HIP_CHECK(hipModuleGetFunction(&l16[i], mod, n16.c_str()));
+    }
     VSOM_HIP_CHECK(hipModuleGetFunction(&fclr, mod, "vsom_update_clr_rp8_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&d16, mod, "vsom_update_med_rd16_gfx950"));
     VSOM_HIP_CHECK(hipModuleGetFunction(&d14, mod, "vsom_update_med_rd14_gfx950"));
@@ -1162,6 +1171,10 @@ int vsom_load_asm_module(vsom_ctx *c)
     c->upd_fma14 = m14;
     c->upd_sfma16 = sf16;
     c->upd_sfma14 = sf14;
+    for (int i = 0; i < 4; ++i) {
+        c->upd_lds14[i] = l14[i];
+        c->upd_lds16[i] = l16[i];
+    }
     c->upd_clr8 = fclr;
     c->upd_med16 = d16;
     c->upd_med14 = d14;
@@ -1282,7 +1295,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
     const size_t nloc = n1 - n0;
     const size_t ldn = (nloc + 63) / 64 * 64;
     // pair rows: ceil(B/2) + the prefetch ring of the assembly kernel (4) + slack
-    const size_t prow = (c->B + 1) / 2 + 8;
+    const size_t prow = (c->B + 1) / 2 + 24;   // (the LDS-sharing kernels fetch three groups of four pair-rows ahead)
     const size_t need = prow * ldn * 2;   // float2 elements
     if (need > c->cw_cap) {
         if (c->cw)
@@ -1467,8 +1480,26 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 vsom_update_split(c->D, c->pitch < c->xpitch ? c->pitch : c->xpitch, n16, n14);
                 const bool fma = c->update_mode == VSOM_UPDATE_FMA, sfma = c->update_mode == VSOM_UPDATE_FMA_SIGMA;
                 const bool med = c->transform == VSOM_MEDIAN;     // its FMAs are exact: one kernel for all modes
-                void *const fn16 = med ? c->upd_med16 : (fma ? c->upd_fma16 : (sfma ? c->upd_sfma16 : c->upd_fn16));
-                void *const fn14 = med ? c->upd_med14 : (fma ? c->upd_fma14 : (sfma ? c->upd_sfma14 : c->upd_fn14));
+                void *fn16 = med ? c->upd_med16 : (fma ? c->upd_fma16 : (sfma ? c->upd_sfma16 : c->upd_fn16));
+                void *fn14 = med ? c->upd_med14 : (fma ? c->upd_fma14 : (sfma ? c->upd_sfma14 : c->upd_fn14));
+                // 14-dim Standard kernels whose workgroup shares ONE (c,w) stream through LDS (gen_update_asm.py,
+                // "lds"): a quarter of the L2 requests (VSOM_UPD_LDS=0/1 overrides the choice, development)
+                static int lds_env = -1;
+                if (lds_env < 0) {
+                    const char *e = std::getenv("VSOM_UPD_LDS");
+                    lds_env = e ? (e[0] == '1' ? 1 : 0) : 2;
+                }
+                // Measured (strict, 784 dims, B = 4096): 16384 nodes (two rounds of 7 wavefronts per SIMD) update 4.56 ->
+                // 4.46 ms, sigma-contracted 4.16 -> 3.91, contracted 3.50 -> 3.30, Median 6.37 -> 5.96; 8192 nodes (one
+                // round) 2.36 vs 2.37; 4096 nodes 1.50 -> 1.53; 2048 nodes 0.81 -> 0.88 -- the barriers cost more than the
+                // L2 requests once a SIMD holds few wavefronts, so the shared stream is used from one full round up.
+                const bool use_lds = lds_env == 1 || (lds_env == 2 && VSOM_UPD_LDS_DEFAULT &&
+                                                      (size_t)gx * ((c->D + 13) / 14) > 7168);
+                if (use_lds) {
+                    const int v = med ? 3 : (fma ? 1 : (sfma ? 2 : 0));
+                    fn14 = c->upd_lds14[v];
+                    fn16 = c->upd_lds16[v];
+                }
                 // column compaction (vsom_compact.hip): the chains of the columns that are zero in every row of
                 // the chunk are retired -- the 14-wide kernel runs on the gathered live columns (device-side
                 // slice count) into dense scratch rows and cc_expand_kernel writes map / sigmaMap back
