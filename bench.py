@@ -439,7 +439,7 @@ def main():
             else:
                 flops = 6.0 * n_nodes_rank * D * sp.Bglob
             ach = flops / upd_avg_s / 1e12 if upd_avg_s > 0 else 0.0
-            kern = {capi.STANDARD: "vsom_update_{std,sfma,fma}_rd14/16_gfx950 (phase-2 mean/sigma^2 chains, hand-scheduled)",
+            kern = {capi.STANDARD: "vsom_update_{std,sfma,fma}_rd14/16[_lds]_gfx950 (phase-2 mean/sigma^2 chains, hand-scheduled)",
                     capi.MEDIAN: "update chain kernel, median stepper (phase-2 chains)",
                     capi.CLR: "vsom_update_clr_rp8_gfx950 (phase-2 CLR chains, hand-scheduled)"}[tr]
             return {"bound": "valu_fp32", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -15,9 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r3"
 # key = "<bench.py --config>_<--arith>" (what bench.py looks up); value = (summary tag, dominant kernel)
-KERNEL = {"c3_strict": ("c3", r"vsom_update_std_rd14_gfx950"), "c3_sigma": ("c3_sigma", r"vsom_update_sfma_rd14_gfx950"),
-          "c3_contracted": ("c3_contracted", r"vsom_update_fma_rd14_gfx950"),
-          "c2_strict": ("c2", r"vsom_update_std_rd14_gfx950"), "c4_strict": ("c4", r"update_chain3_kernel"),
+KERNEL = {"c3_strict": ("c3", r"vsom_update_std_rd14(_lds)?_gfx950"), "c3_sigma": ("c3_sigma", r"vsom_update_sfma_rd14(_lds)?_gfx950"),
+          "c3_contracted": ("c3_contracted", r"vsom_update_fma_rd14(_lds)?_gfx950"),
+          "c2_strict": ("c2", r"vsom_update_std_rd14(_lds)?_gfx950"), "c4_strict": ("c4", r"update_chain3_kernel"),
           "c5_strict": ("c5", r"vsom_update_clr_rp8_gfx950"), "online_strict": ("online", r"online_window_kernel")}
 
 
