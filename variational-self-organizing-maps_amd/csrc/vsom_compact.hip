@@ -90,7 +90,7 @@ __global__ __launch_bounds__(1024) void cc_scan_kernel(const unsigned *__restric
     }
 }
 
-// Zero-slice mask for the strict chain kernels' fast path (gen_update_asm.py, compute_zero_x): bit j of word
+// Zero-slice mask for the Standard chain kernels' fast path (gen_update_asm.py, compute_zero_x): bit j of word
 // zmask[q * ldz + i] says that the 14 values of slice q (compacted columns [14 q, 14 q + 14)) of sample 32 i + j
 // are all zero (+0 or -0; NaN / inf / anything else is not).  One workgroup = 32 rows x CC_ZQ slices: a thread
 // tests one (row, slice) block -- 56 contiguous, 8-byte aligned bytes; consecutive threads read consecutive
@@ -276,9 +276,7 @@ int vsom_cc_stage(vsom_ctx *c)
     return VSOM_OK;
 }
 
-// zero-slice mask of the gathered chunk, built once per chunk when a strict Standard phase 2 asks for it (the
-// sigma-contracted and contracted chains are one instruction shorter already and measured no gain from the
-// branch: update at C3 3.99 -> 4.02 and 3.39 -> 3.55 ms; strict 4.82 -> 4.59 ms)
+// zero-slice mask of the gathered chunk, built once per chunk when a Standard phase 2 asks for it
 int vsom_cc_ensure_zmask(vsom_ctx *c)
 {
     if (c->cc_zmask_valid)

@@ -1506,8 +1506,8 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 const bool compact = c->cc_valid;
                 if (compact && (rc = vsom_cc_ensure_update_scratch(c)))
                     return rc;
-                // strict Standard chains: (sample, slice) blocks that are all zero take the 5-operation form
-                const bool zpath = compact && c->transform == VSOM_STANDARD && c->update_mode == VSOM_UPDATE_STRICT;
+                // Standard chains: (sample, slice) blocks that are all zero take the form without the subtraction
+                const bool zpath = compact && c->transform == VSOM_STANDARD;
                 if (zpath && (rc = vsom_cc_ensure_zmask(c)))
                     return rc;
                 auto launch = [&](void *fn, unsigned nsl, unsigned col0, hipStream_t st) -> int {
