@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void cc_zmask_kernel(const float *__restrict__
 // permutation gives the same results (it only assigns chains to wavefronts).
 #define CC_ORDER_MAX 512
 __global__ __launch_bounds__(512) void cc_slice_order_kernel(const unsigned *__restrict__ zmask, int ldz, int nwords,
-                                                             unsigned *__restrict__ meta)
+                                                             unsigned *__restrict__ meta, int interleave)
 {
     __shared__ int cnt[CC_ORDER_MAX];
     const int nsl = (int)meta[1];
@@ -158,7 +158,15 @@ __global__ __launch_bounds__(512) void cc_slice_order_kernel(const unsigned *__r
         int rank = 0;
         for (int j = 0; j < nsl; ++j)
             rank += (cnt[j] > cnt[q] || (cnt[j] == cnt[q] && j < q)) ? 1 : 0;
-        meta[16 + rank] = (unsigned)q;
+        // interleave: workgroup k takes the slices ranked k, k + nq, k + 2 nq, k + 3 nq -- the same mix everywhere
+        int pos = rank;
+        if (interleave) {
+            const int nq = (nsl + 3) / 4;
+            pos = 4 * (rank % nq) + rank / nq;
+            if (pos >= nsl)          // ragged last quad: keep it a permutation of 0 .. nsl-1
+                pos = rank;
+        }
+        meta[16 + pos] = (unsigned)q;
     }
 }
 
@@ -332,15 +340,17 @@ int vsom_cc_ensure_zmask(vsom_ctx *c)
                        c->stream, c->Xc, (int)c->cpitch, (int)c->B, (int)nslm, c->cc_meta, c->cc_zmask, (int)ldz);
     // measured and left OFF: with the slices sorted every workgroup is homogeneous, but the workgroups then differ
     // from each other as much as they can, and the launch got 1-3 % slower in all three arithmetics (C3 update
-    // strict 4.45 -> 4.51, sigma-contracted 3.81 -> 3.93, contracted 3.20 -> 3.27 ms); VSOM_SLICE_ORDER=1 enables it
+    // strict 4.45 -> 4.51, sigma-contracted 3.81 -> 3.93, contracted 3.20 -> 3.27 ms); the opposite, every workgroup
+    // the same mix (interleaved ranks), is within noise of the raster order (4.42 / 3.89 / 3.23 vs 4.47 / 3.88 / 3.22).
+    // VSOM_SLICE_ORDER=1 (sorted) / 2 (interleaved) enable them
     static int order_env = -1;
     if (order_env < 0) {
         const char *e = std::getenv("VSOM_SLICE_ORDER");
-        order_env = (e && e[0] == '1') ? 1 : 0;
+        order_env = e ? std::atoi(e) : 0;
     }
     if (order_env && nslm <= CC_ORDER_MAX)
         hipLaunchKernelGGL(cc_slice_order_kernel, dim3(1), dim3(512), 0, c->stream, c->cc_zmask, (int)ldz,
-                           (int)((c->B + 31) / 32), c->cc_meta);
+                           (int)((c->B + 31) / 32), c->cc_meta, order_env == 2 ? 1 : 0);
     VSOM_HIP_CHECK(hipGetLastError());
     c->cc_zmask_valid = true;
     return VSOM_OK;
