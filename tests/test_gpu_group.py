@@ -184,3 +184,16 @@ def test_random_group_shapes_match_oracle(name, W, H, J, tr, B, n, sigma, seed):
     assert all(beq(a, b) for a, b in zip(lbs, olb)), name
     check_members(g, o)
     g.close()
+
+
+def test_borrowed_member_is_invalidated_when_the_group_closes():
+    """Group.member() hands out a Context that wraps a vsom_ctx the group owns: it keeps the group alive, and
+    after Group.close() a call on it raises instead of touching freed memory (r2 advisor finding)"""
+    grp = capi.Group(6, 5, 7, capi.STANDARD, devices=[0, 0])
+    m = grp.member(1)
+    assert m.n_nodes == 30 and m.get_state(S=False)["map"].shape == (30, 7)
+    grp.close()
+    with pytest.raises(capi.VsomError):
+        m.get_state()
+    with pytest.raises(capi.VsomError):
+        grp.member(0)
