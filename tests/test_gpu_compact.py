@@ -112,6 +112,33 @@ def test_zero_chunk_negative_zero_and_non_finite_samples():
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_special_values_with_dead_columns_and_zero_blocks(seed):
+    """denormals, 3e38, +-inf, NaN and -0 sprinkled over MNIST-like rows (and NaN / inf / denormal model values in
+    live AND dead columns): every shortcut -- retired columns, the zero-slice form, the shared (c,w) stream -- must
+    propagate them exactly as the reference's chains do"""
+    rs = np.random.RandomState(seed)
+    W, H, B = 44, 40, 200 + 37 * seed
+    X = gen.mnist_like(B, 10 + seed, 784)
+    nz = X != 0
+    pick = lambda p: nz & (rs.rand(*X.shape) < p)
+    X[pick(0.002)] = np.float32(1e-42)
+    X[pick(0.002)] = np.float32(-3e-45)
+    X[pick(0.001)] = np.float32(3e38)
+    X[pick(0.0005)] = np.inf
+    X[pick(0.0005)] = -np.inf
+    X[pick(0.0005)] = np.nan
+    X[rs.rand(*X.shape) < 0.01] = -0.0
+    init = gen.random_map(W * H, 784, 42 + seed) * np.float32(100)
+    init[rs.rand(*init.shape) < 0.0005] = np.nan
+    init[rs.rand(*init.shape) < 0.0003] = np.inf
+    init[rs.rand(*init.shape) < 0.001] = np.float32(2e-41)
+    ctx, orc = _pair(W, H, 784, po.STANDARD, init)
+    _check_epoch(ctx, orc, X, 7.5, True, "special-first")
+    _check_epoch(ctx, orc, X, 5.0, False, "special-local")
+    ctx.close()
+
+
 def test_live_set_changes_between_chunks_and_dense_chunks_pause_the_passes():
     W = H = 40
     J = 784
