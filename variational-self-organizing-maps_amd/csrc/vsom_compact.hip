@@ -246,7 +246,12 @@ bool vsom_cc_applies(const vsom_ctx *c)
         return false;
     if (c->transform != VSOM_STANDARD && c->transform != VSOM_MEDIAN)
         return false;
-    return c->D >= 64;       // below: the chain / tiny kernels, and nothing worth retiring
+    if (c->D < 64)           // the chain / tiny kernels, and nothing worth retiring
+        return false;
+    // only the lane = node assembly kernels and the MFMA shortlist consume the compaction: maps below their
+    // thresholds (launch_phase2: VSOM_CHAIN_MAX_WAVES wavefronts; launch_bmu_full: 1024 nodes) skip the passes
+    const size_t waves = ((size_t)c->N + 63) / 64 * ((c->D + 13) / 14);
+    return waves > VSOM_CHAIN_MAX_WAVES || c->N >= 1024;
 }
 
 static int cc_ensure(vsom_ctx *c)
