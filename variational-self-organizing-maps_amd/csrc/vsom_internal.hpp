@@ -28,6 +28,10 @@ typedef unsigned long long u64;
 // kernel ~2.2e-13 s per (node, dim, sample): they meet near N*D = 4e5 (tools/exp/chain_crossover.py:
 // 4096 x 128: 0.99 vs 1.12 ms at B = 8192; 4096 x 64: ~2 vs 0.75 ms at B = 16384)
 #define VSOM_CHAIN_MAX_WAVES 448
+// ... and up to this many lane = node wavefronts (one resident round of 7 per SIMD) the lane = (node, four dims)
+// kernels of gen_nq_asm.py run instead: their small equal workgroups balance where 1.75-3.5 whole wavefronts per
+// SIMD cannot (BASELINE config 2; the node shards of config 3's multi-GPU split)
+#define VSOM_NQ_MAX_WAVES 7168
 
 #define VSOM_TK 32          // K-chunk of the tile kernels; row pitches are multiples of it
 
@@ -101,7 +105,8 @@ struct vsom_ctx {
 
     // hand-scheduled update kernel (code object loaded with hipModuleLoadData)
     void *upd_module = nullptr, *upd_fn16 = nullptr, *upd_fn14 = nullptr, *upd_fma16 = nullptr, *upd_fma14 = nullptr,
-         *upd_clr8 = nullptr, *upd_med16 = nullptr, *upd_med14 = nullptr, *upd_sfma16 = nullptr, *upd_sfma14 = nullptr, *upd_lds14[4] = {nullptr, nullptr, nullptr, nullptr}, *upd_lds16[4] = {nullptr, nullptr, nullptr, nullptr};
+         *upd_clr8 = nullptr, *upd_med16 = nullptr, *upd_med14 = nullptr, *upd_sfma16 = nullptr, *upd_sfma14 = nullptr, *upd_lds14[4] = {nullptr, nullptr, nullptr, nullptr}, *upd_lds16[4] = {nullptr, nullptr, nullptr, nullptr},
+         *upd_nq[4] = {nullptr, nullptr, nullptr, nullptr};   // lane = (node, four dims) kernels (gen_nq_asm.py): std, fma, sfma, med
     int update_mode = VSOM_UPDATE_STRICT;
     bool use_asm = true;
     bool use_chain = true;

@@ -1178,6 +1178,13 @@ int vsom_load_asm_module(vsom_ctx *c)
     c->upd_clr8 = fclr;
     c->upd_med16 = d16;
     c->upd_med14 = d14;
+    static const char *const nq_names[4] = {"std", "fma", "sfma", "med"};
+    for (int i = 0; i < 4; ++i) {
+        hipFunction_t f;
+        const std::string n = std::string("vsom_update_") + nq_names[i] + "_nq32_gfx950";
+        VSOM_HIP_CHECK(hipModuleGetFunction(&f, mod, n.c_str()));
+        c->upd_nq[i] = f;
+    }
     return VSOM_OK;
 }
 
@@ -1500,6 +1507,14 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     fn14 = c->upd_lds14[v];
                     fn16 = c->upd_lds16[v];
                 }
+                // lane = (node, four dims) kernels (gen_nq_asm.py) where lane = node has too few wavefronts to balance
+                // (VSOM_UPD_NQ=0/1 overrides the choice: tests/test_gpu_nq_kernels.py runs the suite's shapes through them)
+                static int nq_env = -1;
+                if (nq_env < 0) {
+                    const char *e = std::getenv("VSOM_UPD_NQ");
+                    nq_env = e ? (e[0] == '1' ? 1 : 0) : 2;
+                }
+                const bool use_nq = nq_env == 1 || (nq_env == 2 && (size_t)gx * ((c->D + 13) / 14) <= VSOM_NQ_MAX_WAVES);
                 // column compaction (vsom_compact.hip): the chains of the columns that are zero in every row of
                 // the chunk are retired -- the 14-wide kernel runs on the gathered live columns (device-side
                 // slice count) into dense scratch rows and cc_expand_kernel writes map / sigmaMap back
@@ -1507,7 +1522,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 if (compact && (rc = vsom_cc_ensure_update_scratch(c)))
                     return rc;
                 // Standard chains: (sample, slice) blocks that are all zero take the form without the subtraction
-                const bool zpath = compact && c->transform == VSOM_STANDARD;
+                const bool zpath = compact && c->transform == VSOM_STANDARD && !use_nq;
                 if (zpath && (rc = vsom_cc_ensure_zmask(c)))
                     return rc;
                 auto launch = [&](void *fn, unsigned nsl, unsigned col0, hipStream_t st) -> int {
@@ -1545,6 +1560,36 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     n16 = 0;
                     n14 = (c->D + 13) / 14;      // upper bound; the kernel reads the live count from cc_meta
                 }
+                if (use_nq) {
+                    // workgroup = 32 nodes x 32 columns; grid.x = 8 * column blocks (XCD-aware, gen_nq_asm.py); the
+                    // last block of a ragged depth runs into the rows' zero padding (pitches are multiples of 32)
+                    const unsigned cols = compact ? c->cpitch : c->pitch;
+                    const unsigned nb = compact ? c->cpitch / 32 : (c->D + 31) / 32;
+                    const unsigned ng = (unsigned)((nloc + 31) / 32);
+                    UpdAsmArgs a;
+                    a.xs = compact ? c->Xc : c->Xs;
+                    a.cw2 = c->cw;
+                    a.map = compact ? c->Uc_map : c->map;
+                    a.sbuf = compact ? c->Uc_S : c->sigma;
+                    a.ldx_bytes = (compact ? c->cpitch : c->xpitch) * 4u;
+                    a.ldn_bytes = (unsigned)(ldn * 16u);
+                    a.B = (unsigned)c->B;
+                    a.nloc = (unsigned)nloc;
+                    a.nslices = nb;
+                    a.pitch_bytes = cols * 4u;
+                    a.n0 = (unsigned)n0;
+                    a.ppitch_bytes = 0;
+                    a.yp = compact ? (const void *)c->cc_meta : nullptr;
+                    a.zmask = nullptr;
+                    size_t sz = 80;
+                    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
+                                     HIP_LAUNCH_PARAM_END};
+                    void *fn = c->upd_nq[med ? 3 : (fma ? 1 : (sfma ? 2 : 0))];
+                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, 8 * nb, (ng + 7) / 8, 1, 256, 1, 1, 0, c->stream,
+                                                         nullptr, extra));
+                    dbase = (int)c->D;
+                    sig_cols = compact ? -1 : (int)(nb * 32);
+                } else
                 if (n16 + n14 > 0) {
                     const bool both = n16 > 0 && n14 > 0;
                     if (both) {   // fork: the 14-wide part beside the 16-wide one
