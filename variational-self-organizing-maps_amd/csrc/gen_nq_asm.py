@@ -32,11 +32,31 @@ sqrt(S/W) and re-zeroes padding columns (sigma_finalize_kernel / cc_expand_kerne
 lane = node kernels.
 """
 
-NW, PQ, CT = 32, 8, 32          # nodes x quads per workgroup; samples per staged block
-RINGD = 3                       # sample pairs of LDS reads in flight per lane
-X_SLOT_XOR = 0x1000             # x slots at 0x0000 / 0x1000
-C_BASE, C_SLOT_XOR = 0x2000, 0x6000   # (c,w) slots at 0x2000 / 0x4000 (0x2000 ^ 0x6000)
-LDS_BYTES = 0x6000
+import os
+
+NW, PQ = 32, 8                  # nodes x quads (of 4 columns) per workgroup
+
+
+class Cfg:
+    """CT samples per staged block, RINGD sample pairs of LDS reads in flight per lane.
+    CT = 32, RINGD = 3: 77 VGPRs, 24 KB of LDS -> 6 workgroups per CU (6 wavefronts per SIMD);
+    CT = 16, RINGD = 2: <= 64 VGPRs, 12 KB -> 8 per SIMD (the hardware's maximum)."""
+
+    def __init__(self, ct, ringd):
+        assert ct in (16, 32)
+        self.CT, self.RINGD = ct, ringd
+        self.LOG = 5 if ct == 32 else 4
+        self.X_XOR = ct * 128                    # x slots at 0 / CT*128 (CT rows of 128 B)
+        self.C_BASE = ct * 256                   # (c,w) slots (CT/2 pair-rows of 32 nodes x 16 B) at CT*256 / CT*512
+        self.C_XOR = ct * 768
+        self.LDS_BYTES = ct * 768
+        self.NCW = ct // 16                      # 16-byte (c,w) pieces per thread and block
+        self.V_RING = V_RING
+        self.V_G = V_RING + 12 * ringd           # staging: x 4, (c,w) 4 * NCW
+        b = self.V_G + 4 + 4 * self.NCW
+        self.V_XR, self.V_CR, self.V_XW, self.V_CW, self.V_OX, self.V_OC, self.V_OC2 = b, b + 1, b + 2, b + 3, b + 4, b + 5, b + 6
+        self.NVGPR = b + (7 if self.NCW == 2 else 6)
+
 
 # SGPRs
 S_KARG = "s[0:1]"
@@ -45,18 +65,15 @@ S_XP, S_CP, S_MAP, S_SBUF = (4, 5), (6, 7), (8, 9), (10, 11)
 S_LDX, S_LDN, S_B, S_NLOC, S_NB, S_PITCH, S_N0 = "s12", "s13", "s14", "s15", "s16", "s17", "s18"
 S_CNT, S_TAIL, S_TMP, S_TMP2 = "s19", "s20", "s21", "s22"
 S_XSTEP, S_CSTEP = "s23", "s24"
-S_EXEC = "s[32:33]"
 S_REC = (28, 29)
 S_BIG = "s[30:31]"              # Median: both halves 2^100
+S_EXEC = "s[32:33]"
+S_XEXEC = "s[36:37]"            # CT = 16: the 128 threads that stage x
 # VGPRs
 V_TID = 0
 V_M, V_S, V_D, V_T, V_U = 2, 6, 10, 14, 18        # two packed pairs each
 V_RING = 22                                        # RINGD slots of {x(2j) 4, x(2j+1) 4, cw 4}
-V_G = V_RING + 12 * RINGD                          # staging: x 4, cw 8
-V_XR, V_CR, V_XW, V_CW = V_G + 12, V_G + 13, V_G + 14, V_G + 15
-V_OX, V_OC, V_OC2 = V_G + 16, V_G + 17, V_G + 18
 V_A = V_D                                          # epilogue address pair (v[V_D:V_D+1]), V_D+2 node
-NVGPR = V_OC2 + 1
 
 
 def vp(base, p):
@@ -111,6 +128,8 @@ def compute(o, mode, xb, cwb):
 class LdsQueue:
     """issue order of this wavefront's LDS operations (they complete in order): lgkmcnt for 'tag done'"""
 
+    scale = 3       # (timing experiments issue fewer reads per pair)
+
     def __init__(self):
         self.q = []
 
@@ -119,15 +138,17 @@ class LdsQueue:
 
     def wait_for(self, o, tag):
         last = max(i for i, t in enumerate(self.q) if t == tag)
-        younger = len(self.q) - 1 - last
+        younger = (len(self.q) - 1 - last) * LdsQueue.scale // 3
         assert younger <= 15
         o.append(f"\ts_waitcnt lgkmcnt({younger})")
         self.q = self.q[last + 1:]
 
 
-def kernel(name, mode):
+def kernel(name, mode, k):
     o = []
     E = o.append
+    CT, RINGD = k.CT, k.RINGD
+    V_G, V_XR, V_CR, V_XW, V_CW, V_OX, V_OC, V_OC2 = k.V_G, k.V_XR, k.V_CR, k.V_XW, k.V_CW, k.V_OX, k.V_OC, k.V_OC2
     E(f"\t.text\n\t.globl {name}\n\t.p2align 8\n\t.type {name},@function\n{name}:")
     E(f"\ts_load_dwordx8 s[4:11], {S_KARG}, 0x0")              # xs, cw2, map, sbuf
     E(f"\ts_load_dwordx4 s[12:15], {S_KARG}, 0x20")            # ldx_bytes, ldn_bytes, B, nloc
@@ -155,6 +176,11 @@ def kernel(name, mode):
     if mode == "med":
         E(f"\ts_mov_b32 s30, 0x71800000")                         # 2^100
         E(f"\ts_mov_b32 s31, 0x71800000")
+    if CT == 16:   # x block = 16 rows x 8 pieces: threads 0..127 (wavefronts 0, 1) stage it
+        E(f"\tv_readfirstlane_b32 {S_TMP}, v{V_TID}")
+        E(f"\ts_cmp_lt_u32 {S_TMP}, 128")
+        E(f"\ts_cselect_b32 s36, -1, 0")
+        E(f"\ts_mov_b32 s37, s36")
     # per-thread addresses
     E(f"\tv_and_b32_e32 v{V_XR}, 7, v{V_TID}")
     E(f"\tv_lshlrev_b32_e32 v{V_XR}, 4, v{V_XR}")              # quad * 16: x read base (slot 0)
@@ -162,15 +188,16 @@ def kernel(name, mode):
     E(f"\tv_mul_lo_u32 v{V_OX}, v{V_CR}, {S_LDX}")             # staging: row tid>>3 of the block ...
     E(f"\tv_add_u32_e32 v{V_OX}, v{V_OX}, v{V_XR}")            # ... 16-byte piece tid&7
     E(f"\tv_lshlrev_b32_e32 v{V_CR}, 4, v{V_CR}")
-    E(f"\tv_add_u32_e32 v{V_CR}, {C_BASE}, v{V_CR}")           # (c,w) read base (slot 0)
+    E(f"\tv_add_u32_e32 v{V_CR}, {k.C_BASE}, v{V_CR}")         # (c,w) read base (slot 0)
     E(f"\tv_lshlrev_b32_e32 v{V_XW}, 4, v{V_TID}")             # x write: tid * 16
-    E(f"\tv_add_u32_e32 v{V_CW}, {C_BASE}, v{V_XW}")           # (c,w) write: pair-row tid>>5 (+8), node tid&31
+    E(f"\tv_add_u32_e32 v{V_CW}, {k.C_BASE}, v{V_XW}")         # (c,w) write: pair-row tid>>5 (+8), node tid&31
     E(f"\tv_lshrrev_b32_e32 v{V_OC}, 5, v{V_TID}")
     E(f"\tv_mul_lo_u32 v{V_OC}, v{V_OC}, {S_LDN}")
-    E(f"\tv_and_b32_e32 v{V_OC2}, 31, v{V_TID}")
-    E(f"\tv_lshl_add_u32 v{V_OC}, v{V_OC2}, 4, v{V_OC}")
-    E(f"\ts_lshl_b32 {S_TMP}, {S_LDN}, 3")
-    E(f"\tv_add_u32_e32 v{V_OC2}, {S_TMP}, v{V_OC}")           # pair-rows 8..15 of the block
+    E(f"\tv_and_b32_e32 v{V_D}, 31, v{V_TID}")
+    E(f"\tv_lshl_add_u32 v{V_OC}, v{V_D}, 4, v{V_OC}")
+    if k.NCW == 2:
+        E(f"\ts_lshl_b32 {S_TMP}, {S_LDN}, 3")
+        E(f"\tv_add_u32_e32 v{V_OC2}, {S_TMP}, v{V_OC}")       # pair-rows 8..15 of the block
     # global bases: x + column block * 128 B ; cw2 + node group * 32 nodes * 16 B
     E(f"\ts_lshl_b32 {S_TMP}, {S_WGY}, 7")
     E(f"\ts_add_u32 s{S_XP[0]}, s{S_XP[0]}, {S_TMP}")
@@ -178,41 +205,59 @@ def kernel(name, mode):
     E(f"\ts_lshl_b32 {S_TMP}, {S_WGX}, 9")
     E(f"\ts_add_u32 s{S_CP[0]}, s{S_CP[0]}, {S_TMP}")
     E(f"\ts_addc_u32 s{S_CP[1]}, s{S_CP[1]}, 0")
-    E(f"\ts_lshl_b32 {S_XSTEP}, {S_LDX}, 5")                   # 32 sample rows
-    E(f"\ts_lshl_b32 {S_CSTEP}, {S_LDN}, 4")                   # 16 pair-rows
+    E(f"\ts_lshl_b32 {S_XSTEP}, {S_LDX}, {k.LOG}")             # CT sample rows
+    E(f"\ts_lshl_b32 {S_CSTEP}, {S_LDN}, {k.LOG - 1}")         # CT/2 pair-rows
     for r in range(V_M, V_M + 8):                               # currentModel / currentModelSigma .setZero() :843-844
         E(f"\tv_mov_b32_e32 v{r}, 0")
     E(f"\ts_cmp_eq_u32 {S_B}, 0")
     E(f"\ts_cbranch_scc1 .L_store_{name}")
-    E(f"\ts_add_u32 {S_CNT}, {S_B}, 31")
-    E(f"\ts_lshr_b32 {S_CNT}, {S_CNT}, 5")
+    E(f"\ts_add_u32 {S_CNT}, {S_B}, {CT - 1}")
+    E(f"\ts_lshr_b32 {S_CNT}, {S_CNT}, {k.LOG}")
     E(f"\ts_sub_u32 {S_CNT}, {S_CNT}, 1")                      # full blocks before the last one
-    E(f"\ts_lshl_b32 {S_TMP}, {S_CNT}, 5")
-    E(f"\ts_sub_u32 {S_TAIL}, {S_B}, {S_TMP}")                 # samples of the last block: 1..32
+    E(f"\ts_lshl_b32 {S_TMP}, {S_CNT}, {k.LOG}")
+    E(f"\ts_sub_u32 {S_TAIL}, {S_B}, {S_TMP}")                 # samples of the last block: 1..CT
+
+    def xmask(on):
+        if CT == 16:
+            E(f"\ts_mov_b64 exec, {S_XEXEC if on else -1}")
 
     def gload():
+        xmask(True)
         E(f"\tglobal_load_dwordx4 v[{V_G}:{V_G + 3}], v{V_OX}, s[{S_XP[0]}:{S_XP[1]}]")
+        xmask(False)
         E(f"\tglobal_load_dwordx4 v[{V_G + 4}:{V_G + 7}], v{V_OC}, s[{S_CP[0]}:{S_CP[1]}]")
-        E(f"\tglobal_load_dwordx4 v[{V_G + 8}:{V_G + 11}], v{V_OC2}, s[{S_CP[0]}:{S_CP[1]}]")
+        if k.NCW == 2:
+            E(f"\tglobal_load_dwordx4 v[{V_G + 8}:{V_G + 11}], v{V_OC2}, s[{S_CP[0]}:{S_CP[1]}]")
         E(f"\ts_add_u32 s{S_XP[0]}, s{S_XP[0]}, {S_XSTEP}")
         E(f"\ts_addc_u32 s{S_XP[1]}, s{S_XP[1]}, 0")
         E(f"\ts_add_u32 s{S_CP[0]}, s{S_CP[0]}, {S_CSTEP}")
         E(f"\ts_addc_u32 s{S_CP[1]}, s{S_CP[1]}, 0")
 
     def lwrite():
+        xmask(True)
         E(f"\tds_write_b128 v{V_XW}, v[{V_G}:{V_G + 3}]")
+        xmask(False)
         E(f"\tds_write_b128 v{V_CW}, v[{V_G + 4}:{V_G + 7}]")
-        E(f"\tds_write_b128 v{V_CW}, v[{V_G + 8}:{V_G + 11}] offset:4096")
+        if k.NCW == 2:
+            E(f"\tds_write_b128 v{V_CW}, v[{V_G + 8}:{V_G + 11}] offset:4096")
 
     def flip_w():
-        E(f"\tv_xor_b32_e32 v{V_XW}, {X_SLOT_XOR}, v{V_XW}")
-        E(f"\tv_xor_b32_e32 v{V_CW}, {C_SLOT_XOR}, v{V_CW}")
+        E(f"\tv_xor_b32_e32 v{V_XW}, {k.X_XOR}, v{V_XW}")
+        E(f"\tv_xor_b32_e32 v{V_CW}, {k.C_XOR}, v{V_CW}")
+
+    EXP = os.environ.get("VSOM_GEN_NQ_EXP", "")     # timing experiments (wrong results)
 
     def lread(slot, jj):
         r = V_RING + 12 * slot
         E(f"\tds_read_b128 v[{r}:{r + 3}], v{V_XR} offset:{128 * (2 * jj)}")
-        E(f"\tds_read_b128 v[{r + 4}:{r + 7}], v{V_XR} offset:{128 * (2 * jj + 1)}")
-        E(f"\tds_read_b128 v[{r + 8}:{r + 11}], v{V_CR} offset:{512 * jj}")
+        if EXP == "halfx":
+            E(f"\ts_nop 0")
+        else:
+            E(f"\tds_read_b128 v[{r + 4}:{r + 7}], v{V_XR} offset:{128 * (2 * jj + 1)}")
+        if EXP == "nocw":
+            E(f"\ts_nop 0")
+        else:
+            E(f"\tds_read_b128 v[{r + 8}:{r + 11}], v{V_CR} offset:{512 * jj}")
 
     # ---- prologue: block 0 -> slot 0, block 1 -> registers --------------------------------------
     gload()
@@ -230,39 +275,34 @@ def kernel(name, mode):
     # ---- main loop: one full block per iteration ---------------------------------------------
     E(f"\t.p2align 6\n.L_loop_{name}:")
     q = LdsQueue()
-    for jj in range(RINGD):
+    E(f"\ts_waitcnt vmcnt(0)")                                # block b+1 landed in the staging registers
+    lwrite()                                                    # -> the slot block b-1 was read from (LDS operations
+    for jj in range(RINGD):                                     #    complete in order: the reads below wait for them)
         lread(jj, jj)
         q.push(("r", jj), 3)
-    E(f"\ts_waitcnt vmcnt(0)")                                # block b+1 landed in the staging registers
-    lwrite()                                                    # -> the slot block b-1 was read from
-    q.push("w", 3)
-    loads_done = False
     for jj in range(CT // 2):
-        had_w = "w" in q.q
         q.wait_for(o, ("r", jj))
-        if had_w and "w" not in q.q and not loads_done:
+        if jj == 0:
             # the writes have left the staging registers: block b+2 -> registers (if there is one)
             E(f"\ts_cmp_lt_u32 {S_CNT}, 2")
             E(f"\ts_cbranch_scc1 .L_nl_{name}")
             gload()
             E(f".L_nl_{name}:")
-            loads_done = True
         r = V_RING + 12 * (jj % RINGD)
         compute(o, mode, r, r + 8)
         compute(o, mode, r + 4, r + 10)
         if jj + RINGD < CT // 2:
             lread(jj % RINGD, jj + RINGD)
             q.push(("r", jj + RINGD), 3)
-    assert loads_done
     flip_w()
-    E(f"\tv_xor_b32_e32 v{V_XR}, {X_SLOT_XOR}, v{V_XR}")
-    E(f"\tv_xor_b32_e32 v{V_CR}, {C_SLOT_XOR}, v{V_CR}")
+    E(f"\tv_xor_b32_e32 v{V_XR}, {k.X_XOR}, v{V_XR}")
+    E(f"\tv_xor_b32_e32 v{V_CR}, {k.C_XOR}, v{V_CR}")
     E(f"\ts_waitcnt lgkmcnt(0)")
     E(f"\ts_barrier")                                          # slot b+1 written by all, slot b read by all
     E(f"\ts_sub_u32 {S_CNT}, {S_CNT}, 1")
     E(f"\ts_cmp_lg_u32 {S_CNT}, 0")
     E(f"\ts_cbranch_scc1 .L_loop_{name}")
-    # ---- last block: 1..32 samples, no staging --------------------------------------------------
+    # ---- last block: 1..CT samples, no staging --------------------------------------------------
     E(f".L_last_{name}:")
     lread(0, 0)
     for jj in range(CT // 2):
@@ -313,8 +353,11 @@ MODES = ("std", "fma", "sfma", "med")
 
 def emit():
     """[(name, text, vgprs, kernarg bytes, lds bytes, dx10_clamp)] for gen_update_asm.main()"""
+    k = Cfg(int(os.environ.get("VSOM_GEN_NQ_CT", "32")), int(os.environ.get("VSOM_GEN_NQ_RING", "3")))
+    if os.environ.get("VSOM_GEN_NQ_EXP", "") in ("halfx", "nocw"):
+        LdsQueue.scale = 2
     out = []
     for m in MODES:
         name = f"vsom_update_{m}_nq32_gfx950"
-        out.append((name, kernel(name, m), NVGPR, 80, LDS_BYTES, 0 if m == "med" else 1))
+        out.append((name, kernel(name, m, k), k.NVGPR, 80, k.LDS_BYTES, 0 if m == "med" else 1))
     return out

@@ -106,7 +106,7 @@ struct vsom_ctx {
     // hand-scheduled update kernel (code object loaded with hipModuleLoadData)
     void *upd_module = nullptr, *upd_fn16 = nullptr, *upd_fn14 = nullptr, *upd_fma16 = nullptr, *upd_fma14 = nullptr,
          *upd_clr8 = nullptr, *upd_med16 = nullptr, *upd_med14 = nullptr, *upd_sfma16 = nullptr, *upd_sfma14 = nullptr, *upd_lds14[4] = {nullptr, nullptr, nullptr, nullptr}, *upd_lds16[4] = {nullptr, nullptr, nullptr, nullptr},
-         *upd_nq[4] = {nullptr, nullptr, nullptr, nullptr};   // lane = (node, four dims) kernels (gen_nq_asm.py): std, fma, sfma, med
+         *upd_nq[4] = {nullptr, nullptr, nullptr, nullptr}, *upd_nt[4] = {nullptr, nullptr, nullptr, nullptr};   // lane = (node, four dims) kernels (gen_nq_asm.py): std, fma, sfma, med
     int update_mode = VSOM_UPDATE_STRICT;
     bool use_asm = true;
     bool use_chain = true;
@@ -129,6 +129,11 @@ struct vsom_ctx {
     float *Uc_map = nullptr, *Uc_S = nullptr;    // N x cpitch: the chains' M and raw S on the live columns
     unsigned *cc_zmask = nullptr; size_t cc_zmask_cap = 0;   // [slice][ceil(B/32)+2] all-zero (sample, slice) bits
     bool cc_zmask_valid = false;
+    // the chunk transposed into column quads (vsom_xq.hip) for the lane = node, four-dims-per-wavefront chain kernels
+    float *Xq = nullptr; size_t Xq_cap = 0;      // [quads rounded up to 8][bpad] float4
+    unsigned *zq = nullptr;                      // [quads][bpad / 32] all-zero (sample, quad) bits
+    bool xq_valid = false;
+    uint32_t xq_bpad = 0, xq_quads = 0;
 
     // online path scratch
     float *v_dev = nullptr;         // one sample, padded
@@ -187,5 +192,6 @@ int vsom_cc_gather_map(vsom_ctx *c);
 int vsom_cc_ensure_zmask(vsom_ctx *c);
 int vsom_cc_ensure_update_scratch(vsom_ctx *c);
 int vsom_cc_expand(vsom_ctx *c, size_t n0, size_t nloc);
+int vsom_xq_ensure(vsom_ctx *c);                                 // vsom_xq.hip
 bool vsom_tiny_applies(const vsom_ctx *c);                        // vsom_tiny.hip
 int launch_tiny_epoch(vsom_ctx *c, double sigma, int is_first);   // whole batch epoch, one workgroup

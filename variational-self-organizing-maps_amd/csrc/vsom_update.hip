@@ -1184,6 +1184,9 @@ int vsom_load_asm_module(vsom_ctx *c)
         const std::string n = std::string("vsom_update_") + nq_names[i] + "_nq32_gfx950";
         VSOM_HIP_CHECK(hipModuleGetFunction(&f, mod, n.c_str()));
         c->upd_nq[i] = f;
+        const std::string n2 = std::string("vsom_update_") + nq_names[i] + "_nt4_gfx950";
+        VSOM_HIP_CHECK(hipModuleGetFunction(&f, mod, n2.c_str()));
+        c->upd_nt[i] = f;
     }
     return VSOM_OK;
 }
@@ -1514,7 +1517,14 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     const char *e = std::getenv("VSOM_UPD_NQ");
                     nq_env = e ? (e[0] == '1' ? 1 : 0) : 2;
                 }
-                const bool use_nq = nq_env == 1 || (nq_env == 2 && (size_t)gx * ((c->D + 13) / 14) <= VSOM_NQ_MAX_WAVES);
+                // lane = node, four dims per wavefront, x from scalar loads of the transposed chunk (gen_nt_asm.py)
+                static int nt_env = -1;
+                if (nt_env < 0) {
+                    const char *e = std::getenv("VSOM_UPD_NT");
+                    nt_env = e ? (e[0] == '1' ? 1 : 0) : 2;
+                }
+                const bool use_nt = nt_env == 1;
+                const bool use_nq = !use_nt && (nq_env == 1 || (nq_env == 2 && (size_t)gx * ((c->D + 13) / 14) <= VSOM_NQ_MAX_WAVES));
                 // column compaction (vsom_compact.hip): the chains of the columns that are zero in every row of
                 // the chunk are retired -- the 14-wide kernel runs on the gathered live columns (device-side
                 // slice count) into dense scratch rows and cc_expand_kernel writes map / sigmaMap back
@@ -1522,7 +1532,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                 if (compact && (rc = vsom_cc_ensure_update_scratch(c)))
                     return rc;
                 // Standard chains: (sample, slice) blocks that are all zero take the form without the subtraction
-                const bool zpath = compact && c->transform == VSOM_STANDARD && !use_nq;
+                const bool zpath = compact && c->transform == VSOM_STANDARD && !use_nq && !use_nt;
                 if (zpath && (rc = vsom_cc_ensure_zmask(c)))
                     return rc;
                 auto launch = [&](void *fn, unsigned nsl, unsigned col0, hipStream_t st) -> int {
@@ -1560,6 +1570,36 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     n16 = 0;
                     n14 = (c->D + 13) / 14;      // upper bound; the kernel reads the live count from cc_meta
                 }
+                if (use_nt) {
+                    // workgroup = 64 nodes x 8 column quads (one per wavefront); grid.x = 8 * column blocks (XCD-aware)
+                    if ((rc = vsom_xq_ensure(c)))
+                        return rc;
+                    const unsigned cols = compact ? c->cpitch : c->pitch;
+                    const unsigned quads = compact ? c->cpitch / 4 : (c->D + 3) / 4;
+                    UpdAsmArgs a;
+                    a.xs = c->Xq;
+                    a.cw2 = c->cw;
+                    a.map = compact ? c->Uc_map : c->map;
+                    a.sbuf = compact ? c->Uc_S : c->sigma;
+                    a.ldx_bytes = c->xq_bpad * 16u;
+                    a.ldn_bytes = (unsigned)(ldn * 16u);
+                    a.B = (unsigned)c->B;
+                    a.nloc = (unsigned)nloc;
+                    a.nslices = quads;
+                    a.pitch_bytes = cols * 4u;
+                    a.n0 = (unsigned)n0;
+                    a.ppitch_bytes = 0;
+                    a.yp = compact ? (const void *)c->cc_meta : nullptr;
+                    a.zmask = c->zq;
+                    size_t sz = 80;
+                    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
+                                     HIP_LAUNCH_PARAM_END};
+                    void *fn = c->upd_nt[med ? 3 : (fma ? 1 : (sfma ? 2 : 0))];
+                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, 8 * ((quads + 7) / 8), (gx + 7) / 8, 1, 512, 1, 1, 0,
+                                                         c->stream, nullptr, extra));
+                    dbase = (int)c->D;
+                    sig_cols = compact ? -1 : (int)(quads * 4);
+                } else
                 if (use_nq) {
                     // workgroup = 32 nodes x 32 columns; grid.x = 8 * column blocks (XCD-aware, gen_nq_asm.py); the
                     // last block of a ragged depth runs into the rows' zero padding (pitches are multiples of 32)
