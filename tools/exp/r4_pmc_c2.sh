@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 B="--no-cpu --no-other-arith --steps 3 --warmup 1 $*"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/d -o p -- python3 $R/bench.py $B > $O/d.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $O/e -o p -- python3 $R/bench.py $B > $O/e.log 2>&1
-rocprofv3 --pmc FETCH_SIZE WRITE_SIZE TCC_HIT TCC_MISS TCC_REQ --kernel-trace --output-format csv -d $O/f -o p -- python3 $R/bench.py $B > $O/f.log 2>&1
+echo skip > $O/f.log
 for p in d e f; do
   cc=$(find $O/$p -name '*counter_collection.csv' | head -1)
   kt=$(find $O/$p -name '*kernel_trace.csv' | head -1)

@@ -1523,7 +1523,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
                     const char *e = std::getenv("VSOM_UPD_NT");
                     nt_env = e ? (e[0] == '1' ? 1 : 0) : 2;
                 }
-                const bool use_nt = nt_env == 1;
+                const bool use_nt = nt_env != 0;
                 const bool use_nq = !use_nt && (nq_env == 1 || (nq_env == 2 && (size_t)gx * ((c->D + 13) / 14) <= VSOM_NQ_MAX_WAVES));
                 // column compaction (vsom_compact.hip): the chains of the columns that are zero in every row of
                 // the chunk are retired -- the 14-wide kernel runs on the gathered live columns (device-side
