@@ -53,8 +53,9 @@ V_M, V_S, V_D, V_T, V_U = 2, 6, 10, 14, 18
 V_RING = 22                               # 2 sets x 2 pairs x {c, w, c, w}
 V_G = 38                                  # staging: two 16-byte pieces
 V_CR, V_CW, V_OC, V_OC2 = 46, 47, 48, 49
+V_K = 50                                  # Median: both halves -2^24
 V_A = V_D
-NVGPR = 50
+NVGPR = 52
 
 
 def vp(base, p):
@@ -69,14 +70,17 @@ def compute(o, mode, xs, cwb):
     """one sample: x in s[xs:xs+3], {c, w} in v[cwb:cwb+1] (Som.cpp:861-867, Transformation.cpp:12,50)"""
     cw = f"v[{cwb}:{cwb + 1}]"
     P = (0, 1)
-    for p in P:   # delta = x - M
-        o.append(f"\tv_pk_add_f32 {vp(V_D, p)}, {sp(xs, p)}, {vp(V_M, p)} neg_lo:[0,1] neg_hi:[0,1]")
     if mode == "med":
-        for p in P:   # t = delta * 2^100
-            o.append(f"\tv_pk_mul_f32 {vp(V_D, p)}, {vp(V_D, p)}, {S_BIG}")
-        for p in P:   # p = [delta > 0]
+        # StandardMedianEstimator, 7 operations per pair (vsom_update.hip, VSOM_MED_STEP): the transposed chunk holds
+        # x * 2^24 for a Median context (vsom_xq.hip), and t = fma(M, -2^24, x * 2^24) has exactly the sign of x - M
+        # (the scaling is exact, the fused difference rounds once and never to zero; NaN stays NaN);
+        # p = clamp(t * 2^127) = [t > 0], n = clamp(-t * 2^127) = [t < 0] (DX10_CLAMP off: NaN passes); the four
+        # accumulations are exact-product FMAs that round where the reference's separate multiply and add round.
+        for p in P:   # t = M * (-2^24) + x * 2^24
+            o.append(f"\tv_pk_fma_f32 {vp(V_D, p)}, {vp(V_M, p)}, v[{V_K}:{V_K + 1}], {sp(xs, p)}")
+        for p in P:   # p = [t > 0]
             o.append(f"\tv_pk_mul_f32 {vp(V_T, p)}, {vp(V_D, p)}, {S_BIG} clamp")
-        for p in P:   # n = [delta < 0]
+        for p in P:   # n = [t < 0]
             o.append(f"\tv_pk_mul_f32 {vp(V_U, p)}, {vp(V_D, p)}, {S_BIG} neg_lo:[1,0] neg_hi:[1,0] clamp")
         for p in P:   # M = M + c*p
             o.append(f"\tv_pk_fma_f32 {vp(V_M, p)}, {cw}, {vp(V_T, p)}, {vp(V_M, p)} op_sel_hi:[0,1,1]")
@@ -87,6 +91,8 @@ def compute(o, mode, xs, cwb):
         for p in P:   # S = S + w*n
             o.append(f"\tv_pk_fma_f32 {vp(V_S, p)}, {cw}, {vp(V_U, p)}, {vp(V_S, p)} op_sel:[1,0,0]")
         return
+    for p in P:   # delta = x - M
+        o.append(f"\tv_pk_add_f32 {vp(V_D, p)}, {sp(xs, p)}, {vp(V_M, p)} neg_lo:[0,1] neg_hi:[0,1]")
     if mode == "fma":
         for p in P:   # M = c*delta + M
             o.append(f"\tv_pk_fma_f32 {vp(V_M, p)}, {cw}, {vp(V_D, p)}, {vp(V_M, p)} op_sel_hi:[0,1,1]")
@@ -192,8 +198,10 @@ def kernel(name, mode):
     E(f"\ts_cmp_ge_u32 {S_Q}, {S_NQ}")                         # a dead quad inside a live block: takes part in the
     E(f"\ts_cselect_b32 {S_DEAD}, 1, 0")                       # staging and the barriers, stores nothing
     if mode == "med":
-        E(f"\ts_mov_b32 s30, 0x71800000")                         # 2^100
-        E(f"\ts_mov_b32 s31, 0x71800000")
+        E(f"\ts_mov_b32 s30, 0x7f000000")                         # 2^127
+        E(f"\ts_mov_b32 s31, 0x7f000000")
+        E(f"\tv_mov_b32_e32 v{V_K}, 0xcb800000")                  # -2^24
+        E(f"\tv_mov_b32_e32 v{V_K + 1}, 0xcb800000")
     # x / mask rows of this quad
     E(f"\ts_mul_i32 {S_TMP}, {S_Q}, {S_LDX}")
     E(f"\ts_mul_hi_u32 {S_TMP2}, {S_Q}, {S_LDX}")

@@ -12,7 +12,7 @@
 // vsom_compact.hip) -- one pass over ~13 MB per 4096 x 784 chunk.
 #include "vsom_device.hpp"
 
-__global__ __launch_bounds__(256) void xq_transpose_kernel(const float *__restrict__ src, int ld, int B, int bpad, int nq8,
+__global__ __launch_bounds__(256) void xq_transpose_kernel(const float *__restrict__ src, int ld, int B, int bpad, int nq8, float scale,
                                                            float4 *__restrict__ xq, unsigned *__restrict__ zq)
 {
     __shared__ float4 tile[16][65];
@@ -23,6 +23,10 @@ __global__ __launch_bounds__(256) void xq_transpose_kernel(const float *__restri
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (j < B && col + 3 < ld)                       // ld is a multiple of 32: whole quads
             v = *reinterpret_cast<const float4 *>(src + (size_t)j * ld + col);
+        v.x *= scale;                                    // Median: x * 2^24, exact (gen_nt_asm.py); else 1
+        v.y *= scale;
+        v.z *= scale;
+        v.w *= scale;
         tile[qq][js] = v;
     }
     __syncthreads();
@@ -67,7 +71,8 @@ int vsom_xq_ensure(vsom_ctx *c)
     }
     const uint32_t bpad = (uint32_t)((c->B + 31) / 32 * 32 + 32);
     hipLaunchKernelGGL(xq_transpose_kernel, dim3((bpad + 63) / 64, nq8 / 16 + (nq8 % 16 ? 1 : 0)), dim3(256), 0, c->stream,
-                       compact ? c->Xc : c->Xs, (int)cols, (int)c->B, (int)bpad, (int)nq8, reinterpret_cast<float4 *>(c->Xq),
+                       compact ? c->Xc : c->Xs, (int)cols, (int)c->B, (int)bpad, (int)nq8,
+                       c->transform == VSOM_MEDIAN ? 0x1.0p24f : 1.f, reinterpret_cast<float4 *>(c->Xq),
                        c->zq);
     VSOM_HIP_CHECK(hipGetLastError());
     c->xq_bpad = bpad;
