@@ -115,7 +115,7 @@ def test_zero_chunk_negative_zero_and_non_finite_samples():
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_special_values_with_dead_columns_and_zero_blocks(seed):
     """denormals, 3e38, +-inf, NaN and -0 sprinkled over MNIST-like rows (and NaN / inf / denormal model values in
-    live AND dead columns): every shortcut -- retired columns, the zero-slice form, the shared (c,w) stream -- must
+    live AND dead columns): every shortcut -- retired columns, the zero-quad form -- must
     propagate them exactly as the reference's chains do"""
     rs = np.random.RandomState(seed)
     W, H, B = 44, 40, 200 + 37 * seed
@@ -156,55 +156,69 @@ def test_live_set_changes_between_chunks_and_dense_chunks_pause_the_passes():
 
 def test_default_threshold_and_switch():
     """chunks below 1024 rows are left alone by default, larger ones are compacted; either way and with the
-    feature switched off the results are the same bits"""
+    feature switched off (-1) or forced onto every chunk (1) the results are the oracle's bits"""
     W = H = 40
     init = gen.random_map(W * H, 784, 42) * np.float32(100)
     X = gen.mnist_like(1100, 3, 784)
-    ref = None
     for setting in (None, -1, 1):
         ctx = vsom_amd.Context(W, H, 784, po.STANDARD)
+        orc = po.OracleSom(W, H, 784, po.STANDARD)
         if setting is not None:
             ctx.set_column_compaction(setting)
         ctx.set_state(map=init)
-        for Xc in (X, X[:300]):
-            ctx.upload_chunk(Xc)
-            ctx.batch_epoch(9.0, True)
-        st = ctx.get_state(S=False)
-        if ref is None:
-            ref = st
-        else:
-            for k in ("map", "sigma", "weight", "hits"):
-                assert _same(st[k], ref[k]), (setting, k)
+        orc.set_state(map=init)
+        for i, Xc in enumerate((X, X[:300])):
+            _check_epoch(ctx, orc, Xc, 9.0, True, f"setting {setting} chunk {i}")
         ctx.close()
 
 
+@pytest.mark.parametrize("compaction", [1, -1], ids=["compacted", "plain"])
 @pytest.mark.parametrize("mode", [capi.UPDATE_STRICT, capi.UPDATE_FMA_SIGMA, capi.UPDATE_FMA], ids=["strict", "sigma", "contracted"])
-def test_zero_slice_form_is_exact_in_every_arithmetic(mode):
-    """42 % of the (sample, 14-column slice) blocks of an MNIST-like chunk's live columns are all zero; the chain
-    kernels then take a form without the subtraction (delta = -M; gen_update_asm.py, compute_zero_x).  It is exact
-    in each of the three arithmetics: with the passes on (mask present) and off (plain kernels) the same mode
-    gives the same bits -- and strict equals the oracle (the other tests of this file)."""
+def test_zero_quad_form_in_every_arithmetic(mode, compaction):
+    """~70 % of the (sample, column quad) blocks of an MNIST-like chunk are all zero; the chain kernels then take a
+    form without the subtraction (delta = -M; csrc/gen_nt_asm.py, compute_zero) in each of the three arithmetics.
+    Against the oracle, with and without the column compaction: strict -- every bit; sigma-contracted -- lastBMU,
+    MSE, map, weightMap, bmuHits every bit over the three chunks and sigmaMap within 1e-5 relative;
+    contracted -- one epoch from the same map: BMUs / MSE / weightMap / bmuHits every bit, map and sigmaMap within
+    1e-5 of max(|reference|, largest sample value of the column) (include/vsom_hip.h, vsom_update_mode)."""
     W = H = 48
     X = gen.mnist_like(2000, 6, 784)
     X[7] = 0.0
     X[100:140, :] = 0.0                                     # a run of all-zero samples
     X[300, 200:260] = -0.0
     init = gen.random_map(W * H, 784, 42) * np.float32(100)
-    out = []
-    for setting in (1, -1):
-        ctx = vsom_amd.Context(W, H, 784, po.STANDARD)
-        ctx.set_column_compaction(setting)
-        ctx.set_update_mode(mode)
-        ctx.set_state(map=init)
-        for first, Xc in ((True, X), (False, X[:1037]), (True, X[5:1994])):      # tails of 5 and 5 samples too
-            ctx.upload_chunk(Xc)
-            ctx.batch_epoch(7.0, first)
-        out.append((ctx.get_state(S=False), ctx.get_last_bmu()))
-        ctx.close()
-    (a, la), (b, lb) = out
-    assert _same(la, lb)
-    for k in ("map", "sigma", "weight", "hits"):
-        assert _same(a[k], b[k]), k
+    ctx = vsom_amd.Context(W, H, 784, po.STANDARD)
+    ctx.set_column_compaction(compaction)
+    ctx.set_update_mode(mode)
+    orc = po.OracleSom(W, H, 784, po.STANDARD)
+    ctx.set_state(map=init)
+    orc.set_state(map=init)
+
+    def close(a, b):
+        a64, b64 = a.astype(np.float64), b.astype(np.float64)
+        nz = b64 != 0
+        return bool((np.abs(a64 - b64)[nz] <= 1e-5 * np.abs(b64[nz])).all() and (a64[~nz] == 0).all())
+
+    chunks = ((True, X), (False, X[:1037]), (True, X[5:1994]))      # tails of 5 and 5 samples too
+    for i, (first, Xc) in enumerate(chunks[:1] if mode == capi.UPDATE_FMA else chunks):
+        lb = np.zeros(Xc.shape[0], np.uint64)
+        mse_o = orc.batch_epoch(Xc, lb, 7.0, first, nthreads=THREADS)
+        ctx.upload_chunk(Xc)
+        mse_g = ctx.batch_epoch(7.0, first)
+        st = ctx.get_state(S=False)
+        assert _same(ctx.get_last_bmu(), lb) and _same(np.float32(mse_g), np.float32(mse_o)), i
+        assert _same(st["weight"], orc.weight) and _same(st["hits"], orc.hits), i
+        if mode == capi.UPDATE_STRICT:
+            assert _same(st["map"], orc.map) and _same(st["sigma"], orc.sigma), i
+        elif mode == capi.UPDATE_FMA_SIGMA:
+            assert _same(st["map"], orc.map) and close(st["sigma"], orc.sigma), i
+        else:       # the documented bound of the contracted arithmetic (tests/test_gpu_fma_mode.py): 1e-5 of the larger of
+            #     the reference element and the magnitude of the operands its chain consumed
+            sd = np.abs(Xc).max(axis=0)[None, :].astype(np.float64)
+            for k, ref in (("map", orc.map), ("sigma", orc.sigma)):
+                a64, b64 = st[k].astype(np.float64), ref.astype(np.float64)
+                assert (np.abs(a64 - b64) <= 1e-5 * np.maximum(np.abs(b64), sd)).all(), (i, k)
+    ctx.close()
 
 
 def test_group_of_three_on_data_with_dead_columns():

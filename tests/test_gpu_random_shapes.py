@@ -133,7 +133,7 @@ def test_random_shape_assembly_update(name, W, H, J, B, sigma, seed, tr):
     frac = [0.0, 0.25, 0.6][seed % 3]
     X[:, rs.rand(J) < frac] = 0.0
     # ... and runs of zeros inside single rows: (sample, 14-column slice) blocks that are entirely zero take the
-    # chains' zero-slice form (gen_update_asm.py, compute_zero_x), -0.0 included
+    # chains' zero-quad form (gen_nt_asm.py, compute_zero), -0.0 included
     for r in np.flatnonzero(rs.rand(B) < 0.4):
         c0 = int(rs.randint(0, J))
         X[r, c0:c0 + int(rs.randint(14, 90))] = 0.0 if rs.rand() < 0.8 else -0.0

@@ -9,7 +9,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function"
 # hand-scheduled update kernel: generator -> .s -> code object -> C array included by vsom_update.hip
 LLVM="${LLVM_BIN:-/opt/rocm/lib/llvm/bin}"
-if [ ! -f "$here/vsom_update_hsaco.inc" ] || [ "$here/gen_update_asm.py" -nt "$here/vsom_update_hsaco.inc" ] || [ "$here/gen_nq_asm.py" -nt "$here/vsom_update_hsaco.inc" ] || [ "$here/gen_nt_asm.py" -nt "$here/vsom_update_hsaco.inc" ]; then
+if [ ! -f "$here/vsom_update_hsaco.inc" ] || [ "$here/gen_update_asm.py" -nt "$here/vsom_update_hsaco.inc" ] || [ "$here/gen_nt_asm.py" -nt "$here/vsom_update_hsaco.inc" ]; then
   python3 "$here/gen_update_asm.py" "$here/vsom_update_gfx950.s"
   "$LLVM/clang" -x assembler -target amdgcn-amd-amdhsa -mcpu=gfx950 -c "$here/vsom_update_gfx950.s" -o "$here/vsom_update_gfx950.o"
   "$LLVM/ld.lld" -shared "$here/vsom_update_gfx950.o" -o "$here/vsom_update_gfx950.hsaco"

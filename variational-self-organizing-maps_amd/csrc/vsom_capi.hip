@@ -145,7 +145,7 @@ static int free_all(vsom_ctx *c)
     void *ptrs[] = {c->map, c->sigma, c->S, c->weight, c->hits, c->Xs, c->XP, c->YP, c->Xraw,
                     c->lastbmu, c->sqres, c->mse, c->bxy, c->pair_i, c->pair_j, c->partial, c->nan0,
                     c->cw, c->lut, c->lutd, c->sl_G, c->sl_nrm, c->sl_scal, c->sl_list, c->sl_tmin, c->sl_fs, c->sl_fm, c->v_dev, c->res_dev, c->onl_state, c->onl_f,
-                    c->cc_flags, c->cc_idx, c->cc_inv, c->cc_meta, c->Xc, c->Mc, c->Uc_map, c->Uc_S, c->cc_zmask, c->Xq, c->zq};
+                    c->cc_flags, c->cc_idx, c->cc_inv, c->cc_meta, c->Xc, c->Mc, c->Uc_map, c->Uc_S, c->Xq, c->zq};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -238,10 +238,6 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
     c->part_pitch = roundup(c->part_len, VSOM_TK);
     c->pitch = c->nparts * c->part_pitch;
     c->xpitch = roundup(c->J, VSOM_TK);
-    if (const char *e = std::getenv("VSOM_NO_ASM"))
-        c->use_asm = !(e[0] == '1');   // debugging aid: HIP update kernel instead of the hand-scheduled one
-    if (const char *e = std::getenv("VSOM_CW_MODE"))
-        c->cw_mode = e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0);
     if (const char *e = std::getenv("VSOM_NO_TINY"))
         c->use_tiny = !(e[0] == '1');
     if (const char *e = std::getenv("VSOM_COMPACT_MIN_ROWS"))     // development: initial vsom_set_column_compaction

@@ -13,7 +13,7 @@
 // So the chain kernels and the contraction run on the LIVE columns only, gathered into dense scratch matrices,
 // and an expansion pass writes the model rows back in the reference's layout.  Which columns are live is
 // data-dependent and known on the device only: the kernels read the counts from `cc_meta`, the host launches
-// full-size grids whose surplus wavefronts exit at once, and nothing synchronises.  The count is also mirrored
+// full-size grids whose surplus workgroups exit at once, and nothing synchronises.  The count is also mirrored
 // into pinned host memory; when the last chunks had (almost) no dead column the host skips the passes for a
 // few chunks (dense data pays ~2 % for nothing otherwise).
 //
@@ -23,9 +23,8 @@
 
 #include <cstdlib>
 
-// meta: [0] live columns Kc, [1] live 14-dim slices ceil(Kc/14), [2] Kc rounded up to 32 (K of the contraction),
-//       [3] sequence number; [16 + L] the PHYSICAL slice the chain kernels' logical slice L works on (identity until
-//       cc_slice_order_kernel sorts the slices by how often they are all zero)
+// meta: [0] live columns Kc (the chain kernels derive their live column quads from it), [1] live column quads ceil(Kc/4),
+//       [2] Kc rounded up to 32 (K of the contraction), [3] sequence number
 __global__ __launch_bounds__(256) void cc_flag_kernel(const float *__restrict__ xs, int ldx, int B, int D,
                                                       unsigned *__restrict__ flags)
 {
@@ -80,93 +79,14 @@ __global__ __launch_bounds__(1024) void cc_scan_kernel(const unsigned *__restric
     const int kc = base;
     for (int k = kc + (int)threadIdx.x; k < cpitch; k += 1024)
         idx[k] = -1;
-    for (int q = threadIdx.x; q < (cpitch + 13) / 14 + 4; q += 1024)
-        meta[16 + q] = (unsigned)q;
     if (threadIdx.x == 0) {
         meta[0] = (unsigned)kc;
-        meta[1] = (unsigned)((kc + 13) / 14);
+        meta[1] = (unsigned)((kc + 3) / 4);
         meta[2] = (unsigned)((kc + 31) / 32 * 32);
         meta[3] = meta[3] + 1u;
         host_fb[0] = (unsigned)kc;
         __threadfence_system();
         host_fb[1] = host_fb[1] + 1u;
-    }
-}
-
-// Zero-slice mask for the Standard chain kernels' fast path (gen_update_asm.py, compute_zero_x): bit j of word
-// zmask[q * ldz + i] says that the 14 values of slice q (compacted columns [14 q, 14 q + 14)) of sample 32 i + j
-// are all zero (+0 or -0; NaN / inf / anything else is not).  One workgroup = 32 rows x CC_ZQ slices: a thread
-// tests one (row, slice) block -- 56 contiguous, 8-byte aligned bytes; consecutive threads read consecutive
-// slices of a row -- and thread q then assembles the 32-sample word of its slice.  Words past the chunk stay
-// zero (the kernels read two words ahead).
-#define CC_ZQ 16
-__global__ __launch_bounds__(256) void cc_zmask_kernel(const float *__restrict__ xc, int ldc, int B, int nslices_max,
-                                                       const unsigned *__restrict__ meta, unsigned *__restrict__ zmask, int ldz)
-{
-    __shared__ unsigned char zero[32][CC_ZQ];
-    const int nsl = (int)meta[1] < nslices_max ? (int)meta[1] : nslices_max;
-    const int q0 = blockIdx.y * CC_ZQ, r0 = blockIdx.x * 32;
-    if (q0 >= nsl)
-        return;                                            // block-uniform
-    for (int t = threadIdx.x; t < 32 * CC_ZQ; t += 256) {
-        const int rr = t / CC_ZQ, q = q0 + t % CC_ZQ, r = r0 + rr;
-        bool z = false;
-        if (r < B && q < nsl) {
-            const float2 *p = reinterpret_cast<const float2 *>(xc + (size_t)r * ldc + 14 * q);
-            float2 v[7];
-#pragma unroll
-            for (int u = 0; u < 7; ++u)
-                v[u] = p[u];
-            z = true;
-#pragma unroll
-            for (int u = 0; u < 7; ++u)
-                z = z && (v[u].x == 0.f) && (v[u].y == 0.f);
-        }
-        zero[rr][t % CC_ZQ] = z ? 1 : 0;
-    }
-    __syncthreads();
-    if (threadIdx.x < CC_ZQ && q0 + (int)threadIdx.x < nsl) {
-        unsigned word = 0u;
-        for (int j = 0; j < 32; ++j)
-            word |= (unsigned)zero[j][threadIdx.x] << j;
-        zmask[(size_t)(q0 + threadIdx.x) * ldz + blockIdx.x] = word;
-    }
-}
-
-// Slice order for the chain kernels: a workgroup is four consecutive LOGICAL slices, and with the (c,w) stream
-// shared through LDS its barrier holds it to the slowest of them per 8 samples -- so slices that take the
-// zero-slice form about equally often should sit together.  Logical slice L works on physical slice order[L]:
-// the live slices sorted by their count of all-zero samples, descending (ties: lower slice first).  Any
-// permutation gives the same results (it only assigns chains to wavefronts).
-#define CC_ORDER_MAX 512
-__global__ __launch_bounds__(512) void cc_slice_order_kernel(const unsigned *__restrict__ zmask, int ldz, int nwords,
-                                                             unsigned *__restrict__ meta, int interleave)
-{
-    __shared__ int cnt[CC_ORDER_MAX];
-    const int nsl = (int)meta[1];
-    if (nsl > CC_ORDER_MAX)
-        return;                                   // (identity order stays)
-    const int q = threadIdx.x;
-    if (q < nsl) {
-        int c = 0;
-        for (int i = 0; i < nwords; ++i)
-            c += __popc(zmask[(size_t)q * ldz + i]);
-        cnt[q] = c;
-    }
-    __syncthreads();
-    if (q < nsl) {
-        int rank = 0;
-        for (int j = 0; j < nsl; ++j)
-            rank += (cnt[j] > cnt[q] || (cnt[j] == cnt[q] && j < q)) ? 1 : 0;
-        // interleave: workgroup k takes the slices ranked k, k + nq, k + 2 nq, k + 3 nq -- the same mix everywhere
-        int pos = rank;
-        if (interleave) {
-            const int nq = (nsl + 3) / 4;
-            pos = 4 * (rank % nq) + rank / nq;
-            if (pos >= nsl)          // ragged last quad: keep it a permutation of 0 .. nsl-1
-                pos = rank;
-        }
-        meta[16 + pos] = (unsigned)q;
     }
 }
 
@@ -229,27 +149,17 @@ static bool cc_env_enabled()
     return v != 0;
 }
 
-static bool cc_zero_path_enabled()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = std::getenv("VSOM_NO_ZERO_PATH");     // development: time the chains without the fast path
-        v = (e && e[0] == '1') ? 0 : 1;
-    }
-    return v != 0;
-}
-
 // whether this context's shapes can use the compaction at all
 bool vsom_cc_applies(const vsom_ctx *c)
 {
-    if (!cc_env_enabled() || !c->use_asm)
+    if (!cc_env_enabled())
         return false;
     if (c->transform != VSOM_STANDARD && c->transform != VSOM_MEDIAN)
         return false;
     if (c->D < 64)           // the chain / tiny kernels, and nothing worth retiring
         return false;
-    // only the lane = node assembly kernels and the MFMA shortlist consume the compaction: maps below their
-    // thresholds (launch_phase2: VSOM_CHAIN_MAX_WAVES wavefronts; launch_bmu_full: 1024 nodes) skip the passes
+    // only the lane = node chain kernels and the MFMA shortlist consume the compaction: maps below their
+    // thresholds (launch_phase2: VSOM_CHAIN_MAX_WAVES; launch_bmu_full: 1024 nodes) skip the passes
     const size_t waves = ((size_t)c->N + 63) / 64 * ((c->D + 13) / 14);
     return waves > VSOM_CHAIN_MAX_WAVES || c->N >= 1024;
 }
@@ -257,12 +167,12 @@ bool vsom_cc_applies(const vsom_ctx *c)
 static int cc_ensure(vsom_ctx *c)
 {
     if (!c->cpitch)
-        c->cpitch = ((c->D + 13) / 14 * 14 + 31) / 32 * 32;
+        c->cpitch = (c->D + 31) / 32 * 32;
     if (!c->cc_meta) {
         VSOM_HIP_CHECK(hipMalloc(&c->cc_flags, (size_t)c->xpitch * 4));
         VSOM_HIP_CHECK(hipMalloc(&c->cc_idx, (size_t)c->cpitch * 4));
         VSOM_HIP_CHECK(hipMalloc(&c->cc_inv, (size_t)c->xpitch * 4));
-        const size_t meta_bytes = 64 + 4 * ((size_t)(c->cpitch + 13) / 14 + 8);
+        const size_t meta_bytes = 64;
         VSOM_HIP_CHECK(hipMalloc(&c->cc_meta, meta_bytes));
         VSOM_HIP_CHECK(hipMemsetAsync(c->cc_meta, 0, meta_bytes, c->stream));
         VSOM_HIP_CHECK(hipHostMalloc(&c->cc_fb, 64));
@@ -289,9 +199,8 @@ static int cc_ensure(vsom_ctx *c)
 int vsom_cc_stage(vsom_ctx *c)
 {
     c->cc_valid = false;
-    c->cc_zmask_valid = false;
     // small chunks: the passes (and the model-row gather / expansion around them) cost more than a few retired
-    // slices of a short chain save; vsom_set_column_compaction moves the threshold
+    // column quads of a short chain save; vsom_set_column_compaction moves the threshold
     if (!vsom_cc_applies(c) || c->B == 0 || c->cc_min_rows < 0 || (long)c->B < c->cc_min_rows)
         return VSOM_OK;
     // feedback of earlier chunks (pinned memory, read without synchronising: stale values only delay the decision)
@@ -299,7 +208,7 @@ int vsom_cc_stage(vsom_ctx *c)
     if (fb && fb[1] != c->cc_seen) {
         c->cc_seen = fb[1];
         const unsigned kc = fb[0];
-        if (kc + 14 > c->D)          // not even one 14-dim slice to retire
+        if ((kc + 3) / 4 >= (c->D + 3) / 4)      // not even one column quad to retire
             c->cc_skip = 8;
     }
     if (c->cc_skip > 0) {
@@ -316,48 +225,8 @@ int vsom_cc_stage(vsom_ctx *c)
                        c->cc_inv, c->cc_meta, c->cc_fb);
     hipLaunchKernelGGL(cc_gather_rows_kernel, dim3((unsigned)c->B), dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->Xc,
                        (int)c->cpitch, c->cc_idx, (int)c->B);
-    c->cc_zmask_valid = false;        // built on demand by vsom_cc_ensure_zmask
     VSOM_HIP_CHECK(hipGetLastError());
     c->cc_valid = true;
-    return VSOM_OK;
-}
-
-// zero-slice mask of the gathered chunk, built once per chunk when a Standard phase 2 asks for it
-int vsom_cc_ensure_zmask(vsom_ctx *c)
-{
-    if (c->cc_zmask_valid)
-        return VSOM_OK;
-    if (!c->cc_valid || !cc_zero_path_enabled())
-        return VSOM_OK;
-    const size_t nslm = (c->D + 13) / 14, ldz = (c->B + 31) / 32 + 2, need = nslm * ldz;
-    if (need > c->cc_zmask_cap) {
-        if (c->cc_zmask) {
-            VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
-            VSOM_HIP_CHECK(hipFree(c->cc_zmask));
-        }
-        c->cc_zmask = nullptr;
-        c->cc_zmask_cap = 0;
-        VSOM_HIP_CHECK(hipMalloc(&c->cc_zmask, need * 4));
-        c->cc_zmask_cap = need;
-    }
-    VSOM_HIP_CHECK(hipMemsetAsync(c->cc_zmask, 0, need * 4, c->stream));
-    hipLaunchKernelGGL(cc_zmask_kernel, dim3((unsigned)((c->B + 31) / 32), (unsigned)((nslm + CC_ZQ - 1) / CC_ZQ)), dim3(256), 0,
-                       c->stream, c->Xc, (int)c->cpitch, (int)c->B, (int)nslm, c->cc_meta, c->cc_zmask, (int)ldz);
-    // measured and left OFF: with the slices sorted every workgroup is homogeneous, but the workgroups then differ
-    // from each other as much as they can, and the launch got 1-3 % slower in all three arithmetics (C3 update
-    // strict 4.45 -> 4.51, sigma-contracted 3.81 -> 3.93, contracted 3.20 -> 3.27 ms); the opposite, every workgroup
-    // the same mix (interleaved ranks), is within noise of the raster order (4.42 / 3.89 / 3.23 vs 4.47 / 3.88 / 3.22).
-    // VSOM_SLICE_ORDER=1 (sorted) / 2 (interleaved) enable them
-    static int order_env = -1;
-    if (order_env < 0) {
-        const char *e = std::getenv("VSOM_SLICE_ORDER");
-        order_env = e ? std::atoi(e) : 0;
-    }
-    if (order_env && nslm <= CC_ORDER_MAX)
-        hipLaunchKernelGGL(cc_slice_order_kernel, dim3(1), dim3(512), 0, c->stream, c->cc_zmask, (int)ldz,
-                           (int)((c->B + 31) / 32), c->cc_meta, order_env == 2 ? 1 : 0);
-    VSOM_HIP_CHECK(hipGetLastError());
-    c->cc_zmask_valid = true;
     return VSOM_OK;
 }
 

@@ -28,10 +28,6 @@ typedef unsigned long long u64;
 // kernel ~2.2e-13 s per (node, dim, sample): they meet near N*D = 4e5 (tools/exp/chain_crossover.py:
 // 4096 x 128: 0.99 vs 1.12 ms at B = 8192; 4096 x 64: ~2 vs 0.75 ms at B = 16384)
 #define VSOM_CHAIN_MAX_WAVES 448
-// ... and up to this many lane = node wavefronts (one resident round of 7 per SIMD) the lane = (node, four dims)
-// kernels of gen_nq_asm.py run instead: their small equal workgroups balance where 1.75-3.5 whole wavefronts per
-// SIMD cannot (BASELINE config 2; the node shards of config 3's multi-GPU split)
-#define VSOM_NQ_MAX_WAVES 7168
 
 #define VSOM_TK 32          // K-chunk of the tile kernels; row pitches are multiples of it
 
@@ -104,14 +100,10 @@ struct vsom_ctx {
     double *lutd = nullptr; size_t lutd_cap = 0; double lutd_sigma = -1.0;   // online path (double)
 
     // hand-scheduled update kernel (code object loaded with hipModuleLoadData)
-    void *upd_module = nullptr, *upd_fn16 = nullptr, *upd_fn14 = nullptr, *upd_fma16 = nullptr, *upd_fma14 = nullptr,
-         *upd_clr8 = nullptr, *upd_med16 = nullptr, *upd_med14 = nullptr, *upd_sfma16 = nullptr, *upd_sfma14 = nullptr, *upd_lds14[4] = {nullptr, nullptr, nullptr, nullptr}, *upd_lds16[4] = {nullptr, nullptr, nullptr, nullptr},
-         *upd_nq[4] = {nullptr, nullptr, nullptr, nullptr}, *upd_nt[4] = {nullptr, nullptr, nullptr, nullptr};   // lane = (node, four dims) kernels (gen_nq_asm.py): std, fma, sfma, med
+    void *upd_module = nullptr, *upd_clr8 = nullptr, *upd_nt[4] = {nullptr, nullptr, nullptr, nullptr};   // nt: std, fma, sfma, med
     int update_mode = VSOM_UPDATE_STRICT;
-    bool use_asm = true;
     bool use_chain = true;
     bool use_tiny = true;           // one-launch epoch for tiny maps (VSOM_NO_TINY=1 disables, debugging)
-    int cw_mode = 0;                // 0 role-split kernel, 1 quad kernel, 2 16-lane kernel (VSOM_CW_MODE, debugging)
 
     // column compaction (vsom_compact.hip): columns that are zero in every row of the chunk are retired exactly
     unsigned *cc_flags = nullptr;   // [xpitch] live flags
@@ -127,8 +119,6 @@ struct vsom_ctx {
     float *Xc = nullptr; size_t Xc_cap = 0;      // (Bcap + VSOM_ROW_PAD) x cpitch
     float *Mc = nullptr;            // N x cpitch: model rows on the live columns (search)
     float *Uc_map = nullptr, *Uc_S = nullptr;    // N x cpitch: the chains' M and raw S on the live columns
-    unsigned *cc_zmask = nullptr; size_t cc_zmask_cap = 0;   // [slice][ceil(B/32)+2] all-zero (sample, slice) bits
-    bool cc_zmask_valid = false;
     // the chunk transposed into column quads (vsom_xq.hip) for the lane = node, four-dims-per-wavefront chain kernels
     float *Xq = nullptr; size_t Xq_cap = 0;      // [quads rounded up to 8][bpad] float4
     unsigned *zq = nullptr;                      // [quads][bpad / 32] all-zero (sample, quad) bits
@@ -189,7 +179,6 @@ int ensure_lut(vsom_ctx *c, double sigma);
 bool vsom_cc_applies(const vsom_ctx *c);
 int vsom_cc_stage(vsom_ctx *c);
 int vsom_cc_gather_map(vsom_ctx *c);
-int vsom_cc_ensure_zmask(vsom_ctx *c);
 int vsom_cc_ensure_update_scratch(vsom_ctx *c);
 int vsom_cc_expand(vsom_ctx *c, size_t n0, size_t nloc);
 int vsom_xq_ensure(vsom_ctx *c);                                 // vsom_xq.hip

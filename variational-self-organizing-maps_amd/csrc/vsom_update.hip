@@ -11,22 +11,16 @@
 //   cwp_kernel   : the neighbourhood chain per node: LUT lookup of w (the double exp is tabulated on
 //                  the host over (|dx|,|dy|), bit-identical), the serial fp32 prefix sum W and
 //                  c = w/W -> cw[j][i] = (c, w).  Role-split workgroups: one wavefront only adds,
-//                  eight look up / divide / store (cw_kernel / cw16_kernel are the earlier
-//                  redundant-chain versions, kept behind VSOM_CW_MODE for comparison).
-//   update_*     : the N*D chains.
-//                  - vsom_update_{std,fma,med}_rd{14,16}_gfx950, vsom_update_clr_rp8_gfx950: hand-scheduled
-//                    code object (gen_update_asm.py): lane = node, RD dims (8 CLR pairs) per lane in
-//                    VGPRs, x rows through scalar loads (SGPR operands of v_pk_* ops), a ring of
-//                    (c,w) loads always in flight, x rows prefetched into L2.  A ragged depth is
-//                    covered by a 16/14 column split or by a last slice that runs into the rows'
-//                    zero padding (vsom_update_split; the padding is re-zeroed afterwards).  `med`:
-//                    the Median sign from packed clamped multiplications, bit-identical (compute_median).
-//                  - update_kernel, update_clr_kernel (VSOM_NO_ASM, and depths the assembly kernels do not
-//                    cover): the same decomposition in HIP, sample pairs software-pipelined.
-//                  - update_chain_kernel: one lane per (node, dim) chain for maps too small to fill
-//                    the chip with lane = node.
-//                  Every fp32 operation is rounded separately (-ffp-contract=off), so the result is
-//                  bit-identical to the reference's SSE2 build (VSOM_UPDATE_FMA opts out, 1e-5).
+//                  eight look up / divide / store.
+//   the N*D chains, hand-scheduled code object (one rounding per fp32 operation as the reference's SSE2
+//   build rounds it, so bit-identical; VSOM_UPDATE_FMA / _FMA_SIGMA opt out for Standard, include/vsom_hip.h):
+//                  - vsom_update_{std,sfma,fma,med}_nt4_gfx950 (gen_nt_asm.py): Standard / Median, lane = node,
+//                    one column quad per wavefront, x from scalar loads of the transposed chunk (vsom_xq.hip)
+//                    as SGPR operands of v_pk_*, (c,w) staged once per workgroup through LDS, the 5-operation
+//                    step for all-zero quads.
+//                  - vsom_update_clr_rp8_gfx950 (gen_update_asm.py): CLR, lane = node, 8 parameter pairs per lane.
+//                  - update_chain3_kernel (HIP, below): maps too small to fill the chip with lane = node
+//                    (C4: 64x64x32): one lane per (node, dim pair) chain, operands staged through LDS.
 //   sigma_finalize_kernel : sigmaMap = sqrt(S / W) for the columns the assembly kernels left as S
 //                  (+ zeroes of the padding columns a ragged last slice wrote).
 #include "vsom_device.hpp"
@@ -34,15 +28,8 @@
 #include <cstdlib>
 #include <mutex>
 
-// (c,w) layout: pair-interleaved, float2 at ((j>>1)*ldn + node)*2 + (j&1), i.e. one float4
-// {c_j, w_j, c_j+1, w_j+1} per node and sample pair -- the assembly kernel (gen_update_asm.py)
-// fetches it with one global_load_dwordx4 per two samples.
-__device__ __forceinline__ size_t cw2_index(int j, int ldn, int nl)
-{
-    return (((size_t)(j >> 1) * ldn + nl) << 1) + (j & 1);
-}
-
-typedef const __attribute__((address_space(4))) float *vsom_cfp;   // forces s_load_* (scalar cache)
+// (c,w) layout: pair-interleaved, one float4 {c_j, w_j, c_j+1, w_j+1} per node and sample pair at
+// [(j>>1)][node] -- the chain kernels stage it with 16-byte loads.
 
 __global__ void bxy_kernel(const u64 *__restrict__ lastbmu, int B, int W, int H,
                            int2 *__restrict__ bxy)
@@ -53,144 +40,6 @@ __global__ void bxy_kernel(const u64 *__restrict__ lastbmu, int B, int W, int H,
     int x, y;
     vsom_somindex(lastbmu[j], (u64)W, (u64)H, x, y);
     bxy[j] = make_int2(x, y);
-}
-
-// Neighbourhood chain.  Only the fp32 prefix sum W_j = W_{j-1} + w_j is inherently serial; the
-// table lookup of w and the division c = w/W are not.  A quad of 4 lanes serves one node: lane q
-// of the quad looks up / divides / stores the samples j = 4r+q, while all four lanes run the
-// same serial chain redundantly (w of the other lanes arrives through DPP quad broadcasts), so
-// no lane ever waits for a cross-lane hand-off.  16 nodes per wavefront, N/16 wavefronts.
-#define CWR 4   // rounds (of 4 samples) in flight per loop iteration
-template <bool LUT_LDS>
-__global__ __launch_bounds__(256) void cw_kernel(const int2 *__restrict__ bxy, int B, int n0, int n1,
-                                                 int W, int H, const float *__restrict__ lut,
-                                                 int lutw, int luth, float2 *__restrict__ cw, int ldn,
-                                                 float *__restrict__ weight)
-{
-    extern __shared__ float slut[];
-    if (LUT_LDS) {
-        for (int i = threadIdx.x; i < lutw * luth; i += blockDim.x)
-            slut[i] = lut[i];
-        __syncthreads();
-    }
-    const float *tab = LUT_LDS ? slut : lut;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = gid & 3;
-    const int nl = gid >> 2;
-    const int node = n0 + nl;
-    const bool valid = node < n1;
-    int cx = 0, cy = 0;
-    if (valid)
-        vsom_somindex((u64)node, (u64)W, (u64)H, cx, cy);   // SomIndex(*this, index) (Som.cpp:816)
-    float run = 0.f;                                         // sumOfWeights :840
-    const int nlo = valid ? nl : 0;
-    const int Bq = B & ~3;
-    int j = 0;
-    for (; j + 4 * CWR <= Bq; j += 4 * CWR) {
-        float w[CWR], Wm[CWR];
-#pragma unroll
-        for (int r = 0; r < CWR; ++r) {
-            int2 b = bxy[j + 4 * r + q];
-            int dx = cx - b.x, dy = cy - b.y;
-            dx = dx < 0 ? -dx : dx;
-            dy = dy < 0 ? -dy : dy;
-            w[r] = tab[dy * lutw + dx];      // (float)calculateNeighbourhoodWeight(...)  :851
-        }
-#pragma unroll
-        for (int r = 0; r < CWR; ++r) {
-            // samples 4r..4r+3 in order; every lane of the quad runs the same additions
-            float w0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w[r]), 0x00, 0xF, 0xF, true));
-            float w1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w[r]), 0x55, 0xF, 0xF, true));
-            float w2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w[r]), 0xAA, 0xF, 0xF, true));
-            float w3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, w[r]), 0xFF, 0xF, 0xF, true));
-            float W0 = run + w0;             // :857
-            float W1 = W0 + w1;
-            float W2 = W1 + w2;
-            float W3 = W2 + w3;
-            run = W3;
-            Wm[r] = q == 0 ? W0 : (q == 1 ? W1 : (q == 2 ? W2 : W3));
-        }
-        if (valid) {
-#pragma unroll
-            for (int r = 0; r < CWR; ++r)
-                cw[cw2_index(j + 4 * r + q, ldn, nlo)] = make_float2(w[r] / Wm[r], w[r]);   // c = w/W :864 (0/0 -> NaN, Q7)
-        }
-    }
-    for (; j < B; ++j) {   // tail, every lane of the quad redundantly; lane 0 stores
-        int2 b = bxy[j];
-        int dx = cx - b.x, dy = cy - b.y;
-        dx = dx < 0 ? -dx : dx;
-        dy = dy < 0 ? -dy : dy;
-        float w = tab[dy * lutw + dx];
-        run = run + w;
-        if (valid && q == 0)
-            cw[cw2_index(j, ldn, nlo)] = make_float2(w / run, w);
-    }
-    if (valid && q == 0)
-        weight[node] = run;   // :875
-}
-
-// Same chain with 16 lanes per node (4 nodes per wavefront, N/4 wavefronts) for maps too small to
-// occupy the chip with quads: lane q of a group looks up / divides / stores sample j+q of each
-// round of 16; the serial prefix runs redundantly in all 16 lanes, fed by ds_bpermute broadcasts.
-template <bool LUT_LDS>
-__global__ __launch_bounds__(256) void cw16_kernel(const int2 *__restrict__ bxy, int B, int n0, int n1,
-                                                   int W, int H, const float *__restrict__ lut,
-                                                   int lutw, int luth, float2 *__restrict__ cw, int ldn,
-                                                   float *__restrict__ weight)
-{
-    extern __shared__ float slut[];
-    if (LUT_LDS) {
-        for (int i = threadIdx.x; i < lutw * luth; i += blockDim.x)
-            slut[i] = lut[i];
-        __syncthreads();
-    }
-    const float *tab = LUT_LDS ? slut : lut;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = gid & 15;
-    const int nl = gid >> 4;
-    const int node = n0 + nl;
-    const bool valid = node < n1;
-    int cx = 0, cy = 0;
-    if (valid)
-        vsom_somindex((u64)node, (u64)W, (u64)H, cx, cy);   // SomIndex(*this, index) (Som.cpp:816)
-    float run = 0.f;                                         // sumOfWeights :840
-    const int nlo = valid ? nl : 0;
-    const int B16 = B & ~15;
-    int j = 0;
-    int2 b = B16 > 0 ? bxy[q] : make_int2(0, 0);
-    for (; j < B16; j += 16) {
-        int dx = cx - b.x, dy = cy - b.y;
-        dx = dx < 0 ? -dx : dx;
-        dy = dy < 0 ? -dy : dy;
-        const float w = tab[dy * lutw + dx];     // (float)calculateNeighbourhoodWeight(...)  :851
-        if (j + 16 < B16)
-            b = bxy[j + 16 + q];
-        float wk[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            wk[k] = __shfl(w, k, 16);
-        float Wm = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            run = run + wk[k];                   // :857, samples j..j+15 in order
-            Wm = q == k ? run : Wm;
-        }
-        if (valid)
-            cw[cw2_index(j + q, ldn, nlo)] = make_float2(w / Wm, w);   // c = w/W :864 (0/0 -> NaN, Q7)
-    }
-    for (; j < B; ++j) {   // tail, every lane of the group redundantly; lane 0 stores
-        int2 bb = bxy[j];
-        int dx = cx - bb.x, dy = cy - bb.y;
-        dx = dx < 0 ? -dx : dx;
-        dy = dy < 0 ? -dy : dy;
-        float w = tab[dy * lutw + dx];
-        run = run + w;
-        if (valid && q == 0)
-            cw[cw2_index(j, ldn, nlo)] = make_float2(w / run, w);
-    }
-    if (valid && q == 0)
-        weight[node] = run;   // :875
 }
 
 // Role-split neighbourhood chain: one workgroup (9 wavefronts) serves NW nodes and walks the chunk
@@ -343,354 +192,7 @@ __global__ __launch_bounds__(CWP_THREADS) void cwp_kernel(const int2 *__restrict
         weight[n0 + nl] = run;                   // :875
 }
 
-// Eigen scalar_sign_op<float> (Transformation.cpp:50) as the chains need it: +-1 for a nonzero
-// number, NaN for NaN, and the argument itself for +-0.  The reference yields +0 for -0; inside the
-// chains the difference cannot surface: t = c*s is -0 instead of +0 (or NaN either way when c is
-// NaN/inf), M + (-0) == M + (+0) because M is never -0 (it starts at +0 and x + y is -0 only for
-// -0 + -0), and (w*s)*s is +0 either way.  Three VALU ops (v_bfi, v_cmp_lg, v_cndmask) instead of
-// five -- the sign is what the Median kernels spend their time on.
-__device__ __forceinline__ float vsom_sign(float a)
-{
-    const float one = __builtin_copysignf(1.f, a);
-    return (a < 0.f || a > 0.f) ? one : a;
-}
-
-// (w * s) * s of the sigma^2 accumulation (Som.cpp:867) when s = sign(..) is -1, +-0, +1 or NaN and w a
-// finite weight >= 0: both products are exact, and equal w * |s| -- w for +-1, +0 for +-0 (w*(-0) = -0,
-// (-0)*(-0) = +0), NaN for NaN.  One multiplication with a source modifier instead of two.
-__device__ __forceinline__ float vsom_median_sq(float w, float s)
-{
-    return w * __builtin_fabsf(s);
-}
-
-// Standard / Median: lane = node, RD dims per lane, 4 waves per workgroup = 4 dim slices
-template <int RD, bool MEDIAN>
-__global__ __launch_bounds__(256) void update_kernel(const float *__restrict__ Xs, int ldx,
-                                                     const float2 *__restrict__ cw, int ldn, int B,
-                                                     int n0, int nloc, int D, int nslices, int dbase,
-                                                     float *__restrict__ map,
-                                                     float *__restrict__ sigma, int pitch,
-                                                     const float *__restrict__ weight)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int slice = blockIdx.y * 4 + wave;
-    if (slice >= nslices)
-        return;
-    const int d0 = dbase + slice * RD;   // dbase: first dim not covered by the assembly kernel
-    const int nl = blockIdx.x * 64 + lane;
-    const bool valid = nl < nloc;
-    const int nlc = valid ? nl : nloc - 1;
-
-    float M[RD], S[RD];
-#pragma unroll
-    for (int k = 0; k < RD; ++k) {
-        M[k] = 0.f;   // currentModel.setZero()       :843
-        S[k] = 0.f;   // currentModelSigma.setZero()  :844
-    }
-    vsom_cfp xr = (vsom_cfp)(Xs + d0);
-    const float4 *cp = (const float4 *)cw + nlc;     // {c_j, w_j, c_j+1, w_j+1} of pair row r at cp[r * ldn]
-    // Sample pairs, software-pipelined: the scalar loads of x and the (c,w) load of pair r+1 are
-    // issued before pair r is consumed (two register sets used alternately).  Reads one pair past
-    // the chunk at most: Xs has B + VSOM_ROW_PAD rows, cw ceil(B/2)+8 pair rows.
-    auto load = [&](float (&xa)[RD], float (&xb)[RD], float4 &cv, int r) {
-        vsom_cfp p0 = xr + (size_t)(2 * r) * ldx;
-        vsom_cfp p1 = p0 + ldx;
-#pragma unroll
-        for (int k = 0; k < RD; ++k) {
-            xa[k] = p0[k];
-            xb[k] = p1[k];
-        }
-        cv = cp[(size_t)r * ldn];
-    };
-    auto step = [&](const float (&x)[RD], float c, float w) {
-#pragma unroll
-        for (int k = 0; k < RD; ++k) {
-            float dl = x[k] - M[k];         // Stepper: value - model        (Transformation.cpp:12)
-            if (MEDIAN)
-                dl = vsom_sign(dl);         //          sign(value - model)  (Transformation.cpp:50)
-            float t = c * dl;
-            M[k] = M[k] + t;                // :864
-            float u = w * dl;           // (packed: v_pk_mul_f32 has no |x| modifier, so no vsom_median_sq here)
-            u = u * dl;
-            S[k] = S[k] + u;                // :867
-        }
-    };
-    const int npair = B >> 1;
-    float xa0[RD], xa1[RD], xb0[RD], xb1[RD];
-    float4 ca, cb;
-    load(xa0, xa1, ca, 0);
-    int r = 0;
-    for (; r + 2 <= npair; r += 2) {
-        load(xb0, xb1, cb, r + 1);
-        step(xa0, ca.x, ca.y);
-        step(xa1, ca.z, ca.w);
-        load(xa0, xa1, ca, r + 2);
-        step(xb0, cb.x, cb.y);
-        step(xb1, cb.z, cb.w);
-    }
-    if (r < npair) {                       // one more full pair (set a holds it)
-        load(xb0, xb1, cb, r + 1);
-        step(xa0, ca.x, ca.y);
-        step(xa1, ca.z, ca.w);
-        if (B & 1)
-            step(xb0, cb.x, cb.y);         // odd tail sample = first half of the next pair row
-    } else if (B & 1) {
-        step(xa0, ca.x, ca.y);
-    }
-    if (valid) {
-        const size_t node = (size_t)(n0 + nl);
-        const float Wf = weight[node];
-#pragma unroll
-        for (int k = 0; k < RD; ++k) {
-            if (d0 + k < D) {
-                map[node * pitch + d0 + k] = M[k];                   // :870
-                sigma[node * pitch + d0 + k] = sqrtf(S[k] / Wf);     // :873
-            }
-        }
-    }
-}
-
-// Standard / Median on maps whose node count cannot fill the chip with lane = node (fewer than a
-// few hundred wavefronts, e.g. C4: 64x64x32): lane = one (node, dim) chain.  A group of DL =
-// 2^dl_log2 consecutive lanes covers DL consecutive dims of one node (x is a coalesced row
-// segment, (c,w) a same-address broadcast), 256/DL nodes per workgroup, blockIdx.y = dim slice.
-// Loads of the next U samples are issued before the current U are consumed.  Same fp32 operation
-// sequence per chain as update_kernel, so the results are bit-identical.
-template <bool MEDIAN, int U, int FMA>
-__global__ __launch_bounds__(256) void update_chain_kernel(const float *__restrict__ Xs, int ldx,
-                                                           const float2 *__restrict__ cw, int ldn, int B,
-                                                           int n0, int nloc, int D, int dl_log2,
-                                                           float *__restrict__ map,
-                                                           float *__restrict__ sigma, int pitch,
-                                                           const float *__restrict__ weight)
-{
-    static_assert(U % 2 == 0, "pairs of samples share one float4 of (c,w)");
-    const int DL = 1 << dl_log2;
-    const int nl = blockIdx.x * (256 >> dl_log2) + ((int)threadIdx.x >> dl_log2);
-    const int d = blockIdx.y * DL + ((int)threadIdx.x & (DL - 1));
-    const bool valid = nl < nloc && d < D;
-    const int nlc = nl < nloc ? nl : nloc - 1;
-    const int dc = d < D ? d : D - 1;
-
-    const float *xp = Xs + dc;
-    const float4 *cp = (const float4 *)cw + nlc;      // pair row r at cp[r * ldn]
-    float M = 0.f, S = 0.f;                           // :843-844
-
-    // two register sets used alternately (no copies): while one is consumed the loads of the
-    // following group are already in flight into the other
-    float xa[U], xb[U];
-    float4 ca[U / 2], cb[U / 2];
-    const int nfull = B / U;
-    auto load = [&](float (&x)[U], float4 (&cv)[U / 2], int g) {
-        // clamped to the last full group: re-reads it, never past the buffers
-        g = g < nfull ? g : nfull - 1;
-        const float *xq = xp + (size_t)g * U * ldx;
-        const float4 *cq = cp + (size_t)g * (U / 2) * ldn;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            x[u] = xq[(size_t)u * ldx];
-#pragma unroll
-        for (int u = 0; u < U / 2; ++u)
-            cv[u] = cq[(size_t)u * ldn];
-    };
-    auto steps = [&](const float (&x)[U], const float4 (&cv)[U / 2]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float c = (u & 1) ? cv[u >> 1].z : cv[u >> 1].x;
-            const float w = (u & 1) ? cv[u >> 1].w : cv[u >> 1].y;
-            float dl = x[u] - M;            // Stepper (Transformation.cpp:12 / :50)
-            if (MEDIAN)
-                dl = vsom_sign(dl);
-            if (FMA == 1) {                 // opt-in contracted arithmetic (VSOM_UPDATE_FMA)
-                M = __builtin_fmaf(c, dl, M);
-                S = __builtin_fmaf(w * dl, dl, S);
-            } else if (FMA == 2 && !MEDIAN) {   // VSOM_UPDATE_FMA_SIGMA: the mean chain strict, only S contracted
-                float t = c * dl;
-                M = M + t;
-                S = __builtin_fmaf(w * dl, dl, S);
-            } else {
-                float t = c * dl;
-                M = M + t;                  // :864
-                float s;
-                if (MEDIAN) {
-                    s = vsom_median_sq(w, dl);
-                } else {
-                    s = w * dl;
-                    s = s * dl;
-                }
-                S = S + s;                  // :867
-            }
-        }
-    };
-    if (nfull > 0)
-        load(xa, ca, 0);
-    int g = 0;
-    for (; g + 2 <= nfull; g += 2) {
-        load(xb, cb, g + 1);
-        steps(xa, ca);
-        load(xa, ca, g + 2);
-        steps(xb, cb);
-    }
-    if (g < nfull)
-        steps(xa, ca);
-    for (int j = nfull * U; j < B; ++j) {
-        const float2 v = cw[cw2_index(j, ldn, nlc)];
-        float dl = xp[(size_t)j * ldx] - M;
-        if (MEDIAN)
-            dl = vsom_sign(dl);
-        if (FMA == 1) {
-            M = __builtin_fmaf(v.x, dl, M);
-            S = __builtin_fmaf(v.y * dl, dl, S);
-        } else if (FMA == 2 && !MEDIAN) {
-            float t = v.x * dl;
-            M = M + t;
-            S = __builtin_fmaf(v.y * dl, dl, S);
-        } else {
-            float t = v.x * dl;
-            M = M + t;
-            float s;
-            if (MEDIAN) {
-                s = vsom_median_sq(v.y, dl);
-            } else {
-                s = v.y * dl;
-                s = s * dl;
-            }
-            S = S + s;
-        }
-    }
-    if (valid) {
-        const size_t node = (size_t)(n0 + nl);
-        const float Wf = weight[node];
-        map[node * pitch + d] = M;                   // :870
-        sigma[node * pitch + d] = sqrtf(S / Wf);     // :873
-    }
-}
-
-// The same chains with TWO dims per lane (packed fp32 arithmetic) for the shapes where even lane = (node, dim)
-// yields no more than two wavefronts per SIMD (C4: 64x64x32): half the wavefronts, each with a ring of
-// NG groups of U samples of loads in flight -- a single wavefront per SIMD has the registers for it (up to
-// 512) and nothing else to cover the L2 / HBM latency with.  Median: the sign through clamped
-// multiplications (see gen_update_asm.py, compute_median: p = [delta > 0], n = [delta < 0], exact fused
-// accumulation, bit-identical); the clamp must pass NaN, so the kernel switches DX10_CLAMP off for itself.
 typedef float vsom_f2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ vsom_f2 vsom_pk_mul_clamp(vsom_f2 a, vsom_f2 b)
-{
-    vsom_f2 r;
-    asm volatile("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ vsom_f2 vsom_pk_mul_negclamp(vsom_f2 a, vsom_f2 b)
-{
-    vsom_f2 r;
-    asm volatile("v_pk_mul_f32 %0, %1, %2 neg_lo:[1,0] neg_hi:[1,0] clamp" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-template <bool MEDIAN, int U, int NG, int FMA>
-__global__ __launch_bounds__(256, 1) void update_chain2_kernel(const float *__restrict__ Xs, int ldx,
-                                                               const float2 *__restrict__ cw, int ldn, int B,
-                                                               int n0, int nloc, int D, int dl_log2,
-                                                               float *__restrict__ map,
-                                                               float *__restrict__ sigma, int pitch,
-                                                               const float *__restrict__ weight)
-{
-    static_assert(U % 2 == 0, "pairs of samples share one float4 of (c,w)");
-    if (MEDIAN)
-        asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 8, 1), 0");   // DX10_CLAMP off: clamp(NaN) = NaN
-    const int DL = 1 << dl_log2;                       // dim PAIRS per node row of the workgroup
-    const int nl = blockIdx.x * (256 >> dl_log2) + ((int)threadIdx.x >> dl_log2);
-    const int dp = blockIdx.y * DL + ((int)threadIdx.x & (DL - 1));
-    const int d = 2 * dp;                              // rows are zero padded to a multiple of 32: d+1 is readable
-    const bool valid = nl < nloc && d < D;
-    const int nlc = nl < nloc ? nl : nloc - 1;
-    const int dc = d < D ? d : (D - 1) & ~1;
-
-    const float *xp = Xs + dc;
-    const float4 *cp = (const float4 *)cw + nlc;      // pair row r at cp[r * ldn]
-    vsom_f2 M = {0.f, 0.f}, S = {0.f, 0.f};            // :843-844
-    const vsom_f2 big = {0x1.0p100f, 0x1.0p100f};
-
-    vsom_f2 x[NG][U];
-    float4 cv[NG][U / 2];
-    const int nfull = B / U;
-    auto load = [&](int slot, int g) {
-        g = g < nfull ? g : nfull - 1;                 // clamped: re-reads the last full group, never past the buffers
-        const float *xq = xp + (size_t)g * U * ldx;
-        const float4 *cq = cp + (size_t)g * (U / 2) * ldn;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            x[slot][u] = *reinterpret_cast<const vsom_f2 *>(xq + (size_t)u * ldx);
-#pragma unroll
-        for (int u = 0; u < U / 2; ++u)
-            cv[slot][u] = cq[(size_t)u * ldn];
-    };
-    auto one = [&](vsom_f2 xv, float c, float w) {
-        const vsom_f2 cc = {c, c}, ww = {w, w};
-        vsom_f2 dl = xv - M;                           // Stepper (Transformation.cpp:12 / :50)
-        if (MEDIAN) {
-            const vsom_f2 t = dl * big;
-            const vsom_f2 pp = vsom_pk_mul_clamp(t, big), nn = vsom_pk_mul_negclamp(t, big);
-            M = __builtin_elementwise_fma(cc, pp, M);  // exact products: rounds like mul + add (:864)
-            M = __builtin_elementwise_fma(-cc, nn, M);
-            S = __builtin_elementwise_fma(ww, pp, S);  // (:867)
-            S = __builtin_elementwise_fma(ww, nn, S);
-        } else if (FMA == 1) {
-            M = __builtin_elementwise_fma(cc, dl, M);
-            S = __builtin_elementwise_fma(ww * dl, dl, S);
-        } else if (FMA == 2) {                         // VSOM_UPDATE_FMA_SIGMA: mean chain strict
-            const vsom_f2 t = cc * dl;
-            M = M + t;
-            S = __builtin_elementwise_fma(ww * dl, dl, S);
-        } else {
-            const vsom_f2 t = cc * dl;
-            M = M + t;                                 // :864
-            vsom_f2 q = ww * dl;
-            q = q * dl;
-            S = S + q;                                 // :867
-        }
-    };
-    auto steps = [&](int slot) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float c = (u & 1) ? cv[slot][u >> 1].z : cv[slot][u >> 1].x;
-            const float w = (u & 1) ? cv[slot][u >> 1].w : cv[slot][u >> 1].y;
-            one(x[slot][u], c, w);
-        }
-    };
-    if (nfull > 0) {
-#pragma unroll
-        for (int k = 0; k < NG - 1; ++k)
-            load(k, k);
-    }
-    int g = 0;
-    for (; g + NG <= nfull; g += NG) {
-#pragma unroll
-        for (int k = 0; k < NG; ++k) {
-            load((k + NG - 1) % NG, g + k + NG - 1);   // NG-1 groups ahead of the one consumed next
-            steps(k);
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NG - 1; ++k)                   // the (< NG) full groups left are already in their slots
-        if (g + k < nfull)
-            steps(k);
-    for (int j = nfull * U; j < B; ++j) {
-        const float2 v = cw[cw2_index(j, ldn, nlc)];
-        one(*reinterpret_cast<const vsom_f2 *>(xp + (size_t)j * ldx), v.x, v.y);
-    }
-    if (valid) {
-        const size_t node = (size_t)(n0 + nl);
-        const float Wf = weight[node];
-        map[node * pitch + d] = M.x;                   // :870
-        sigma[node * pitch + d] = sqrtf(S.x / Wf);     // :873
-        if (d + 1 < D) {
-            map[node * pitch + d + 1] = M.y;
-            sigma[node * pitch + d + 1] = sqrtf(S.y / Wf);
-        }
-    }
-}
 
 // StandardMedianEstimator steps of EIGHT consecutive samples for one lane's packed (dim, dim+1) chains, as one
 // hand-scheduled block (update_chain3_kernel runs ONE wavefront per SIMD, where a single wavefront issues an
@@ -746,10 +248,10 @@ __device__ __forceinline__ void vsom_median_step1(vsom_f2 &M, vsom_f2 &S, vsom_f
                  : [x0] "v"(xs), [c0] "v"(cw), [k24] "s"(k24), [k127] "s"(k127));
 }
 
-// update_chain2_kernel with the operands staged ONCE per workgroup through LDS.  In chain2 every wavefront
-// issues, per sample, a 512-byte x load and half a 1-KB (c,w) load whose lanes mostly repeat addresses --
-// the vector-memory pipe processes every lane's address and return slot, and that, not arithmetic, bounded
-// it (C4: Median and Standard both 0.86 ms).  Here the 256 lanes of a workgroup (NW = 256 >> PLOG nodes x
+// Chains of the maps too small for lane = node (C4: 64x64x32 = 65 536 packed chains): lane = (node, dim pair),
+// packed arithmetic, operands staged ONCE per workgroup through LDS.  (Loading them per lane straight from
+// global memory -- a 512-byte x load and half a 1-KB (c,w) load per wavefront and sample whose lanes mostly
+// repeat addresses -- was bound by the vector-memory pipe, not by arithmetic: C4 0.86 ms.)  The 256 lanes of a workgroup (NW = 256 >> PLOG nodes x
 // PL = 1 << PLOG dim pairs) fetch each block of CT samples with 16-byte loads that touch every byte once
 // (x: CT rows of PL pairs; (c,w): CT/2 pair rows of NW nodes), two blocks ahead of the one being consumed
 // (registers -> LDS ring of three), and the chains read their operands from LDS as broadcasts.
@@ -833,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void update_chain3_kernel(const float *__re
     } while (0)
 
     vsom_f2 M = {0.f, 0.f}, S = {0.f, 0.f};               // :843-844
-    auto one = [&](vsom_f2 xv, float c, float w) {        // Standard; the same operations as update_chain2_kernel's
+    auto one = [&](vsom_f2 xv, float c, float w) {        // Standard, one sample
         const vsom_f2 cc = {c, c}, ww = {w, w};           // (Median: vsom_median_steps8 / vsom_median_step1 on x * 2^24)
         vsom_f2 dl = xv - M;
         if (MEDIAN) {
@@ -938,108 +440,6 @@ __global__ __launch_bounds__(256, 1) void update_chain3_kernel(const float *__re
 #undef VSOM_C3_LOAD
 #undef VSOM_C3_STORE
 
-// CLR: lane = node, RP pairs per lane; model = [A | B] (Transformation.cpp:107-142)
-template <int RP>
-__global__ __launch_bounds__(256) void update_clr_kernel(const float *__restrict__ XP,
-                                                         const float *__restrict__ YP, int ldx,
-                                                         const float2 *__restrict__ cw, int ldn,
-                                                         int B, int n0, int nloc, int P, int ppitch,
-                                                         int nslices, int pbase, float *__restrict__ map,
-                                                         float *__restrict__ sigma, int pitch,
-                                                         const float *__restrict__ weight)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int slice = blockIdx.y * 4 + wave;
-    if (slice >= nslices)
-        return;
-    const int p0 = pbase + slice * RP;   // pbase: first pair not covered by the assembly kernel
-    const int nl = blockIdx.x * 64 + lane;
-    const bool valid = nl < nloc;
-    const int nlc = valid ? nl : nloc - 1;
-
-    float A[RP], Bv[RP], SA[RP], SB[RP];
-#pragma unroll
-    for (int k = 0; k < RP; ++k) {
-        A[k] = 0.f;
-        Bv[k] = 0.f;
-        SA[k] = 0.f;
-        SB[k] = 0.f;
-    }
-    vsom_cfp xr = (vsom_cfp)(XP + p0);
-    vsom_cfp yr = (vsom_cfp)(YP + p0);
-    const float4 *cp = (const float4 *)cw + nlc;
-    // same software pipeline as update_kernel: loads of sample pair r+1 in flight while pair r is used
-    auto load = [&](float (&xa)[RP], float (&ya)[RP], float (&xb)[RP], float (&yb)[RP], float4 &cv, int r) {
-        vsom_cfp px0 = xr + (size_t)(2 * r) * ldx, py0 = yr + (size_t)(2 * r) * ldx;
-        vsom_cfp px1 = px0 + ldx, py1 = py0 + ldx;
-#pragma unroll
-        for (int k = 0; k < RP; ++k) {
-            xa[k] = px0[k];
-            ya[k] = py0[k];
-            xb[k] = px1[k];
-            yb[k] = py1[k];
-        }
-        cv = cp[(size_t)r * ldn];
-    };
-    auto step = [&](const float (&x)[RP], const float (&y)[RP], float c, float w) {
-#pragma unroll
-        for (int k = 0; k < RP; ++k) {
-            const float xp = x[k], yp = y[k];
-            float inner = A[k] * xp;       // A.*x' + B - y'   (Transformation.cpp:129)
-            inner = inner + Bv[k];
-            inner = inner - yp;
-            float m2 = -2.f * inner;       // -2*inner (exact)  :135-136
-            float aD = m2 * xp;            // aDelta            :135
-            float tA = c * aD;
-            float tB = c * m2;
-            float uA = w * aD;
-            uA = uA * aD;
-            float uB = w * m2;
-            uB = uB * m2;
-            A[k] = A[k] + tA;              // Som.cpp:864
-            Bv[k] = Bv[k] + tB;
-            SA[k] = SA[k] + uA;            // Som.cpp:867
-            SB[k] = SB[k] + uB;
-        }
-    };
-    const int npair = B >> 1;
-    float xa0[RP], ya0[RP], xa1[RP], ya1[RP], xb0[RP], yb0[RP], xb1[RP], yb1[RP];
-    float4 ca, cb;
-    load(xa0, ya0, xa1, ya1, ca, 0);
-    int r = 0;
-    for (; r + 2 <= npair; r += 2) {
-        load(xb0, yb0, xb1, yb1, cb, r + 1);
-        step(xa0, ya0, ca.x, ca.y);
-        step(xa1, ya1, ca.z, ca.w);
-        load(xa0, ya0, xa1, ya1, ca, r + 2);
-        step(xb0, yb0, cb.x, cb.y);
-        step(xb1, yb1, cb.z, cb.w);
-    }
-    if (r < npair) {
-        load(xb0, yb0, xb1, yb1, cb, r + 1);
-        step(xa0, ya0, ca.x, ca.y);
-        step(xa1, ya1, ca.z, ca.w);
-        if (B & 1)
-            step(xb0, yb0, cb.x, cb.y);
-    } else if (B & 1) {
-        step(xa0, ya0, ca.x, ca.y);
-    }
-    if (valid) {
-        const size_t node = (size_t)(n0 + nl);
-        const float Wf = weight[node];
-#pragma unroll
-        for (int k = 0; k < RP; ++k) {
-            if (p0 + k < P) {
-                map[node * pitch + p0 + k] = A[k];
-                map[node * pitch + ppitch + p0 + k] = Bv[k];
-                sigma[node * pitch + p0 + k] = sqrtf(SA[k] / Wf);
-                sigma[node * pitch + ppitch + p0 + k] = sqrtf(SB[k] / Wf);
-            }
-        }
-    }
-}
-
 // sigmaMap[i] = sqrt(S / W)  (Som.cpp:873) for the columns the assembly kernels left as raw S.
 // One workgroup per node row, 8-byte accesses (ncols is even: 14/16 dims or 8 pairs per slice).
 // When the last slice ran over the end of the part (ncols > nvalid: it read the zero padding of the
@@ -1074,68 +474,21 @@ __global__ __launch_bounds__(256) void sigma_finalize_kernel(float *__restrict__
     }
 }
 
-// hand-scheduled gfx950 code object (gen_update_asm.py -> vsom_update_gfx950.s -> .hsaco),
+// hand-scheduled gfx950 code object (gen_update_asm.py + gen_nt_asm.py -> vsom_update_gfx950.s -> .hsaco),
 // embedded at build time
 static const unsigned char vsom_update_hsaco[] = {
 #include "vsom_update_hsaco.inc"
 };
 
-// Column split of the Standard assembly update: n16 slices of 16 dims followed by n14 slices of 14,
-// covering D (rounded up to even: one padding column) exactly when 16*n16 + 14*n14 has a solution --
-// every even count >= 84 has one -- choosing the fewest idle wavefront slots (workgroups carry 4 slices)
-// and then the most 14-wide slices (the faster kernel: 784 = 56 * 14 tiles the chip with no tail).
-// Otherwise one kernel whose ragged last slice runs into the padding (limit = usable row pitch).
-// VSOM_UPD_SPLIT="n16,n14" overrides (development).
-static void vsom_update_split(unsigned D, unsigned limit, unsigned &n16, unsigned &n14)
-{
-    static int env16 = -2, env14 = -2;
-    if (env16 == -2) {
-        env16 = env14 = -1;
-        if (const char *e = getenv("VSOM_UPD_SPLIT"))
-            if (sscanf(e, "%d,%d", &env16, &env14) != 2)
-                env16 = env14 = -1;
-    }
-    if (env16 >= 0 && env14 >= 0 && (unsigned)(16 * env16 + 14 * env14) >= D &&
-        (unsigned)(16 * env16 + 14 * env14) <= limit) {
-        n16 = (unsigned)env16;
-        n14 = (unsigned)env14;
-        return;
-    }
-    const unsigned De = (D + 1) & ~1u;
-    int best = -1;
-    for (unsigned b = 0; 16 * b <= De; ++b) {
-        const unsigned rem = De - 16 * b;
-        if (rem % 14)
-            continue;
-        const unsigned a = rem / 14;
-        const int idle = (int)((4 - a % 4) % 4 + (4 - b % 4) % 4);
-        const int score = 1000000 - idle * 10000 + (int)a;      // fewest idle slots, then most 14-wide slices
-        if (score > best) {
-            best = score;
-            n16 = b;
-            n14 = a;
-        }
-    }
-    if (best >= 0 && De <= limit)
-        return;
-    const unsigned s14 = (D + 13) / 14, s16 = (D + 15) / 16;
-    n16 = n14 = 0;
-    if (s14 * 14 <= limit && s14 * 14 <= s16 * 16)
-        n14 = s14;
-    else if (s16 * 16 <= limit)
-        n16 = s16;
-}
-
-#define VSOM_UPD_LDS_DEFAULT 1
-
+// kernarg segment shared by the hand-scheduled kernels (80 bytes; the CLR kernel reads the first 72)
 struct UpdAsmArgs {
-    const void *xs;
+    const void *xs;                  // nt: Xq (vsom_xq.hip); CLR: x' rows
     const void *cw2;
     void *map;
     void *sbuf;
     unsigned ldx_bytes, ldn_bytes, B, nloc, nslices, pitch_bytes, n0, ppitch_bytes;   // ppitch: CLR only
-    const void *yp;                  // CLR: y' rows; Standard / Median: live-slice record of the compaction or null
-    const void *zmask;               // Standard family: all-zero (sample, slice) bit mask or null (kernarg 80 B)
+    const void *yp;                  // CLR: y' rows; nt: live-column record of the compaction or null
+    const void *zq;                  // nt: all-zero (sample, quad) bit mask
 };
 
 int vsom_load_asm_module(vsom_ctx *c)
@@ -1143,51 +496,22 @@ int vsom_load_asm_module(vsom_ctx *c)
     if (c->upd_module)
         return VSOM_OK;
     hipModule_t mod;
-    if (const char *alt = std::getenv("VSOM_ASM_HSACO")) {   // development: time a variant code object (tools/exp)
+#ifdef VSOM_DEVELOPMENT
+    if (const char *alt = std::getenv("VSOM_ASM_HSACO")) {   // time a variant code object (tools/exp/mk_variant.sh)
         VSOM_HIP_CHECK(hipModuleLoad(&mod, alt));
     } else
+#endif
     VSOM_HIP_CHECK(hipModuleLoadData(&mod, vsom_update_hsaco));
-    hipFunction_t f16, f14, m16, m14, fclr, d16, d14, sf16, sf14, l14[4], l16[4];
-    VSOM_HIP_CHECK(hipModuleGetFunction(&f16, mod, "vsom_update_std_rd16_gfx950"));
-    VSOM_HIP_CHECK(hipModuleGetFunction(&f14, mod, "vsom_update_std_rd14_gfx950"));
-    VSOM_HIP_CHECK(hipModuleGetFunction(&m16, mod, "vsom_update_fma_rd16_gfx950"));
-    VSOM_HIP_CHECK(hipModuleGetFunction(&m14, mod, "vsom_update_fma_rd14_gfx950"));
-    VSOM_HIP_CHECK(hipModuleGetFunction(&sf16, mod, "vsom_update_sfma_rd16_gfx950"));
-    VSOM_HIP_CHECK(hipModuleGetFunction(&sf14, mod, "vsom_update_sfma_rd14_gfx950"));
-    static const char *const lds_names[4] = {"std", "fma", "sfma", "med"};
+    hipFunction_t f;
+    VSOM_HIP_CHECK(hipModuleGetFunction(&f, mod, "vsom_update_clr_rp8_gfx950"));
+    c->upd_clr8 = f;
+    static const char *const nt_names[4] = {"std", "fma", "sfma", "med"};
     for (int i = 0; i < 4; ++i) {
-        const std::string n14 = std::string("vsom_update_") + lds_names[i] + "_rd14_lds_gfx950",
-                          n16 = std::string("vsom_update_") + lds_names[i] + "_rd16_lds_gfx950";
-        VSOM_HIP_CHECK(hipModuleGetFunction(&l14[i], mod, n14.c_str()));
-        VSOM_HIP_CHECK(hipModuleGetFunction(&l16[i], mod, n16.c_str()));
-    }
-    VSOM_HIP_CHECK(hipModuleGetFunction(&fclr, mod, "vsom_update_clr_rp8_gfx950"));
-    VSOM_HIP_CHECK(hipModuleGetFunction(&d16, mod, "vsom_update_med_rd16_gfx950"));
-    VSOM_HIP_CHECK(hipModuleGetFunction(&d14, mod, "vsom_update_med_rd14_gfx950"));
-    c->upd_module = mod;
-    c->upd_fn16 = f16;
-    c->upd_fn14 = f14;
-    c->upd_fma16 = m16;
-    c->upd_fma14 = m14;
-    c->upd_sfma16 = sf16;
-    c->upd_sfma14 = sf14;
-    for (int i = 0; i < 4; ++i) {
-        c->upd_lds14[i] = l14[i];
-        c->upd_lds16[i] = l16[i];
-    }
-    c->upd_clr8 = fclr;
-    c->upd_med16 = d16;
-    c->upd_med14 = d14;
-    static const char *const nq_names[4] = {"std", "fma", "sfma", "med"};
-    for (int i = 0; i < 4; ++i) {
-        hipFunction_t f;
-        const std::string n = std::string("vsom_update_") + nq_names[i] + "_nq32_gfx950";
+        const std::string n = std::string("vsom_update_") + nt_names[i] + "_nt4_gfx950";
         VSOM_HIP_CHECK(hipModuleGetFunction(&f, mod, n.c_str()));
-        c->upd_nq[i] = f;
-        const std::string n2 = std::string("vsom_update_") + nq_names[i] + "_nt4_gfx950";
-        VSOM_HIP_CHECK(hipModuleGetFunction(&f, mod, n2.c_str()));
         c->upd_nt[i] = f;
     }
+    c->upd_module = mod;
     return VSOM_OK;
 }
 
@@ -1271,18 +595,14 @@ __global__ void zero_weight_kernel(float *__restrict__ weight, int n0, int nloc)
         weight[n0 + i] = 0.f;
 }
 
-// lane = node assembly kernels need wavefronts: ceil(nodes/64) * ceil(D/14) of them for 1024 SIMDs.  Below
-// this many the chain kernels (lane = (node, dim pair), operands through LDS) are faster although they pay
-// an LDS read per operand where the assembly kernels take x from SGPRs (measured crossover, DESIGN.md
-// section 4; VSOM_CHAIN_MAX_WAVES overrides, development)
-static size_t vsom_chain_max_waves()
+// Maps whose node shard times depth is small (ceil(nodes/64) * ceil(D/14) <= VSOM_CHAIN_MAX_WAVES, the measured
+// crossover against lane = node kernels, vsom_internal.hpp) take the small-map chain kernel, lane = (node, dim
+// pair): C4's 64x64x32 map would give the quad kernels half a wavefront per SIMD.
+static bool vsom_use_chain(const vsom_ctx *c, size_t nloc)
 {
-    static long v = -1;
-    if (v < 0) {
-        const char *e = std::getenv("VSOM_CHAIN_MAX_WAVES");
-        v = e ? std::atol(e) : VSOM_CHAIN_MAX_WAVES;
-    }
-    return (size_t)v;
+    if (!c->use_chain || c->transform == VSOM_CLR)
+        return false;
+    return ((nloc + 63) / 64) * ((c->D + 13) / 14) <= VSOM_CHAIN_MAX_WAVES;
 }
 
 int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
@@ -1304,15 +624,15 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         return rc;
     const size_t nloc = n1 - n0;
     const size_t ldn = (nloc + 63) / 64 * 64;
-    // pair rows: ceil(B/2) + the prefetch ring of the assembly kernel (4) + slack
-    const size_t prow = (c->B + 1) / 2 + 24;   // (the LDS-sharing kernels fetch three groups of four pair-rows ahead)
+    // pair rows: ceil(B/2) + what the kernels' staging reads ahead (one block of 16 pair-rows) + slack
+    const size_t prow = (c->B + 1) / 2 + 24;
     const size_t need = prow * ldn * 2;   // float2 elements
     if (need > c->cw_cap) {
         if (c->cw)
             VSOM_HIP_CHECK(hipFree(c->cw));
         c->cw = nullptr;
         VSOM_HIP_CHECK(hipMalloc(&c->cw, need * sizeof(float2)));
-        // rows beyond B are prefetched (never used): keep them initialised
+        // rows beyond B are staged (never used): keep them initialised
         VSOM_HIP_CHECK(hipMemsetAsync(c->cw, 0, need * sizeof(float2), c->stream));
         c->cw_cap = need;
     }
@@ -1320,349 +640,117 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         TimerScope ts(c, VSOM_T_CW);
         hipLaunchKernelGGL(bxy_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, c->stream,
                            c->lastbmu, (int)c->B, (int)c->W, (int)c->H, c->bxy);
+        // role-split kernel, 16 nodes per workgroup; the table in LDS only while it is small: what counts is how
+        // many workgroups (worker wavefronts) a CU holds -- 40 KB of tiles each; a 64-KB table (128x128 map) would
+        // leave one per CU.  Measured at C3: 64 nodes + LDS table 0.153 ms, 32 + global 0.142, 16 + global 0.121,
+        // 16 + LDS 0.20.
         const size_t lut_bytes = (size_t)c->lut_w * c->lut_h * sizeof(float);
-        bool piped = false;
-        if (c->cw_mode == 0) {
-            // role-split kernel: NW nodes per workgroup so that the grid still covers the CUs
-            // 16 nodes per workgroup and the table in LDS only while it is small: what counts is how
-            // many workgroups (worker wavefronts) a CU holds -- 40 KB of tiles each; a 64-KB table
-            // (128x128 map) would leave one per CU.  Measured at C3: 64 nodes + LDS table 0.153 ms,
-            // 32 + global 0.142, 16 + global 0.121, 16 + LDS 0.20.
-            bool lds = lut_bytes <= 24 * 1024;
-            int nw = 16;
-            if (const char *e = std::getenv("VSOM_CW_NW"))      // development knobs
-                nw = std::atoi(e) == 64 ? 64 : (std::atoi(e) == 32 ? 32 : 16);
-            if (const char *e = std::getenv("VSOM_CW_LUT_GLOBAL"))
-                lds = e[0] == '1' ? false : (e[0] == '0' ? lut_bytes <= 96 * 1024 : lds);
-            const int T = 2048 / nw;
-            const size_t smem = (size_t)5 * 2048 * sizeof(float) + (size_t)3 * T * sizeof(int2) + (lds ? lut_bytes : 0);
-            const void *fn = nw == 64 ? (lds ? (const void *)cwp_kernel<64, 32, true> : (const void *)cwp_kernel<64, 32, false>)
-                           : nw == 32 ? (lds ? (const void *)cwp_kernel<32, 64, true> : (const void *)cwp_kernel<32, 64, false>)
-                                      : (lds ? (const void *)cwp_kernel<16, 128, true> : (const void *)cwp_kernel<16, 128, false>);
-            if (smem <= 64 * 1024 ||
-                hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess) {
-                const int2 *bxy = c->bxy;
-                int B = (int)c->B, in0 = (int)n0, in1 = (int)n1, iW = (int)c->W, iH = (int)c->H, lw = (int)c->lut_w,
-                    lh = (int)c->lut_h, ildn = (int)ldn;
-                const float *lut = c->lut;
-                float2 *cwp = c->cw;
-                float *wgt = c->weight;
-                void *args[] = {&bxy, &B, &in0, &in1, &iW, &iH, &lut, &lw, &lh, &cwp, &ildn, &wgt};
-                VSOM_HIP_CHECK(hipLaunchKernel(fn, dim3((unsigned)((nloc + nw - 1) / nw)), dim3(CWP_THREADS), args, smem,
-                                               c->stream));
-                piped = true;
-            } else {
-                (void)hipGetLastError();
-            }
-        }
-        if (!piped) {
-            const bool lds = lut_bytes <= 64 * 1024;
-            // quads give nloc/16 wavefronts; below one per SIMD use 16 lanes per node (nloc/4 wavefronts)
-            const bool wide = c->cw_mode == 2 || (c->cw_mode != 1 && nloc / 16 < 1024 && c->B >= 64);
-            auto kern = wide ? (lds ? cw16_kernel<true> : cw16_kernel<false>) : (lds ? cw_kernel<true> : cw_kernel<false>);
-            const size_t lanes = nloc * (wide ? 16 : 4);
-            hipLaunchKernelGGL(kern, dim3((unsigned)((lanes + 255) / 256)), dim3(256), lds ? lut_bytes : 0, c->stream,
-                               c->bxy, (int)c->B, (int)n0, (int)n1, (int)c->W, (int)c->H, c->lut, (int)c->lut_w,
-                               (int)c->lut_h, c->cw, (int)ldn, c->weight);
-        }
-        VSOM_HIP_CHECK(hipGetLastError());
+        const bool lds = lut_bytes <= 24 * 1024;
+        constexpr int nw = 16, T = 2048 / nw;
+        const size_t smem = (size_t)5 * 2048 * sizeof(float) + (size_t)3 * T * sizeof(int2) + (lds ? lut_bytes : 0);
+        const void *fn = lds ? (const void *)cwp_kernel<nw, T, true> : (const void *)cwp_kernel<nw, T, false>;
+        if (smem > 64 * 1024)
+            VSOM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const int2 *bxy = c->bxy;
+        int B = (int)c->B, in0 = (int)n0, in1 = (int)n1, iW = (int)c->W, iH = (int)c->H, lw = (int)c->lut_w,
+            lh = (int)c->lut_h, ildn = (int)ldn;
+        const float *lut = c->lut;
+        float2 *cwp = c->cw;
+        float *wgt = c->weight;
+        void *args[] = {&bxy, &B, &in0, &in1, &iW, &iH, &lut, &lw, &lh, &cwp, &ildn, &wgt};
+        VSOM_HIP_CHECK(hipLaunchKernel(fn, dim3((unsigned)((nloc + nw - 1) / nw)), dim3(CWP_THREADS), args, smem, c->stream));
     }
-    int sig_cols = 0;   // columns left as raw S by the assembly kernel
+    int sig_cols = 0;   // > 0: columns left as raw S by the kernel; < 0: the compaction's scratch rows hold M and raw S
     {
         TimerScope ts(c, VSOM_T_UPDATE);
         const unsigned gx = (unsigned)((nloc + 63) / 64);
+        if ((rc = vsom_load_asm_module(c)))
+            return rc;
         if (c->transform == VSOM_CLR) {
-            constexpr int RP = 8;
-            int pbase = 0;
-            if (c->use_asm) {
-                // hand-scheduled kernel for the full 8-pair slices (gen_update_asm.py, KC)
-                if ((rc = vsom_load_asm_module(c)))
-                    return rc;
-                const unsigned nfull = (c->part_len + RP - 1) / RP;   // a ragged last slice runs over the padding
-                if (nfull * RP <= c->part_pitch) {
-                    UpdAsmArgs a;
-                    a.xs = c->XP;
-                    a.cw2 = c->cw;
-                    a.map = c->map;
-                    a.sbuf = c->sigma;
-                    a.ldx_bytes = c->part_pitch * 4u;
-                    a.ldn_bytes = (unsigned)(ldn * 16u);
-                    a.B = (unsigned)c->B;
-                    a.nloc = (unsigned)nloc;
-                    a.nslices = nfull;
-                    a.pitch_bytes = c->pitch * 4u;
-                    a.n0 = (unsigned)n0;
-                    a.ppitch_bytes = c->part_pitch * 4u;
-                    a.yp = c->YP;
-                    a.zmask = nullptr;
-                    size_t sz = 72;          // kernarg segment of the CLR kernel
-                    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
-                                     HIP_LAUNCH_PARAM_END};
-                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)c->upd_clr8, 8 * ((nfull + 3) / 4), (gx + 7) / 8, 1,
-                                                         256, 1, 1, 0, c->stream, nullptr, extra));
-                    pbase = (int)c->part_len;
-                    sig_cols = (int)(nfull * RP);
-                }
-            }
-            const int rest = (int)c->part_len - pbase;
-            if (rest > 0) {
-                const int nsl = (rest + RP - 1) / RP;
-                dim3 grid(gx, (unsigned)((nsl + 3) / 4));
-                hipLaunchKernelGGL(update_clr_kernel<RP>, grid, dim3(256), 0, c->stream, c->XP, c->YP,
-                                   (int)c->part_pitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
-                                   (int)c->part_len, (int)c->part_pitch, nsl, pbase, c->map, c->sigma,
-                                   (int)c->pitch, c->weight);
-            }
-        } else if ((size_t)gx * ((c->D + 13) / 14) <= vsom_chain_max_waves() && c->use_chain) {
-            // lane = node would leave most SIMDs idle: one lane per (node, dim pair) chain instead
-            int dl_log2 = 0;
-            while ((1u << dl_log2) < c->D && dl_log2 < 6)
-                ++dl_log2;
-            const unsigned DL = 1u << dl_log2;
-            constexpr int U = 8;
-            // lanes = nloc * D chains; when that is no more than two wavefronts per SIMD, two dims per lane
-            // with a deep load ring (update_chain2_kernel) beat one dim per lane (VSOM_CHAIN2=0/1 overrides)
-            static int chain2_env = -1;
-            if (chain2_env < 0) {
-                const char *e = std::getenv("VSOM_CHAIN2");
-                chain2_env = e ? (e[0] == '1' ? 1 : 0) : 2;
-            }
-            const bool chain2 = chain2_env != 0;   // VSOM_CHAIN2=0: r1's one-dim-per-lane kernel (development)
-            if (chain2) {
-                int pl_log2 = 0;                               // dim pairs per node row of the workgroup
-                while ((2u << pl_log2) < c->D && pl_log2 < 6)
-                    ++pl_log2;
-                const unsigned PL = 1u << pl_log2, npairs = (c->D + 1) / 2;
-                dim3 grid2((unsigned)((nloc + (256 / PL) - 1) / (256 / PL)), (npairs + PL - 1) / PL);
-                constexpr int NG = 4;
-                const bool med = c->transform == VSOM_MEDIAN, fma = c->update_mode == VSOM_UPDATE_FMA,
-                           sfma = c->update_mode == VSOM_UPDATE_FMA_SIGMA;
-                static int chain3_env = -1;                    // VSOM_CHAIN3=0: the register-ring kernel (development)
-                if (chain3_env < 0) {
-                    const char *e = std::getenv("VSOM_CHAIN3");
-                    chain3_env = e && e[0] == '0' ? 0 : 1;
-                }
-                const void *k3 = nullptr;                      // operands staged through LDS: 8..64 dim pairs per row
+            // lane = node, 8 parameter pairs per wavefront (gen_update_asm.py); a ragged last slice runs over the
+            // parts' zero padding (part_pitch is a multiple of 32)
+            constexpr unsigned RP = 8;
+            const unsigned nsl = (c->part_len + RP - 1) / RP;
+            UpdAsmArgs a;
+            a.xs = c->XP;
+            a.cw2 = c->cw;
+            a.map = c->map;
+            a.sbuf = c->sigma;
+            a.ldx_bytes = c->part_pitch * 4u;
+            a.ldn_bytes = (unsigned)(ldn * 16u);
+            a.B = (unsigned)c->B;
+            a.nloc = (unsigned)nloc;
+            a.nslices = nsl;
+            a.pitch_bytes = c->pitch * 4u;
+            a.n0 = (unsigned)n0;
+            a.ppitch_bytes = c->part_pitch * 4u;
+            a.yp = c->YP;
+            a.zq = nullptr;
+            size_t sz = 72;
+            void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+            VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)c->upd_clr8, 8 * ((nsl + 3) / 4), (gx + 7) / 8, 1, 256, 1, 1, 0,
+                                                 c->stream, nullptr, extra));
+            sig_cols = (int)(nsl * RP);
+        } else if (vsom_use_chain(c, nloc)) {
+            // small maps: one lane per (node, dim pair) chain, operands staged through LDS (update_chain3_kernel);
+            // at least 8 dim pairs per node row (lanes past the depth idle)
+            int pl_log2 = 3;
+            while ((2u << pl_log2) < c->D && pl_log2 < 6)
+                ++pl_log2;
+            const unsigned PL = 1u << pl_log2, npairs = (c->D + 1) / 2;
+            dim3 grid2((unsigned)((nloc + (256 / PL) - 1) / (256 / PL)), (npairs + PL - 1) / PL);
+            const bool med = c->transform == VSOM_MEDIAN, fma = c->update_mode == VSOM_UPDATE_FMA,
+                       sfma = c->update_mode == VSOM_UPDATE_FMA_SIGMA;
 #define VSOM_K3(P) (med ? (const void *)update_chain3_kernel<true, 0, P> \
                         : (fma ? (const void *)update_chain3_kernel<false, 1, P>                    \
                                : (sfma ? (const void *)update_chain3_kernel<false, 2, P> : (const void *)update_chain3_kernel<false, 0, P>)))
-                if (chain3_env && pl_log2 >= 3 && pl_log2 <= 6)
-                    k3 = pl_log2 == 3 ? VSOM_K3(3) : pl_log2 == 4 ? VSOM_K3(4) : pl_log2 == 5 ? VSOM_K3(5) : VSOM_K3(6);
+            const void *k3 = pl_log2 == 3 ? VSOM_K3(3) : pl_log2 == 4 ? VSOM_K3(4) : pl_log2 == 5 ? VSOM_K3(5) : VSOM_K3(6);
 #undef VSOM_K3
-                if (k3) {
-                    const float *xs_ = c->Xs;
-                    const float2 *cw_ = c->cw;
-                    int ildx = (int)c->xpitch, ildn = (int)ldn, iB = (int)c->B, in0 = (int)n0, inl = (int)nloc, iD = (int)c->D,
-                        ipitch = (int)c->pitch;
-                    float *map_ = c->map, *sg_ = c->sigma;
-                    const float *wt_ = c->weight;
-                    void *args[] = {&xs_, &ildx, &cw_, &ildn, &iB, &in0, &inl, &iD, &map_, &sg_, &ipitch, &wt_};
-                    VSOM_HIP_CHECK(hipLaunchKernel(k3, grid2, dim3(256), args, 0, c->stream));
-                } else {
-                auto kern2 = med ? update_chain2_kernel<true, U, NG, 0>
-                                 : (fma ? update_chain2_kernel<false, U, NG, 1>
-                                        : (sfma ? update_chain2_kernel<false, U, NG, 2> : update_chain2_kernel<false, U, NG, 0>));
-                hipLaunchKernelGGL(kern2, grid2, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->cw, (int)ldn,
-                                   (int)c->B, (int)n0, (int)nloc, (int)c->D, pl_log2, c->map, c->sigma,
-                                   (int)c->pitch, c->weight);
-                }
-            } else {
-            dim3 grid((unsigned)((nloc + (256 / DL) - 1) / (256 / DL)), (c->D + DL - 1) / DL);
-            auto kern = c->transform == VSOM_MEDIAN ? update_chain_kernel<true, U, 0>
-                        : (c->update_mode == VSOM_UPDATE_FMA ? update_chain_kernel<false, U, 1>
-                           : (c->update_mode == VSOM_UPDATE_FMA_SIGMA ? update_chain_kernel<false, U, 2>
-                                                                      : update_chain_kernel<false, U, 0>));
-            hipLaunchKernelGGL(kern, grid, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->cw, (int)ldn,
-                               (int)c->B, (int)n0, (int)nloc, (int)c->D, dl_log2, c->map, c->sigma,
-                               (int)c->pitch, c->weight);
-            }
+            const float *xs_ = c->Xs;
+            const float2 *cw_ = c->cw;
+            int ildx = (int)c->xpitch, ildn = (int)ldn, iB = (int)c->B, in0 = (int)n0, inl = (int)nloc, iD = (int)c->D,
+                ipitch = (int)c->pitch;
+            float *map_ = c->map, *sg_ = c->sigma;
+            const float *wt_ = c->weight;
+            void *args[] = {&xs_, &ildx, &cw_, &ildn, &iB, &in0, &inl, &iD, &map_, &sg_, &ipitch, &wt_};
+            VSOM_HIP_CHECK(hipLaunchKernel(k3, grid2, dim3(256), args, 0, c->stream));
         } else {
-            constexpr int RD = 16;
-            int dbase = 0;
-            if ((c->transform == VSOM_STANDARD || c->transform == VSOM_MEDIAN) && c->use_asm) {
-                // hand-scheduled kernels (Standard strict / contracted, Median), 16 or 14 dims per wavefront: the first n16 slices by the
-                // 16-wide kernel, the following n14 by the 14-wide one on the side stream (the two run
-                // concurrently; vsom_update_split picks the pair).  Columns past D are the zero padding
-                // of the rows; sigma_finalize_kernel re-zeroes them afterwards.
-                if ((rc = vsom_load_asm_module(c)))
-                    return rc;
-                unsigned n16 = 0, n14 = 0;
-                vsom_update_split(c->D, c->pitch < c->xpitch ? c->pitch : c->xpitch, n16, n14);
-                const bool fma = c->update_mode == VSOM_UPDATE_FMA, sfma = c->update_mode == VSOM_UPDATE_FMA_SIGMA;
-                const bool med = c->transform == VSOM_MEDIAN;     // its FMAs are exact: one kernel for all modes
-                void *fn16 = med ? c->upd_med16 : (fma ? c->upd_fma16 : (sfma ? c->upd_sfma16 : c->upd_fn16));
-                void *fn14 = med ? c->upd_med14 : (fma ? c->upd_fma14 : (sfma ? c->upd_sfma14 : c->upd_fn14));
-                // 14-dim Standard kernels whose workgroup shares ONE (c,w) stream through LDS (gen_update_asm.py,
-                // "lds"): a quarter of the L2 requests (VSOM_UPD_LDS=0/1 overrides the choice, development)
-                static int lds_env = -1;
-                if (lds_env < 0) {
-                    const char *e = std::getenv("VSOM_UPD_LDS");
-                    lds_env = e ? (e[0] == '1' ? 1 : 0) : 2;
-                }
-                // Measured (strict, 784 dims, B = 4096): 16384 nodes (two rounds of 7 wavefronts per SIMD) update 4.56 ->
-                // 4.46 ms, sigma-contracted 4.16 -> 3.91, contracted 3.50 -> 3.30, Median 6.37 -> 5.96; 8192 nodes (one
-                // round) 2.36 vs 2.37; 4096 nodes 1.50 -> 1.53; 2048 nodes 0.81 -> 0.88 -- the barriers cost more than the
-                // L2 requests once a SIMD holds few wavefronts, so the shared stream is used from one full round up.
-                const bool use_lds = lds_env == 1 || (lds_env == 2 && VSOM_UPD_LDS_DEFAULT &&
-                                                      (size_t)gx * ((c->D + 13) / 14) > 7168);
-                if (use_lds) {
-                    const int v = med ? 3 : (fma ? 1 : (sfma ? 2 : 0));
-                    fn14 = c->upd_lds14[v];
-                    fn16 = c->upd_lds16[v];
-                }
-                // lane = (node, four dims) kernels (gen_nq_asm.py) where lane = node has too few wavefronts to balance
-                // (VSOM_UPD_NQ=0/1 overrides the choice: tests/test_gpu_nq_kernels.py runs the suite's shapes through them)
-                static int nq_env = -1;
-                if (nq_env < 0) {
-                    const char *e = std::getenv("VSOM_UPD_NQ");
-                    nq_env = e ? (e[0] == '1' ? 1 : 0) : 2;
-                }
-                // lane = node, four dims per wavefront, x from scalar loads of the transposed chunk (gen_nt_asm.py)
-                static int nt_env = -1;
-                if (nt_env < 0) {
-                    const char *e = std::getenv("VSOM_UPD_NT");
-                    nt_env = e ? (e[0] == '1' ? 1 : 0) : 2;
-                }
-                const bool use_nt = nt_env != 0;
-                const bool use_nq = !use_nt && (nq_env == 1 || (nq_env == 2 && (size_t)gx * ((c->D + 13) / 14) <= VSOM_NQ_MAX_WAVES));
-                // column compaction (vsom_compact.hip): the chains of the columns that are zero in every row of
-                // the chunk are retired -- the 14-wide kernel runs on the gathered live columns (device-side
-                // slice count) into dense scratch rows and cc_expand_kernel writes map / sigmaMap back
-                const bool compact = c->cc_valid;
-                if (compact && (rc = vsom_cc_ensure_update_scratch(c)))
-                    return rc;
-                // Standard chains: (sample, slice) blocks that are all zero take the form without the subtraction
-                const bool zpath = compact && c->transform == VSOM_STANDARD && !use_nq && !use_nt;
-                if (zpath && (rc = vsom_cc_ensure_zmask(c)))
-                    return rc;
-                auto launch = [&](void *fn, unsigned nsl, unsigned col0, hipStream_t st) -> int {
-                    UpdAsmArgs a;
-                    a.xs = compact ? c->Xc : c->Xs + col0;
-                    a.cw2 = c->cw;
-                    a.map = compact ? c->Uc_map : c->map + col0;
-                    a.sbuf = compact ? c->Uc_S : c->sigma + col0;
-                    a.ldx_bytes = (compact ? c->cpitch : c->xpitch) * 4u;
-                    a.ldn_bytes = (unsigned)(ldn * 16u);
-                    a.B = (unsigned)c->B;
-                    a.nloc = (unsigned)nloc;
-                    a.nslices = nsl;
-                    a.pitch_bytes = (compact ? c->cpitch : c->pitch) * 4u;
-                    a.n0 = (unsigned)n0;
-                    a.ppitch_bytes = 0;
-                    a.yp = compact ? (const void *)c->cc_meta : nullptr;
-                    a.zmask = zpath && c->cc_zmask_valid ? (const void *)c->cc_zmask : nullptr;
-                    size_t sz = med ? 72 : 80;   // kernarg segments of the Median / Standard-family kernels
-                    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
-                                     HIP_LAUNCH_PARAM_END};
-                    // XCD-aware grid: x = 8 * slice quads, y = node groups / 8 (see gen_update_asm.py)
-                    // development: VSOM_UPD_WG_CAP=k reserves (unused) LDS so that a CU holds at most k workgroups
-                    static int wg_cap = -1;
-                    if (wg_cap < 0) {
-                        const char *e = std::getenv("VSOM_UPD_WG_CAP");
-                        wg_cap = e ? std::atoi(e) : 0;
-                    }
-                    const unsigned lds_reserve = wg_cap > 0 ? (unsigned)((160 * 1024 / wg_cap) & ~1023) : 0u;
-                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, 8 * ((nsl + 3) / 4), (gx + 7) / 8, 1, 256, 1,
-                                                         1, lds_reserve, st, nullptr, extra));
-                    return VSOM_OK;
-                };
-                if (compact) {
-                    n16 = 0;
-                    n14 = (c->D + 13) / 14;      // upper bound; the kernel reads the live count from cc_meta
-                }
-                if (use_nt) {
-                    // workgroup = 64 nodes x 8 column quads (one per wavefront); grid.x = 8 * column blocks (XCD-aware)
-                    if ((rc = vsom_xq_ensure(c)))
-                        return rc;
-                    const unsigned cols = compact ? c->cpitch : c->pitch;
-                    const unsigned quads = compact ? c->cpitch / 4 : (c->D + 3) / 4;
-                    UpdAsmArgs a;
-                    a.xs = c->Xq;
-                    a.cw2 = c->cw;
-                    a.map = compact ? c->Uc_map : c->map;
-                    a.sbuf = compact ? c->Uc_S : c->sigma;
-                    a.ldx_bytes = c->xq_bpad * 16u;
-                    a.ldn_bytes = (unsigned)(ldn * 16u);
-                    a.B = (unsigned)c->B;
-                    a.nloc = (unsigned)nloc;
-                    a.nslices = quads;
-                    a.pitch_bytes = cols * 4u;
-                    a.n0 = (unsigned)n0;
-                    a.ppitch_bytes = 0;
-                    a.yp = compact ? (const void *)c->cc_meta : nullptr;
-                    a.zmask = c->zq;
-                    size_t sz = 80;
-                    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
-                                     HIP_LAUNCH_PARAM_END};
-                    void *fn = c->upd_nt[med ? 3 : (fma ? 1 : (sfma ? 2 : 0))];
-                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, 8 * ((quads + 7) / 8), (gx + 7) / 8, 1, 512, 1, 1, 0,
-                                                         c->stream, nullptr, extra));
-                    dbase = (int)c->D;
-                    sig_cols = compact ? -1 : (int)(quads * 4);
-                } else
-                if (use_nq) {
-                    // workgroup = 32 nodes x 32 columns; grid.x = 8 * column blocks (XCD-aware, gen_nq_asm.py); the
-                    // last block of a ragged depth runs into the rows' zero padding (pitches are multiples of 32)
-                    const unsigned cols = compact ? c->cpitch : c->pitch;
-                    const unsigned nb = compact ? c->cpitch / 32 : (c->D + 31) / 32;
-                    const unsigned ng = (unsigned)((nloc + 31) / 32);
-                    UpdAsmArgs a;
-                    a.xs = compact ? c->Xc : c->Xs;
-                    a.cw2 = c->cw;
-                    a.map = compact ? c->Uc_map : c->map;
-                    a.sbuf = compact ? c->Uc_S : c->sigma;
-                    a.ldx_bytes = (compact ? c->cpitch : c->xpitch) * 4u;
-                    a.ldn_bytes = (unsigned)(ldn * 16u);
-                    a.B = (unsigned)c->B;
-                    a.nloc = (unsigned)nloc;
-                    a.nslices = nb;
-                    a.pitch_bytes = cols * 4u;
-                    a.n0 = (unsigned)n0;
-                    a.ppitch_bytes = 0;
-                    a.yp = compact ? (const void *)c->cc_meta : nullptr;
-                    a.zmask = nullptr;
-                    size_t sz = 80;
-                    void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz,
-                                     HIP_LAUNCH_PARAM_END};
-                    void *fn = c->upd_nq[med ? 3 : (fma ? 1 : (sfma ? 2 : 0))];
-                    VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, 8 * nb, (ng + 7) / 8, 1, 256, 1, 1, 0, c->stream,
-                                                         nullptr, extra));
-                    dbase = (int)c->D;
-                    sig_cols = compact ? -1 : (int)(nb * 32);
-                } else
-                if (n16 + n14 > 0) {
-                    const bool both = n16 > 0 && n14 > 0;
-                    if (both) {   // fork: the 14-wide part beside the 16-wide one
-                        VSOM_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
-                        VSOM_HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-                    }
-                    if (n16 > 0 && (rc = launch(fn16, n16, 0, c->stream)))
-                        return rc;
-                    if (n14 > 0 && (rc = launch(fn14, n14, n16 * 16, both ? c->aux_stream : c->stream)))
-                        return rc;
-                    if (both) {
-                        VSOM_HIP_CHECK(hipEventRecord(c->ev_join, c->aux_stream));
-                        c->aux_pending = true;
-                        if ((rc = vsom_join_aux(c)))
-                            return rc;
-                    }
-                    dbase = (int)c->D;
-                    sig_cols = compact ? -1 : (int)(n16 * 16 + n14 * 14);
-                }
-            }
-            const int rest = (int)c->D - dbase;
-            if (rest > 0) {
-                const int nsl = (rest + RD - 1) / RD;
-                dim3 grid(gx, (unsigned)((nsl + 3) / 4));
-                if (c->transform == VSOM_MEDIAN)
-                    hipLaunchKernelGGL((update_kernel<RD, true>), grid, dim3(256), 0, c->stream, c->Xs,
-                                       (int)c->xpitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
-                                       (int)c->D, nsl, dbase, c->map, c->sigma, (int)c->pitch, c->weight);
-                else
-                    hipLaunchKernelGGL((update_kernel<RD, false>), grid, dim3(256), 0, c->stream, c->Xs,
-                                       (int)c->xpitch, c->cw, (int)ldn, (int)c->B, (int)n0, (int)nloc,
-                                       (int)c->D, nsl, dbase, c->map, c->sigma, (int)c->pitch, c->weight);
-            }
+            // Standard / Median: lane = node, one column quad per wavefront, workgroup = 64 nodes x 8 quads, x from
+            // scalar loads of the transposed chunk (gen_nt_asm.py, vsom_xq.hip); grid.x = 8 * column blocks
+            // (XCD-aware).  With the column compaction (vsom_compact.hip) the kernel runs on the gathered live
+            // columns -- their count is a device value the kernel reads from the record -- into dense scratch rows
+            // that cc_expand_kernel writes back; otherwise a last quad of a ragged depth runs into the rows' zero
+            // padding and sigma_finalize_kernel re-zeroes it.
+            if ((rc = vsom_xq_ensure(c)))
+                return rc;
+            const bool compact = c->cc_valid;
+            if (compact && (rc = vsom_cc_ensure_update_scratch(c)))
+                return rc;
+            const bool fma = c->update_mode == VSOM_UPDATE_FMA, sfma = c->update_mode == VSOM_UPDATE_FMA_SIGMA;
+            const bool med = c->transform == VSOM_MEDIAN;     // its FMAs are exact: one kernel for all modes
+            const unsigned cols = compact ? c->cpitch : c->pitch;
+            const unsigned quads = compact ? c->cpitch / 4 : (c->D + 3) / 4;
+            UpdAsmArgs a;
+            a.xs = c->Xq;
+            a.cw2 = c->cw;
+            a.map = compact ? c->Uc_map : c->map;
+            a.sbuf = compact ? c->Uc_S : c->sigma;
+            a.ldx_bytes = c->xq_bpad * 16u;
+            a.ldn_bytes = (unsigned)(ldn * 16u);
+            a.B = (unsigned)c->B;
+            a.nloc = (unsigned)nloc;
+            a.nslices = quads;
+            a.pitch_bytes = cols * 4u;
+            a.n0 = (unsigned)n0;
+            a.ppitch_bytes = 0;
+            a.yp = compact ? (const void *)c->cc_meta : nullptr;
+            a.zq = c->zq;
+            size_t sz = 80;
+            void *extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+            void *fn = c->upd_nt[med ? 3 : (fma ? 1 : (sfma ? 2 : 0))];
+            VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, 8 * ((quads + 7) / 8), (gx + 7) / 8, 1, 512, 1, 1, 0,
+                                                 c->stream, nullptr, extra));
+            sig_cols = compact ? -1 : (int)(quads * 4);
         }
         VSOM_HIP_CHECK(hipGetLastError());
     }
