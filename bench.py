@@ -224,6 +224,33 @@ def profile_traffic(key):
     return None, None
 
 
+def profile_issue(key):
+    """(valu_issue_busy, sustained_clock_ghz) of the dominant kernel from the committed SQ counter pass
+    (profiles/traffic.json, tools/traffic_from_pmc.py) or (None, None)"""
+    try:
+        ent = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+    except Exception:
+        return None, None
+    if isinstance(ent, dict):
+        return ent.get("valu_issue_busy"), ent.get("sustained_clock_ghz")
+    return None, None
+
+
+def zero_quad_stats(X):
+    """(live columns, column quads of the live columns, fraction of (sample, quad) blocks that are all zero) of a
+    chunk: what the chain kernels (csrc/gen_nt_asm.py) actually execute -- dead columns are retired, an all-zero
+    quad's step is 5 operations per pair instead of 6"""
+    import numpy as np
+    live = np.flatnonzero((X != 0).any(axis=0))
+    if live.size == 0:
+        return 0, 0, 1.0
+    nq = (live.size + 3) // 4
+    P = np.zeros((X.shape[0], nq * 4), X.dtype)
+    P[:, :live.size] = X[:, live]
+    z = (P.reshape(X.shape[0], nq, 4) == 0).all(axis=2)
+    return int(live.size), int(nq), float(z.mean())
+
+
 ARITH_MODES = ("strict", "sigma", "contracted")
 ARITH_TEXT = {
     "strict": "strict (library default; everything bit-identical to the CPU oracle over whole schedules)",
@@ -439,23 +466,46 @@ def main():
             else:
                 flops = 6.0 * n_nodes_rank * D * sp.Bglob
             ach = flops / upd_avg_s / 1e12 if upd_avg_s > 0 else 0.0
-            kern = {capi.STANDARD: "vsom_update_{std,sfma,fma}_rd14/16[_lds]_gfx950 (phase-2 mean/sigma^2 chains, hand-scheduled)",
-                    capi.MEDIAN: "update chain kernel, median stepper (phase-2 chains)",
+            chain_small = ((n_nodes_rank + 63) // 64) * ((D + 13) // 14) <= 448      # VSOM_CHAIN_MAX_WAVES
+            kern = {capi.STANDARD: ("update_chain3_kernel (small-map phase-2 chains)" if chain_small else
+                                    "vsom_update_{std,sfma,fma}_nt4_gfx950 (phase-2 mean/sigma^2 chains, hand-scheduled)"),
+                    capi.MEDIAN: ("update_chain3_kernel<median> (small-map phase-2 chains)" if chain_small else
+                                  "vsom_update_med_nt4_gfx950 (phase-2 median chains, hand-scheduled)"),
                     capi.CLR: "vsom_update_clr_rp8_gfx950 (phase-2 CLR chains, hand-scheduled)"}[tr]
-            return {"bound": "valu_fp32", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_PEAK_TFLOPS, 4), "kernel": kern,
-                    "note": ("fp32 VALU-bound chains priced against the fp32 dense peak the vector and matrix pipes "
-                             "share (157.3 TFLOP/s counts an FMA as 2 flop); of the 6 algorithmic flop per element "
-                             "strict arithmetic (no FMA) can reach 0.5 of it, sigma-contracted 0.6, contracted 0.75.  "
-                             "`achieved` counts ALL D columns as work: columns that are zero in every row of the chunk "
-                             "are retired exactly (column_occupancy), so the fraction can exceed the issue cap"),
-                    "avg_launch_ms": round(upd_avg_s * 1e3, 4),
-                    "algorithmic_flop_per_launch": flops}
+            r = {"bound": "valu_fp32", "achieved": round(ach, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(ach / FP32_PEAK_TFLOPS, 4), "kernel": kern,
+                 "note": ("fp32 VALU-bound chains priced against the fp32 dense peak the vector and matrix pipes "
+                          "share (157.3 TFLOP/s counts an FMA as 2 flop); of the 6 algorithmic flop per element "
+                          "strict arithmetic (no FMA) can reach 0.5 of it, sigma-contracted 0.6, contracted 0.75.  "
+                          "`frac` counts ALL D columns and 6 flop per element as the work (the contract's algorithmic "
+                          "figure); `frac_executed` counts what the kernel executes: only the chunk's live columns "
+                          "(dead ones are retired exactly) and 5 instead of 6 flop for all-zero (sample, column quad) "
+                          "blocks"),
+                 "avg_launch_ms": round(upd_avg_s * 1e3, 4),
+                 "algorithmic_flop_per_launch": flops}
+            if tr != capi.CLR and not chain_small:
+                live, nq, zfrac = zero_quad_stats(sp.own_host[0])
+                per_elem = 6.0 - (zfrac if tr == capi.STANDARD else 0.0)     # Median has no cheaper zero form
+                ex = per_elem * n_nodes_rank * (4.0 * nq) * sp.Bglob
+                r["executed_flop_per_launch"] = ex
+                r["frac_executed"] = round(ex / upd_avg_s / 1e12 / FP32_PEAK_TFLOPS, 4) if upd_avg_s > 0 else 0.0
+                r["executed_basis"] = {"live_columns": live, "column_quads": nq, "zero_quad_fraction": round(zfrac, 4),
+                                       "of": "rank-0 rows of chunk 0"}
+            else:
+                r["executed_flop_per_launch"] = flops
+                r["frac_executed"] = r["frac"]
+            return r
 
         roof = roofline_for(timing, split)
         traffic, tsrc = profile_traffic(f"{args.config}_{args.arith}")
         roof["traffic"] = traffic
         roof["traffic_source"] = tsrc
+        if not online:
+            busy, clk = profile_issue(f"{args.config}_{args.arith}")
+            roof["valu_issue_busy"] = busy
+            roof["sustained_clock_ghz"] = clk
+            roof["issue_source"] = ("profiles/traffic.json (SQ_INSTS_VALU x 4 / 1024 SIMDs over GRBM_GUI_ACTIVE / 8; the clock "
+                                    "is those cycles over the launch's duration under the counter pass)")
         arith = "n/a (online path has no contracted mode)" if online else ARITH_TEXT[args.arith]
         if not online and args.arith != "strict" and not capi.has_contracted(tr):
             arith = "strict (this transformation has ONE arithmetic, bit-identical in every mode)"

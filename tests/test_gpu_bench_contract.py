@@ -29,6 +29,12 @@ def test_single_gpu_line_small_shape():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["value"] > 0
     r = d["roofline"]
     assert r["bound"] == "valu_fp32" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # both counts of the roofline: algorithmic (6 * N * D * B, the contract) and executed (live columns, 5 flop for
+    # all-zero quads), plus the issue figures of the committed SQ counter pass (null when no profile of that key exists)
+    assert 0 < r["frac_executed"] <= r["frac"] and r["executed_flop_per_launch"] <= r["algorithmic_flop_per_launch"]
+    b = r["executed_basis"]
+    assert 0 < b["live_columns"] <= 784 and b["column_quads"] == (b["live_columns"] + 3) // 4 and 0 < b["zero_quad_fraction"] < 1
+    assert {"valu_issue_busy", "sustained_clock_ghz", "issue_source"} <= set(r)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     # `value` is quoted on the library's default arithmetic; the two contracted modes are timed beside it
     assert d["update_arithmetic"].startswith("strict") and d["backend"].startswith("none")

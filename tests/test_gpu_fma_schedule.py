@@ -5,7 +5,9 @@ more epochs -- each run on ITS OWN map against the strict oracle on its own.
   * VSOM_UPDATE_STRICT (library default): everything bit-identical, every chunk of every epoch.
   * VSOM_UPDATE_FMA_SIGMA: the mean chain is rounded as the reference rounds it, so map -- and with it lastBMU,
     bmuHits, MSE, weightMap of every later chunk -- stays BIT-IDENTICAL through the schedule; sigmaMap (a sum of
-    non-negative terms that no training step reads) within 1e-5 relative, element by element.
+    non-negative terms that no training step reads) within 1e-5 relative, element by element -- an EMPIRICAL bar
+    (what can be proven for B accumulations with one rounding fewer each is (B+1) * 2^-24 = 2.4e-4 at B = 4096,
+    include/vsom_hip.h); asserted here up to BASELINE config 3's size (10 epochs x 2 chunks of 4096).
   * VSOM_UPDATE_FMA: holds its tolerance for ONE epoch from a given map (tests/test_gpu_fma_mode.py) and no
     longer: the next search runs on a map perturbed by ~3e-7, near-ties flip, and the run leaves the
     reference's trajectory.  That is measured here (tools/fma_schedule_report.py, profiles/r3_fma_schedule.jsonl:
@@ -28,7 +30,8 @@ RTOL = 1e-5
 
 #           W    J   rows  chunk sigma0 decay epochs
 SCHEDULES = {"24x24x784": (24, 784, 2048, 1024, 8.0, 0.1, 12),
-             "C2_64x64x784": (64, 784, 8192, 4096, 16.0, 0.1, 10)}
+             "C2_64x64x784": (64, 784, 8192, 4096, 16.0, 0.1, 10),
+             "C3_128x128x784": (128, 784, 8192, 4096, 32.0, 0.1, 10)}     # BASELINE config 3: 10 epochs x 2 x 4096
 
 
 def _bits_equal(a, b):
@@ -64,7 +67,7 @@ def _run(case, mode, on_chunk):
     assert done >= 10, "the schedule must cover ten epochs and more"
 
 
-@pytest.mark.parametrize("case", sorted(SCHEDULES))
+@pytest.mark.parametrize("case", ["24x24x784", "C2_64x64x784"])      # (C3 strict: tests/test_gpu_baseline_configs.py)
 def test_strict_schedule_is_bit_identical(case):
     def check(e, k, o, lb, mse_o, ctx, mse_g):
         st = ctx.get_state(S=False)

@@ -149,3 +149,28 @@ def test_sqlite_column_spec_file(exe, tmp_path, ican):
     got = np.concatenate(passes[0], axis=0)
     assert [c.shape[0] for c in passes[0]] == [8, 8, 4]
     assert (got == rows.astype(np.float32)).all()
+
+
+REF_DATA = "/root/reference/tests/performance/data"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DATA, "testDb.sq3")),
+                    reason="the reference tree is not present (GPU box): its fixture files cannot be opened")
+@pytest.mark.parametrize("chunk", [0, 8])
+def test_reference_fixture_db_and_column_spec_opened_directly(exe, chunk):
+    """The ONE reference-held artefact for this path, read where it lies (never copied): the mirror's
+    SqliteDataLoader opens /root/reference/tests/performance/data/testDb.sq3 with the reference's own
+    columnSpec.txt -- the scenario of tests/performance/perf_tests.cpp:35-58,77-84 (table `ican`, columns A..I,
+    all weights 1, column E binary) -- and yields rows, names, weights and the binary flag equal to
+    tests/golden/ican_fixture.json, the data this repo's goldens were generated from."""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "ican_fixture.json")))
+    want = np.array(fx["rows"], np.float64).astype(np.float32)
+    passes, other = parse(run(exe, "spec", os.path.join(REF_DATA, "testDb.sq3"), os.path.join(REF_DATA, "columnSpec.txt"),
+                              chunk))
+    specs = [o.split() for o in other if o.startswith("SPEC")]
+    assert [s[1] for s in specs] == list("ABCDEFGHI")
+    assert [float(s[2]) for s in specs] == [1.0] * 9
+    assert [int(s[3]) for s in specs] == [1 if c == "E" else 0 for c in "ABCDEFGHI"]
+    assert [c.shape[0] for c in passes[0]] == ([20] if chunk == 0 else [8, 8, 4])
+    got = np.concatenate(passes[0], axis=0)
+    assert got.shape == (20, 9) and (got == want).all()
