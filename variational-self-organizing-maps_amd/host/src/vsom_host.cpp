@@ -651,8 +651,7 @@ Som::Som(const Som &som)
 // -- custom std::function hooks, ctx == nullptr -- in the host arrays: getState / setState handle both
 void Som::copyStateFrom(const Som &other)
 {
-    if ((ctx == nullptr) != (other.ctx == nullptr))
-        return;
+    // (one side device-resident and the other host-resident is fine too: the copy goes through host arrays)
     const size_t N = width * height;
     std::vector<float> m(N * depth), s(N * depth), S(N * depth), w(N);
     std::vector<uint64_t> hh(N);
