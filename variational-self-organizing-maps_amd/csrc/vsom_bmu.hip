@@ -58,6 +58,7 @@ int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B)
     TimerScope ts(c, VSOM_T_STAGE);
     c->cc_valid = false;
     c->xq_valid = false;
+    c->xi_valid = false;
     if (B == 0)
         return VSOM_OK;
     {

@@ -145,7 +145,7 @@ static int free_all(vsom_ctx *c)
     void *ptrs[] = {c->map, c->sigma, c->S, c->weight, c->hits, c->Xs, c->XP, c->YP, c->Xraw,
                     c->lastbmu, c->sqres, c->mse, c->bxy, c->pair_i, c->pair_j, c->partial, c->nan0,
                     c->cw, c->lut, c->lutd, c->sl_G, c->sl_nrm, c->sl_scal, c->sl_list, c->sl_tmin, c->sl_fs, c->sl_fm, c->v_dev, c->res_dev, c->onl_state, c->onl_f,
-                    c->cc_flags, c->cc_idx, c->cc_inv, c->cc_meta, c->Xc, c->Mc, c->Uc_map, c->Uc_S, c->Xq, c->zq};
+                    c->cc_flags, c->cc_idx, c->cc_inv, c->cc_meta, c->Xc, c->Mc, c->Uc_map, c->Uc_S, c->Xq, c->zq, c->sl_xi, c->sl_l1, c->sl_q, c->sl_qscale, c->sl_qcorr};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);

@@ -88,6 +88,12 @@ struct vsom_ctx {
     unsigned *sl_fb = nullptr;      // pinned host feedback: {redo samples, candidates, rows, seq}
     float *sl_fs = nullptr, *sl_fm = nullptr;      // CLR shortlist: sample / node feature rows (vsom_shortlist.hip)
     size_t sl_fs_cap = 0, sl_fm_cap = 0;           // bytes
+    // integer contraction of the shortlist (vsom_sl_i8.hip): int8 images of the chunk / the model rows
+    signed char *sl_xi = nullptr; size_t sl_xi_cap = 0; float *sl_l1 = nullptr;
+    signed char *sl_q = nullptr; double *sl_qscale = nullptr, *sl_qcorr = nullptr;
+    uint32_t sl_kp8 = 0;
+    bool xi_valid = false;          // sl_xi / sl_l1 describe the staged chunk
+    bool sl_i8 = true;              // try the integer contraction (cleared when a chunk turns out not to be uint8 data)
     int sl_skip = 0;
     unsigned sl_seq_seen = 0;       // feedback sequence number already acted on
     int sl_fail_streak = 0;         // consecutive probes that had to redo most samples exactly

@@ -295,7 +295,8 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
                                                         unsigned *__restrict__ redo_count, int *__restrict__ redo_list,
                                                         unsigned *__restrict__ stats,
                                                         const float *__restrict__ xraw, int ldxr, int J, float c_e1,
-                                                        unsigned cmax)
+                                                        unsigned cmax, const float *__restrict__ l1x, float c_l1,
+                                                        const unsigned *__restrict__ xflag)
 {
     __shared__ unsigned cand[SL_CMAX];
     __shared__ unsigned s_cnt;
@@ -346,8 +347,20 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         for (int off = 32; off > 0; off >>= 1)
             nx = nx + __shfl_xor(nx, off);
     }
-    const float nmax = __uint_as_float(scal[0]);
-    bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f) || !(cx <= 3.0e38f);
+    // integer contraction (vsom_sl_i8.hip, c_l1 > 0): the maxima of |M|^2 and of the digit residual eps sit in 32
+    // line-sized slots each; the approximation error is c_l1 |x|_1 eps_max + c_g1 (nMmax + |x|^2)
+    float nmax = __uint_as_float(scal[0]), epsmax = 0.f;
+    if (c_l1 > 0.f) {
+        unsigned nb = scal[1024 + 32 * (lane & 31)], eb = scal[2048 + 32 * (lane & 31)];
+        for (int off = 16; off > 0; off >>= 1) {
+            const unsigned o1 = (unsigned)__shfl_xor((int)nb, off), o2 = (unsigned)__shfl_xor((int)eb, off);
+            nb = o1 > nb ? o1 : nb;
+            eb = o2 > eb ? o2 : eb;
+        }
+        nmax = __uint_as_float(nb);                      // non-negative floats: the bit patterns order like the values
+        epsmax = __uint_as_float(eb);
+    }
+    bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f) || !(cx <= 3.0e38f) || (c_l1 > 0.f && xflag[0] != 0u);
     float m = __uint_as_float(0x7F800000u);
     for (int i = lane; i < ntm; i += 64) {
         float v = tm[i];
@@ -375,7 +388,9 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
                 bad = true;
         } else {
             // T_s = 4*g1*(nMmax+nx) + 2.1*g2*(m + nx + 2*g1*(nMmax+nx)), inflated by 1.05 (header)
-            const float ea = c_g1 * (nmax + nx);             // c_g1 = 2*g1
+            float ea = c_g1 * (nmax + nx);                   // c_g1 = 2*g1 (fp32 chain) / 3.3u (integer contraction)
+            if (c_l1 > 0.f)
+                ea = ea + 1.001f * c_l1 * l1x[s] * epsmax;
             float dj = m + nx;
             dj = dj + ea;
             dj = dj > 0.f ? dj : 0.f;
@@ -468,12 +483,15 @@ __global__ void sl_reset_kernel(unsigned *scal)
 {
     if (threadIdx.x < 8)
         scal[threadIdx.x] = 0u;
-    if (threadIdx.x < 32)
+    if (threadIdx.x < 32) {
         scal[16 + 32 * threadIdx.x] = 0u;     // candidate-count slots
+        scal[1024 + 32 * threadIdx.x] = 0u;   // max |M|^2 / max eps slots of the integer contraction (vsom_sl_i8.hip)
+        scal[2048 + 32 * threadIdx.x] = 0u;
+    }
 }
 
 // copies {redo samples, candidates} of this call into the host-visible feedback words
-__global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsigned nrows)
+__global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsigned nrows, const unsigned *xflag)
 {
     unsigned cand = 0;
     for (int sl = 0; sl < 32; ++sl)
@@ -481,12 +499,14 @@ __global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsi
     host_fb[0] = scal[4];
     host_fb[1] = cand;
     host_fb[2] = nrows;
+    host_fb[4] = xflag ? xflag[0] : 0u;       // integer contraction asked for on a chunk that is not uint8 data
     __threadfence_system();
     host_fb[3] = host_fb[3] + 1u;
 }
 
 // host side ------------------------------------------------------------------------------------
 int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount);
+int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *xflag);   // vsom_sl_i8.hip
 
 static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1);
 
@@ -523,16 +543,31 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     }
     if (!c->sl_nrm) {
         VSOM_HIP_CHECK(hipMalloc(&c->sl_nrm, (size_t)c->N * sizeof(float)));
-        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 8192));   // 16 words + 32 line-sized counter slots
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 16384));  // 16 words + 3 x 32 line-sized slots + the chunk's data-kind flag
         VSOM_HIP_CHECK(hipHostMalloc(&c->sl_fb, 64));
         std::memset(c->sl_fb, 0, 64);
     }
     // scal: [0] max nrm bits, [1] non-finite flag, [2] redo count, [4] redo samples, [5] candidates
     unsigned *scal = c->sl_scal;
     hipLaunchKernelGGL(sl_reset_kernel, dim3(1), dim3(64), 0, c->stream, scal);
+    // chunks of small non-negative integers (MNIST pixels): the contraction in exact integer arithmetic on the int8
+    // matrix pipe (vsom_sl_i8.hip).  Whether a chunk is of that kind is a device-side fact: the host goes by the
+    // feedback of the previous search (a chunk that is not is searched exactly, once, and the context returns to the
+    // fp32 contraction)
+    if (c->sl_i8 && c->sl_fb && ((volatile unsigned *)c->sl_fb)[4] != 0u)
+        c->sl_i8 = false;
+    const bool i8 = c->sl_i8 && c->xpitch <= 4096;
+    unsigned *xflag = scal + 4000;
+    dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
+    if (i8) {
+        if (!c->xi_valid)
+            VSOM_HIP_CHECK(hipMemsetAsync(xflag, 0, 4, c->stream));
+        int rc = launch_sl_i8(c, s0, s1, ldg, ntm, xflag);
+        if (rc)
+            return rc;
+    } else {
     hipLaunchKernelGGL(sl_norm_kernel, dim3((unsigned)(((size_t)c->N * 16 + 255) / 256)), dim3(256), 0, c->stream,
                        c->map, (int)c->pitch, (int)c->part_pitch, (int)c->N, c->sl_nrm, scal);
-    dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
     if (c->cc_valid) {
         // columns that are zero in every row of the chunk add exactly 0 to every <x, M>: contract over the live
         // ones (norms, bound and refinement keep the whole rows)
@@ -546,6 +581,7 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     hipLaunchKernelGGL(sl_gemm_kernel, grid, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, (int)s0, (int)s1,
                        c->map, (int)c->pitch, (int)c->N, (int)c->xpitch, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm,
                        (const unsigned *)nullptr);
+    }
     DistArgs a;
     a.xa = c->Xs;
     a.xb = c->Xs;
@@ -557,10 +593,13 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     const double u = 5.9604644775390625e-08;   // 2^-24
     const double K = (double)c->xpitch;
     const double g1 = ((double)GK + K / GK + 3.0) * u, g2 = ((double)c->D / 8.0 + 10.0) * u;
+    // integer contraction: |G - (|M|^2 - 2<x,M>)| <= 2 |x|_1 eps_max + 3.1u (nMmax + |x|^2)  (vsom_sl_i8.hip)
     hipLaunchKernelGGL(sl_select_kernel<false>, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0,
-                       (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(2.0 * g1), (float)(2.1 * g2),
-                       c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, (const float *)nullptr, 0, 0, 0.f, (unsigned)SL_CMAX);
-    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows);
+                       (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(i8 ? 3.3 * u : 2.0 * g1),
+                       (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, (const float *)nullptr, 0, 0, 0.f,
+                       (unsigned)SL_CMAX, (const float *)c->sl_l1, i8 ? 2.0f : 0.f, (const unsigned *)xflag);
+    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
+                       i8 ? (const unsigned *)xflag : (const unsigned *)nullptr);
     VSOM_HIP_CHECK(hipGetLastError());
     // exact-order redo of the listed samples (device-side count; blocks beyond it exit at once)
     return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2);
@@ -739,7 +778,7 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
     c->sl_list_cap = capL / sizeof(int);
     if (!c->sl_nrm) {
         VSOM_HIP_CHECK(hipMalloc(&c->sl_nrm, (size_t)c->N * sizeof(float)));
-        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 8192));
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 16384));
         VSOM_HIP_CHECK(hipHostMalloc(&c->sl_fb, 64));
         std::memset(c->sl_fb, 0, 64);
     }
@@ -768,8 +807,10 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
     const size_t xy_bytes = (size_t)2 * c->part_pitch * sizeof(float);   // + 8.3 KB static: fits the default 64 KB up to J = 120
     hipLaunchKernelGGL(sl_select_kernel<true>, dim3((unsigned)nrows), dim3(256), xy_bytes, c->stream, a, (int)s0, (int)s1, (int)c->N,
                        (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(1.0001 * ga), (float)(1.0001 * g2),
-                       c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, c->Xs, (int)c->xpitch, (int)J, (float)(1.0001 * e1), 128u);
-    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows);
+                       c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, c->Xs, (int)c->xpitch, (int)J, (float)(1.0001 * e1), 128u,
+                       (const float *)nullptr, 0.f, (const unsigned *)nullptr);
+    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
+                       (const unsigned *)nullptr);
     VSOM_HIP_CHECK(hipGetLastError());
     return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2);
 }

@@ -1,0 +1,352 @@
+// vsom_sl_i8.hip -- the shortlist contraction of Som::findBmu (Som.cpp:291-309; vsom_shortlist.hip) on the INTEGER
+// matrix pipe, for chunks whose samples are small non-negative integers (MNIST: MnistDataLoader.cpp:73-75 yields the raw
+// pixel values 0..255 as floats).
+//
+// The matrix pipe only PRUNES: G[s][n] ~ |M_n|^2 - 2 <x_s, M_n> with a proven error bound, every returned index and
+// distance comes from the exact-order evaluation of sl_select_kernel.  Here the approximation is computed in exact
+// integer arithmetic instead of an fp32 MFMA chain, 10x faster on the matrix pipe (v_mfma_i32_32x32x32_i8 runs 32x the
+// multiply-adds per cycle of v_mfma_f32_32x32x2_f32; three of them per product) and with a TIGHTER bound:
+//   * model rows: M_nk = s_n (q1 + q2/128 + q3/16384)_nk + r_nk, s_n a power of two >= 2^-5 max_k |M_nk|... chosen so
+//     that q1 = rint(M/s) lies in [-64, 64]; the residuals are formed exactly in fp32 (differences of a value and its
+//     rounding to a coarser grid), q2, q3 in [-64, 64], |r_nk| <= s_n 2^-15 =: eps_n            (sl_prepare_i8_kernel)
+//   * samples: x_sk integer in [0, 255]  ->  int8 (x - 128); the offset is put back with the row sums of q (exact)
+//   * <x, M^> = s_n 2^-14 [ 16384 I1 + 128 I2 + I3 ],  I_l = sum_k x_k q_l,nk exact in int32; the combination, the
+//     offset term, the scale and |M|^2 - 2 <x, M^> are evaluated in fp64 (exact up to the final rounding to fp32)
+// Bound:  |G - (|M_n|^2 - 2 <x, M_n>)| <= 2 |x|_1 eps_n + u (|M_n|^2 from its fp64 sum) + u |G|
+//                                      <= 2 |x|_1 eps_max + 3.1 u (nMmax + |x|^2)               (u = 2^-24)
+// which sl_select_kernel uses in place of the fp32 chain's 2 g1 (nMmax + |x|^2), g1 = (32 + K/32 + 3) u: at C3
+// (K = 672 live columns, |x|_1 ~ 2e4, max |M| ~ 255) about 5 against 70.
+// A chunk that is not of that kind (quant_x raises a flag) is searched by the exact-order kernel this once, and the
+// host returns to the fp32 contraction for the context (vsom_shortlist.hip).
+#include "vsom_device.hpp"
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// scal slots (unsigned words): see vsom_shortlist.hip; 32 line-sized slots each for max nrm / max eps
+#define SLI_NMAX(slot) (1024 + 32 * (slot))
+#define SLI_EMAX(slot) (1024 + 1024 + 32 * (slot))
+
+// ---- samples: int8 image, |x|_1, "is this uint8 data" --------------------------------------------------------------
+// one wavefront per row; xi row pitch kp8 bytes, columns past the row's length hold x = 0 (-128)
+__global__ __launch_bounds__(256) void sl_quant_x_kernel(const float *__restrict__ X, int ldx, int B, int kp8,
+                                                         signed char *__restrict__ xi, float *__restrict__ l1,
+                                                         unsigned *__restrict__ xflag)
+{
+    const int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B)
+        return;
+    const float *x = X + (size_t)row * ldx;
+    signed char *o = xi + (size_t)row * kp8;
+    float sum = 0.f;
+    bool bad = false;
+    for (int k4 = lane * 4; k4 < kp8; k4 += 256) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k4 < ldx)                                   // ldx is a multiple of 32
+            v = *reinterpret_cast<const float4 *>(x + k4);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        char4 q;
+        signed char *qq = reinterpret_cast<signed char *>(&q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float f = vv[u];
+            const bool ok = f >= 0.f && f <= 255.f && f == rintf(f);      // NaN fails the comparisons
+            bad |= !ok;
+            const int iv = ok ? (int)f : 0;
+            sum += (float)iv;                            // exact: integers, total < 2^24 for rows up to 65536 values
+            qq[u] = (signed char)(iv - 128);
+        }
+        *reinterpret_cast<char4 *>(o + k4) = q;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        sum += __shfl_xor(sum, off);
+    if (__ballot(bad) && lane == 0)
+        atomicOr(xflag, 1u);
+    if (lane == 0)
+        l1[row] = sum;
+}
+
+// ---- model rows: |M|^2 (fp64 sum), live columns gathered, three 7-bit digits, row sums -------------------------------
+// one workgroup per node.  idx = live-column list of the compaction (null: identity), kp = contraction length
+// (device value kp_dev[2] when compacted).  q planes: [3][N][kp8].
+__global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restrict__ map, int ldm, int Dp, int N,
+                                                            const int *__restrict__ idx, int kp, const unsigned *__restrict__ kp_dev,
+                                                            int kp8, signed char *__restrict__ q, float *__restrict__ nrm,
+                                                            double *__restrict__ qscale, double *__restrict__ qcorr,
+                                                            unsigned *__restrict__ scal)
+{
+    __shared__ float row[4096];
+    __shared__ double sd[4];
+    __shared__ float sf[4];
+    __shared__ int si[3][4];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (kp_dev)
+        kp = (int)kp_dev[2];
+    const float *src = map + (size_t)n * ldm;
+    double ss = 0.0;
+    for (int d = tid; d < Dp; d += 256) {               // rows are zero padded to Dp
+        const float v = src[d];
+        if (d < 4096)
+            row[d] = v;
+        ss += (double)v * (double)v;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        ss += __shfl_xor(ss, off);
+    if (lane == 0)
+        sd[wave] = ss;
+    __syncthreads();
+    const double tot = (sd[0] + sd[1]) + (sd[2] + sd[3]);
+    const float nf = (float)tot;                         // NaN rows stay NaN, overflow -> inf
+    // the row's largest live magnitude (non-finite values count as 0: such a row is excluded / redone anyway)
+    float mx = 0.f;
+    for (int k = tid; k < kp; k += 256) {
+        const int c = idx ? idx[k] : k;
+        float v = c >= 0 && c < Dp ? (c < 4096 ? row[c] : src[c]) : 0.f;
+        v = fabsf(v);
+        mx = (v <= 3.0e38f && v > mx) ? v : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if (lane == 0)
+        sf[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sf[0], sf[1]), fmaxf(sf[2], sf[3]));
+    // s = 2^E with |M| / s < 64:  E = exponent(mx) - 5  (mx < 2^(exponent+1)); tiny rows: E >= -100
+    int e = mx > 0.f ? (int)((__float_as_uint(mx) >> 23) & 0xFF) - 127 : -100;
+    e = mx > 0.f && ((__float_as_uint(mx) >> 23) & 0xFF) == 0 ? -126 : e;      // denormal maximum
+    int E = e - 5;
+    E = E < -100 ? -100 : E;
+    const float s1 = __uint_as_float((unsigned)(E + 127) << 23), is1 = __uint_as_float((unsigned)(127 - E) << 23);
+    const float s2 = s1 * 0.0078125f, s3 = s2 * 0.0078125f;                     // s / 128, s / 16384 (exact)
+    const float is2 = is1 * 128.f, is3 = is2 * 128.f;
+    int r1 = 0, r2 = 0, r3 = 0;
+    const size_t plane = (size_t)N * kp8;
+    signed char *q1 = q + (size_t)n * kp8, *q2 = q1 + plane, *q3 = q2 + plane;
+    for (int k = tid; k < kp8; k += 256) {
+        int a = 0, b = 0, c3 = 0;
+        if (k < kp) {
+            const int c = idx ? idx[k] : k;
+            float v = c >= 0 && c < Dp ? (c < 4096 ? row[c] : src[c]) : 0.f;
+            v = fabsf(v) <= 3.0e38f ? v : 0.f;
+            float t = rintf(v * is1);                    // |v| / s < 64 unless the row is tiny (E clamped): clamp
+            t = fminf(fmaxf(t, -64.f), 64.f);
+            const float ra = v - t * s1;                 // exact
+            float t2 = rintf(ra * is2);
+            t2 = fminf(fmaxf(t2, -64.f), 64.f);
+            const float rb = ra - t2 * s2;               // exact
+            float t3 = rintf(rb * is3);
+            t3 = fminf(fmaxf(t3, -64.f), 64.f);
+            a = (int)t;
+            b = (int)t2;
+            c3 = (int)t3;
+        }
+        q1[k] = (signed char)a;
+        q2[k] = (signed char)b;
+        q3[k] = (signed char)c3;
+        r1 += a;
+        r2 += b;
+        r3 += c3;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        r1 += __shfl_xor(r1, off);
+        r2 += __shfl_xor(r2, off);
+        r3 += __shfl_xor(r3, off);
+    }
+    if (lane == 0) {
+        si[0][wave] = r1;
+        si[1][wave] = r2;
+        si[2][wave] = r3;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const long long R1 = (long long)si[0][0] + si[0][1] + si[0][2] + si[0][3];
+        const long long R2 = (long long)si[1][0] + si[1][1] + si[1][2] + si[1][3];
+        const long long R3 = (long long)si[2][0] + si[2][1] + si[2][2] + si[2][3];
+        nrm[n] = nf;
+        qscale[n] = (double)s3;                          // s 2^-14: multiplies 16384 I1 + 128 I2 + I3
+        qcorr[n] = 128.0 * (double)(R1 * 16384 + R2 * 128 + R3);   // the (x - 128) offset put back
+        const int slot = n & 31;
+        if (nf == nf) {
+            if (nf > 3.0e38f)
+                atomicOr(&scal[1], 1u);                  // an inf somewhere: the bound does not apply
+            else
+                atomicMax(&scal[SLI_NMAX(slot)], __float_as_uint(nf));
+        }
+        // eps_n = s 2^-15, or the whole magnitude of a row too small for the digit grid (E clamped)
+        const float eps = e - 5 < -100 ? mx : s1 * 3.0517578125e-05f;
+        atomicMax(&scal[SLI_EMAX(slot)], __float_as_uint(eps));
+    }
+}
+
+// ---- G = |M|^2 - 2 <x, M^>, tile minima -----------------------------------------------------------------------------
+// workgroup tile 128 samples x 64 nodes, wavefront tile 64 x 32 (2 x 1 MFMA tiles of 32 x 32), three int32 accumulator
+// sets (the digits), K streamed through LDS in chunks of 64 bytes with the next chunk's global loads in flight
+#define IT_S 128
+#define IT_N 64
+#define IK 64
+#define ILD 80      // LDS row stride in bytes (64 + 16: conflict-free 16-byte fragment reads)
+__global__ __launch_bounds__(256, 2) void sl_gemm_i8_kernel(const signed char *__restrict__ xi, int s0, int s1, const signed char *__restrict__ q,
+                                                            int N, int kp, const unsigned *__restrict__ kp_dev, int kp8,
+                                                            const float *__restrict__ nrm, const double *__restrict__ qscale,
+                                                            const double *__restrict__ qcorr, float *__restrict__ G, int ldg,
+                                                            float *__restrict__ tmin, int ntm)
+{
+    if (kp_dev)
+        kp = (int)kp_dev[2];
+    const int k64 = (kp + IK - 1) / IK * IK;             // <= kp8; columns past kp hold q = 0
+    __shared__ __attribute__((aligned(16))) signed char As[IT_S * ILD];
+    __shared__ __attribute__((aligned(16))) signed char Bs[3][IT_N * ILD];
+    __shared__ float smin[2][IT_S];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int sbase = s0 + blockIdx.y * IT_S, nbase = blockIdx.x * IT_N;
+    const size_t plane = (size_t)N * kp8;
+
+    v16i acc[3][2];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[l][i][r] = 0;
+
+    // staging: A tile 128 rows x 64 B = 512 pieces of 16 B (2 per thread); B tiles 3 x 64 rows x 64 B = 768 pieces (3)
+    v4i pa[2], pb[3];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i, r = f >> 2, c = (f & 3) * 16;
+            const int s = sbase + r;
+            pa[i] = s < s1 ? *reinterpret_cast<const v4i *>(xi + (size_t)s * kp8 + k0 + c) : v4i{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const int r = tid >> 2, c = (tid & 3) * 16;
+            const int n = nbase + r;
+            pb[l] = n < N ? *reinterpret_cast<const v4i *>(q + l * plane + (size_t)n * kp8 + k0 + c) : v4i{0, 0, 0, 0};
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < k64; k0 += IK) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i, r = f >> 2, c = (f & 3) * 16;
+            *reinterpret_cast<v4i *>(&As[r * ILD + c]) = pa[i];
+        }
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            const int r = tid >> 2, c = (tid & 3) * 16;
+            *reinterpret_cast<v4i *>(&Bs[l][r * ILD + c]) = pb[l];
+        }
+        __syncthreads();
+        if (k0 + IK < k64)
+            gload(k0 + IK);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i a[2], b[3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                a[i] = *reinterpret_cast<const v4i *>(&As[(wm * 64 + i * 32 + lr) * ILD + ks * 32 + 16 * lh]);
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+                b[l] = *reinterpret_cast<const v4i *>(&Bs[l][(wn * 32 + lr) * ILD + ks * 32 + 16 * lh]);
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[l][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[l], acc[l][i], 0, 0, 0);
+        }
+    }
+    // epilogue (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)), in fp64: exact up to the
+    // final rounding to fp32
+    const float inf = __uint_as_float(0x7F800000u);
+    const int col = nbase + wn * 32 + lr;
+    const bool cok = col < N;
+    const double nm = cok ? (double)nrm[col] : 0.0, sc = cok ? qscale[col] : 0.0, cr = cok ? qcorr[col] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int row = sbase + lrow;
+            const double t = (double)acc[0][i][r] * 16384.0 + (double)acc[1][i][r] * 128.0 + (double)acc[2][i][r] + cr;
+            const float g = (float)(nm - 2.0 * (sc * t));
+            if (row < s1 && cok)
+                G[(size_t)(row - s0) * ldg + col] = g;
+            // exact minimum of the finite entries of this row over the workgroup's 64 nodes: NaN -> +inf
+            float mn = (cok && g == g) ? g : inf;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {     // the 32 lanes that share this row
+                const float o = __shfl_xor(mn, off);
+                mn = o < mn ? o : mn;
+            }
+            if (lr == 0)
+                smin[wn][lrow] = mn;
+        }
+    }
+    __syncthreads();
+    if (tid < IT_S) {
+        const int row = sbase + tid;
+        if (row < s1) {
+            const float a0 = smin[0][tid], a1 = smin[1][tid];
+            tmin[(size_t)(row - s0) * ntm + blockIdx.x] = a1 < a0 ? a1 : a0;
+        }
+    }
+}
+
+// ---- host --------------------------------------------------------------------------------------------------------------
+// prepares the int8 images and computes G / tmin for samples [s0, s1) (ldg, ntm as the fp32 path lays them out: 64-node
+// tile minima); scal must have been reset
+int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *xflag)
+{
+    const bool compact = c->cc_valid;
+    const uint32_t kmax = compact ? c->cpitch : c->xpitch;
+    const uint32_t kp8 = (kmax + 63) / 64 * 64;
+    if (!c->sl_q || c->sl_kp8 != kp8) {
+        if (c->sl_q) {
+            VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+            VSOM_HIP_CHECK(hipFree(c->sl_q));
+            VSOM_HIP_CHECK(hipFree(c->sl_qscale));
+            VSOM_HIP_CHECK(hipFree(c->sl_qcorr));
+        }
+        c->sl_q = nullptr;
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_q, (size_t)3 * c->N * kp8));
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_qscale, (size_t)c->N * sizeof(double)));
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_qcorr, (size_t)c->N * sizeof(double)));
+        c->sl_kp8 = kp8;
+        c->xi_valid = false;
+        c->sl_xi_cap = 0;
+    }
+    if ((size_t)c->Bcap * kp8 > c->sl_xi_cap) {
+        if (c->sl_xi) {
+            VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+            VSOM_HIP_CHECK(hipFree(c->sl_xi));
+            VSOM_HIP_CHECK(hipFree(c->sl_l1));
+        }
+        c->sl_xi = nullptr;
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_xi, (size_t)c->Bcap * kp8));
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_l1, (size_t)c->Bcap * sizeof(float)));
+        c->sl_xi_cap = (size_t)c->Bcap * kp8;
+        c->xi_valid = false;
+    }
+    unsigned *scal = c->sl_scal;
+    if (!c->xi_valid) {      // once per staged chunk
+        hipLaunchKernelGGL(sl_quant_x_kernel, dim3((unsigned)((c->B + 3) / 4)), dim3(256), 0, c->stream,
+                           compact ? c->Xc : c->Xs, (int)kmax, (int)c->B, (int)kp8, c->sl_xi, c->sl_l1, xflag);
+        c->xi_valid = true;
+    }
+    const unsigned *kp_dev = compact ? (const unsigned *)c->cc_meta : nullptr;
+    hipLaunchKernelGGL(sl_prepare_i8_kernel, dim3((unsigned)c->N), dim3(256), 0, c->stream, c->map, (int)c->pitch,
+                       (int)c->part_pitch, (int)c->N, compact ? (const int *)c->cc_idx : (const int *)nullptr, (int)kmax, kp_dev,
+                       (int)kp8, c->sl_q, c->sl_nrm, c->sl_qscale, c->sl_qcorr, scal);
+    dim3 grid((unsigned)ntm, (unsigned)((s1 - s0 + IT_S - 1) / IT_S));   // ntm 64-node tiles (the last may lie past N: minima +inf)
+    hipLaunchKernelGGL(sl_gemm_i8_kernel, grid, dim3(256), 0, c->stream, c->sl_xi, (int)s0, (int)s1, c->sl_q, (int)c->N,
+                       (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm);
+    VSOM_HIP_CHECK(hipGetLastError());
+    return VSOM_OK;
+}
