@@ -181,13 +181,17 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
 }
 
 // ---- G = |M|^2 - 2 <x, M^>, tile minima -----------------------------------------------------------------------------
-// workgroup tile 128 samples x 64 nodes, wavefront tile 64 x 32 (2 x 1 MFMA tiles of 32 x 32), three int32 accumulator
-// sets (the digits), K streamed through LDS in chunks of 64 bytes with the next chunk's global loads in flight
-#define IT_S 128
+// workgroup tile (64 MI) samples x 64 nodes, wavefront tile (32 MI) x 32 (MI MFMA tiles of 32 x 32), three int32
+// accumulator sets (the digits), K streamed through LDS in chunks of 64 bytes with the next chunk's global loads in
+// flight.  The contraction itself is ~0.06 ms of matrix-pipe time at C3; what the kernel waits for is its staging
+// loads (1.8 GB out of L2 at MI = 2, one chunk of 20 KB per workgroup in flight): measured at C3 -- 128 x 64 tiles, two
+// workgroups per CU 0.37 ms, three (154 VGPRs) 0.27 ms; 64 x 64 tiles, five per CU (2.8 GB) 0.30 ms; the fp64
+// epilogue and the tile minima cost nothing measurable.  (Next: a ring of LDS stages filled by global_load_lds.)
 #define IT_N 64
 #define IK 64
 #define ILD 80      // LDS row stride in bytes (64 + 16: conflict-free 16-byte fragment reads)
-__global__ __launch_bounds__(256, 2) void sl_gemm_i8_kernel(const signed char *__restrict__ xi, int s0, int s1, const signed char *__restrict__ q,
+template <int MI>
+__global__ __launch_bounds__(256, MI == 1 ? 5 : 3) void sl_gemm_i8_kernel(const signed char *__restrict__ xi, int s0, int s1, const signed char *__restrict__ q,
                                                             int N, int kp, const unsigned *__restrict__ kp_dev, int kp8,
                                                             const float *__restrict__ nrm, const double *__restrict__ qscale,
                                                             const double *__restrict__ qcorr, float *__restrict__ G, int ldg,
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_i8_kernel(const signed char *_
     if (kp_dev)
         kp = (int)kp_dev[2];
     const int k64 = (kp + IK - 1) / IK * IK;             // <= kp8; columns past kp hold q = 0
+    constexpr int IT_S = 64 * MI;
     __shared__ __attribute__((aligned(16))) signed char As[IT_S * ILD];
     __shared__ __attribute__((aligned(16))) signed char Bs[3][IT_N * ILD];
     __shared__ float smin[2][IT_S];
@@ -205,20 +210,20 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_i8_kernel(const signed char *_
     const int sbase = s0 + blockIdx.y * IT_S, nbase = blockIdx.x * IT_N;
     const size_t plane = (size_t)N * kp8;
 
-    v16i acc[3][2];
+    v16i acc[3][MI];
 #pragma unroll
     for (int l = 0; l < 3; ++l)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[l][i][r] = 0;
 
-    // staging: A tile 128 rows x 64 B = 512 pieces of 16 B (2 per thread); B tiles 3 x 64 rows x 64 B = 768 pieces (3)
-    v4i pa[2], pb[3];
+    // staging: A tile (64 MI) rows x 64 B = 256 MI pieces of 16 B (MI per thread); B tiles 3 x 64 rows x 64 B = 768 pieces (3)
+    v4i pa[MI], pb[3];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
             const int f = tid + 256 * i, r = f >> 2, c = (f & 3) * 16;
             const int s = sbase + r;
             pa[i] = s < s1 ? *reinterpret_cast<const v4i *>(xi + (size_t)s * kp8 + k0 + c) : v4i{0, 0, 0, 0};
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_i8_kernel(const signed char *_
     for (int k0 = 0; k0 < k64; k0 += IK) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
             const int f = tid + 256 * i, r = f >> 2, c = (f & 3) * 16;
             *reinterpret_cast<v4i *>(&As[r * ILD + c]) = pa[i];
         }
@@ -248,17 +253,17 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_i8_kernel(const signed char *_
             gload(k0 + IK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            v4i a[2], b[3];
+            v4i a[MI], b[3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                a[i] = *reinterpret_cast<const v4i *>(&As[(wm * 64 + i * 32 + lr) * ILD + ks * 32 + 16 * lh]);
+            for (int i = 0; i < MI; ++i)
+                a[i] = *reinterpret_cast<const v4i *>(&As[(wm * 32 * MI + i * 32 + lr) * ILD + ks * 32 + 16 * lh]);
 #pragma unroll
             for (int l = 0; l < 3; ++l)
                 b[l] = *reinterpret_cast<const v4i *>(&Bs[l][(wn * 32 + lr) * ILD + ks * 32 + 16 * lh]);
 #pragma unroll
             for (int l = 0; l < 3; ++l)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
                     acc[l][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[l], acc[l][i], 0, 0, 0);
         }
     }
@@ -269,10 +274,10 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_i8_kernel(const signed char *_
     const bool cok = col < N;
     const double nm = cok ? (double)nrm[col] : 0.0, sc = cok ? qscale[col] : 0.0, cr = cok ? qcorr[col] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int lrow = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int lrow = wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int row = sbase + lrow;
             const double t = (double)acc[0][i][r] * 16384.0 + (double)acc[1][i][r] * 128.0 + (double)acc[2][i][r] + cr;
             const float g = (float)(nm - 2.0 * (sc * t));
@@ -344,8 +349,9 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
     hipLaunchKernelGGL(sl_prepare_i8_kernel, dim3((unsigned)c->N), dim3(256), 0, c->stream, c->map, (int)c->pitch,
                        (int)c->part_pitch, (int)c->N, compact ? (const int *)c->cc_idx : (const int *)nullptr, (int)kmax, kp_dev,
                        (int)kp8, c->sl_q, c->sl_nrm, c->sl_qscale, c->sl_qcorr, scal);
-    dim3 grid((unsigned)ntm, (unsigned)((s1 - s0 + IT_S - 1) / IT_S));   // ntm 64-node tiles (the last may lie past N: minima +inf)
-    hipLaunchKernelGGL(sl_gemm_i8_kernel, grid, dim3(256), 0, c->stream, c->sl_xi, (int)s0, (int)s1, c->sl_q, (int)c->N,
+    constexpr int MI = 2;
+    dim3 grid((unsigned)ntm, (unsigned)((s1 - s0 + 64 * MI - 1) / (64 * MI)));   // ntm 64-node tiles (the last may lie past N: minima +inf)
+    hipLaunchKernelGGL(sl_gemm_i8_kernel<MI>, grid, dim3(256), 0, c->stream, c->sl_xi, (int)s0, (int)s1, c->sl_q, (int)c->N,
                        (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm);
     VSOM_HIP_CHECK(hipGetLastError());
     return VSOM_OK;
