@@ -8,7 +8,7 @@
 //  bmu_local_kernel  : Som::findLocalBmu (Som.cpp:335-454), one wavefront per sample,
 //                      8 candidates x 8 accumulator classes across the 64 lanes.
 //  pair_dist_kernel  : Som::euclidianWeightedDist for arbitrary (node,row) pairs.
-//  hits/mse_kernel   : bmuHits[idx] += 1 and the fp32 MSE running sum in sample order
+//  finish_kernel     : bmuHits[idx] += 1 and the fp32 MSE running sum in sample order
 //                      (Som.cpp:777-781).
 //  stage kernels     : chunk re-layout (zero-padded rows; CLR x'/y' expansion).
 #include "vsom_device.hpp"
@@ -16,15 +16,30 @@
 // ------------------------------------------------------------------------------------------
 // chunk staging
 // ------------------------------------------------------------------------------------------
-__global__ void stage_rows_kernel(const float *__restrict__ x, int J, int B,
-                                  float *__restrict__ xs, int xpitch)
+// one workgroup = 16 rows: zero-padded copy into Xs, lastBMU of those rows zeroed (DataSet::loadNextDataFromStream,
+// DataSet.cpp:136-137), and -- flags != null: the column compaction is on for this chunk (vsom_compact.hip) -- a column
+// is flagged live when any of the rows holds something != 0 (NaN counts; every writer stores the same value, no
+// atomic needed; cc_scan_kernel clears the flags again after reading them).  xflag: the chunk's data-kind word of the
+// integer shortlist (vsom_sl_i8.hip), cleared for the new chunk.
+__global__ __launch_bounds__(256) void stage_rows_kernel(const float *__restrict__ x, int J, int B, float *__restrict__ xs,
+                                                         int xpitch, u64 *__restrict__ lastbmu, unsigned *__restrict__ flags,
+                                                         unsigned *__restrict__ xflag)
 {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t total = (size_t)B * xpitch;
-    if (i >= total)
-        return;
-    int s = (int)(i / xpitch), d = (int)(i % xpitch);
-    xs[i] = d < J ? x[(size_t)s * J + d] : 0.f;
+    const int r0 = blockIdx.x * 16, r1 = r0 + 16 < B ? r0 + 16 : B;
+    if (threadIdx.x < 16 && r0 + (int)threadIdx.x < B)
+        lastbmu[r0 + threadIdx.x] = 0;
+    if (xflag && blockIdx.x == 0 && threadIdx.x == 0)
+        *xflag = 0u;
+    for (int d = threadIdx.x; d < xpitch; d += 256) {
+        bool live = false;
+        for (int r = r0; r < r1; ++r) {
+            const float v = d < J ? x[(size_t)r * J + d] : 0.f;
+            xs[(size_t)r * xpitch + d] = v;
+            live |= !(v == 0.f);
+        }
+        if (flags && live && flags[d] == 0u)
+            flags[d] = 1u;
+    }
 }
 
 // x'_p = x[i(p)], y'_p = x[j(p)]  (Transformation.cpp:94-101)
@@ -46,13 +61,6 @@ __global__ void stage_pairs_kernel(const float *__restrict__ x, int J, int B, in
     yp[i] = b;
 }
 
-__global__ void zero_u64_kernel(u64 *p, size_t n)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        p[i] = 0;
-}
-
 int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B)
 {
     TimerScope ts(c, VSOM_T_STAGE);
@@ -61,22 +69,20 @@ int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B)
     c->xi_valid = false;
     if (B == 0)
         return VSOM_OK;
-    {
-        size_t total = B * c->xpitch;
-        hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                           c->stream, x_dev, (int)c->J, (int)B, c->Xs, (int)c->xpitch);
-    }
+    bool cc = false;
+    if (int rc = vsom_cc_begin(c, &cc))      // does this chunk get the column compaction? (buffers, skip counters)
+        return rc;
+    hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, c->stream, x_dev, (int)c->J,
+                       (int)B, c->Xs, (int)c->xpitch, c->lastbmu, cc ? c->cc_flags : (unsigned *)nullptr,
+                       c->sl_scal ? c->sl_scal + 8192 : (unsigned *)nullptr);
     if (c->transform == VSOM_CLR) {
         size_t total = B * c->part_pitch;
         hipLaunchKernelGGL(stage_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                            c->stream, x_dev, (int)c->J, (int)B, (int)c->part_len, c->pair_i,
                            c->pair_j, c->XP, c->YP, (int)c->part_pitch);
     }
-    // DataSet::loadNextDataFromStream zeroes lastBMU (DataSet.cpp:136-137)
-    hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, c->stream,
-                       c->lastbmu, B);
     VSOM_HIP_CHECK(hipGetLastError());
-    return vsom_cc_stage(c);      // live-column record of this chunk (vsom_compact.hip)
+    return cc ? vsom_cc_stage(c) : VSOM_OK;      // live-column record of this chunk (vsom_compact.hip)
 }
 
 static DistArgs make_dist_args(const vsom_ctx *c)
@@ -595,11 +601,11 @@ int launch_raw_dist(vsom_ctx *c, const u64 *nodes_dev, const u64 *vrows_dev, siz
 // ------------------------------------------------------------------------------------------
 // finish: bmuHits and MSE (Som.cpp:777-781 / 800-804), sample order fixed (Q13)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hits_kernel(const u64 *__restrict__ lastbmu, int B, u64 *__restrict__ hits)
+// bmuHits[idx]++ (:778) for 1024 samples.  BMUs cluster on few nodes, and same-address atomics serialise in L2:
+// each wavefront first merges its equal indices (one atomic per distinct value).
+__device__ __forceinline__ void finish_hits(const u64 *__restrict__ lastbmu, int B, u64 *__restrict__ hits, int base)
 {
-    // bmuHits[idx]++ (:778).  BMUs cluster on few nodes, and same-address atomics serialise in L2:
-    // each wavefront first merges its equal indices (one atomic per distinct value).
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = base + (int)threadIdx.x;
     const bool in = i < B;
     const u64 idx = in ? lastbmu[i] : 0;
     bool todo = in;
@@ -614,9 +620,14 @@ __global__ __launch_bounds__(256) void hits_kernel(const u64 *__restrict__ lastb
 }
 
 #define FIN_TILE 8192
-__global__ __launch_bounds__(1024) void mse_kernel(const float *__restrict__ sqres, int B,
-                                                   float *__restrict__ mse)
+// one launch: workgroup 0 = the MSE running sum, workgroups 1.. = bmuHits of 1024 samples each
+__global__ __launch_bounds__(1024) void finish_kernel(const float *__restrict__ sqres, int B, float *__restrict__ mse,
+                                                      const u64 *__restrict__ lastbmu, u64 *__restrict__ hits)
 {
+    if (blockIdx.x > 0) {
+        finish_hits(lastbmu, B, hits, ((int)blockIdx.x - 1) * 1024);
+        return;
+    }
     // the running sum is serial by definition (fp32, sample order); everything around it is not:
     // the other threads fill the next tile (divisions) while thread 0 adds the current one out of
     // LDS, 16 values (4 x ds_read_b128) per dependent burst.
@@ -661,18 +672,13 @@ __global__ __launch_bounds__(1024) void mse_kernel(const float *__restrict__ sqr
 
 int launch_finish(vsom_ctx *c)
 {
-    {
-        TimerScope ts(c, VSOM_T_FINISH);
-        if (c->B > 0)
-            hipLaunchKernelGGL(hits_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, c->stream, c->lastbmu,
-                               (int)c->B, c->hits);
-        VSOM_HIP_CHECK(hipGetLastError());
-    }
-    // the serial MSE sum (~5 ns per sample) reads sqres and writes mse only: it runs on the side
-    // stream beside phase 2 and is joined at the end of launch_phase2 / by the next entry point
+    // the serial MSE sum (~5 ns per sample) reads sqres and writes mse only, bmuHits is read by no training step: both
+    // run as ONE launch on the side stream beside phase 2, joined at the end of launch_phase2 / by the next entry point
+    TimerScope ts(c, VSOM_T_FINISH);
     VSOM_HIP_CHECK(hipEventRecord(c->ev_fork, c->stream));
     VSOM_HIP_CHECK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(1024), 0, c->aux_stream, c->sqres, (int)c->B, c->mse);
+    hipLaunchKernelGGL(finish_kernel, dim3(1u + (unsigned)((c->B + 1023) / 1024)), dim3(1024), 0, c->aux_stream, c->sqres,
+                       (int)c->B, c->mse, c->lastbmu, c->hits);
     VSOM_HIP_CHECK(hipGetLastError());
     VSOM_HIP_CHECK(hipEventRecord(c->ev_join, c->aux_stream));
     c->aux_pending = true;

@@ -143,7 +143,7 @@ int vsom_device_count(void)
 static int free_all(vsom_ctx *c)
 {
     void *ptrs[] = {c->map, c->sigma, c->S, c->weight, c->hits, c->Xs, c->XP, c->YP, c->Xraw,
-                    c->lastbmu, c->sqres, c->mse, c->bxy, c->pair_i, c->pair_j, c->partial, c->nan0,
+                    c->lastbmu, c->sqres, c->mse, c->pair_i, c->pair_j, c->partial, c->nan0,
                     c->cw, c->lut, c->lutd, c->sl_G, c->sl_nrm, c->sl_scal, c->sl_list, c->sl_tmin, c->sl_fs, c->sl_fm, c->v_dev, c->res_dev, c->onl_state, c->onl_f,
                     c->cc_flags, c->cc_idx, c->cc_inv, c->cc_meta, c->Xc, c->Mc, c->Uc_map, c->Uc_S, c->Xq, c->zq, c->sl_xi, c->sl_l1, c->sl_q, c->sl_qscale, c->sl_qcorr};
     for (void *p : ptrs)
@@ -438,7 +438,7 @@ static int ensure_chunk_capacity(vsom_ctx *c, size_t B)
         return VSOM_OK;
     VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
     void **ptrs[] = {(void **)&c->Xs, (void **)&c->XP, (void **)&c->YP, (void **)&c->lastbmu,
-                     (void **)&c->sqres, (void **)&c->bxy, (void **)&c->nan0, (void **)&c->partial};
+                     (void **)&c->sqres, (void **)&c->nan0, (void **)&c->partial};
     for (void **p : ptrs) {
         if (*p)
             (void)hipFree(*p);
@@ -467,7 +467,6 @@ static int ensure_chunk_capacity(vsom_ctx *c, size_t B)
     }
     VSOM_HIP_CHECK(hipMalloc(&c->lastbmu, cap * 8));
     VSOM_HIP_CHECK(hipMalloc(&c->sqres, cap * 4));
-    VSOM_HIP_CHECK(hipMalloc(&c->bxy, cap * sizeof(int2)));
     VSOM_HIP_CHECK(hipMalloc(&c->nan0, cap));
     VSOM_HIP_CHECK(hipMemsetAsync(c->lastbmu, 0, cap * 8, c->stream));
     VSOM_HIP_CHECK(hipMemsetAsync(c->sqres, 0, cap * 4, c->stream));

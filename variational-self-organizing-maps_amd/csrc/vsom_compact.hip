@@ -25,23 +25,7 @@
 
 // meta: [0] live columns Kc (the chain kernels derive their live column quads from it), [1] live column quads ceil(Kc/4),
 //       [2] Kc rounded up to 32 (K of the contraction), [3] sequence number
-__global__ __launch_bounds__(256) void cc_flag_kernel(const float *__restrict__ xs, int ldx, int B, int D,
-                                                      unsigned *__restrict__ flags)
-{
-    // block = 16 rows x all columns; a column is live when any row holds something != 0 (NaN counts)
-    const int r0 = blockIdx.x * 16, r1 = r0 + 16 < B ? r0 + 16 : B;
-    for (int d = threadIdx.x; d < D; d += 256) {
-        bool live = false;
-        for (int r = r0; r < r1; ++r) {
-            const float v = xs[(size_t)r * ldx + d];
-            live |= !(v == 0.f);
-        }
-        if (live && flags[d] == 0u)
-            flags[d] = 1u;          // every writer stores the same value: no atomic needed
-    }
-}
-
-__global__ __launch_bounds__(1024) void cc_scan_kernel(const unsigned *__restrict__ flags, int D, int cpitch,
+__global__ __launch_bounds__(1024) void cc_scan_kernel(unsigned *__restrict__ flags, int D, int cpitch,
                                                        int *__restrict__ idx, int *__restrict__ inv,
                                                        unsigned *__restrict__ meta, unsigned *__restrict__ host_fb)
 {
@@ -54,6 +38,8 @@ __global__ __launch_bounds__(1024) void cc_scan_kernel(const unsigned *__restric
     for (int d0 = 0; d0 < D; d0 += 1024) {
         const int d = d0 + (int)threadIdx.x;
         const int f = d < D && flags[d] ? 1 : 0;
+        if (d < D)
+            flags[d] = 0u;              // cleared for the next chunk's staging pass (stage_rows_kernel sets them)
         const unsigned long long m = __ballot(f);
         const int before = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0)
@@ -170,6 +156,7 @@ static int cc_ensure(vsom_ctx *c)
         c->cpitch = (c->D + 31) / 32 * 32;
     if (!c->cc_meta) {
         VSOM_HIP_CHECK(hipMalloc(&c->cc_flags, (size_t)c->xpitch * 4));
+        VSOM_HIP_CHECK(hipMemsetAsync(c->cc_flags, 0, (size_t)c->xpitch * 4, c->stream));
         VSOM_HIP_CHECK(hipMalloc(&c->cc_idx, (size_t)c->cpitch * 4));
         VSOM_HIP_CHECK(hipMalloc(&c->cc_inv, (size_t)c->xpitch * 4));
         const size_t meta_bytes = 64;
@@ -195,9 +182,10 @@ static int cc_ensure(vsom_ctx *c)
     return VSOM_OK;
 }
 
-// after the rows are staged: which columns are live, and the chunk gathered onto them
-int vsom_cc_stage(vsom_ctx *c)
+// before the rows are staged: does this chunk get the compaction?  (then stage_rows_kernel also flags the live columns)
+int vsom_cc_begin(vsom_ctx *c, bool *on)
 {
+    *on = false;
     c->cc_valid = false;
     // small chunks: the passes (and the model-row gather / expansion around them) cost more than a few retired
     // column quads of a short chain save; vsom_set_column_compaction moves the threshold
@@ -218,9 +206,13 @@ int vsom_cc_stage(vsom_ctx *c)
     int rc = cc_ensure(c);
     if (rc)
         return rc;
-    VSOM_HIP_CHECK(hipMemsetAsync(c->cc_flags, 0, (size_t)c->xpitch * 4, c->stream));
-    hipLaunchKernelGGL(cc_flag_kernel, dim3((unsigned)((c->B + 15) / 16)), dim3(256), 0, c->stream, c->Xs, (int)c->xpitch,
-                       (int)c->B, (int)c->D, c->cc_flags);
+    *on = true;
+    return VSOM_OK;
+}
+
+// after the rows are staged (and their live columns flagged): the live-column record, and the chunk gathered onto them
+int vsom_cc_stage(vsom_ctx *c)
+{
     hipLaunchKernelGGL(cc_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->cc_flags, (int)c->D, (int)c->cpitch, c->cc_idx,
                        c->cc_inv, c->cc_meta, c->cc_fb);
     hipLaunchKernelGGL(cc_gather_rows_kernel, dim3((unsigned)c->B), dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->Xc,

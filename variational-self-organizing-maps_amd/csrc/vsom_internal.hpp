@@ -74,7 +74,6 @@ struct vsom_ctx {
     u64 *lastbmu = nullptr;
     float *sqres = nullptr;
     float *mse = nullptr;           // [1]
-    int2 *bxy = nullptr;            // BMU coordinates per sample (SomIndex quirk)
     int *pair_i = nullptr, *pair_j = nullptr;   // CLR pair tables [P]
 
     // BMU tile-search scratch
@@ -94,6 +93,7 @@ struct vsom_ctx {
     uint32_t sl_kp8 = 0;
     bool xi_valid = false;          // sl_xi / sl_l1 describe the staged chunk
     bool sl_i8 = true;              // try the integer contraction (cleared when a chunk turns out not to be uint8 data)
+    int sl_par = 0;                 // which of the two scal sets the next search uses
     int sl_skip = 0;
     unsigned sl_seq_seen = 0;       // feedback sequence number already acted on
     int sl_fail_streak = 0;         // consecutive probes that had to redo most samples exactly
@@ -183,6 +183,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1);
 int ensure_lut(vsom_ctx *c, double sigma);
 // column compaction (vsom_compact.hip)
 bool vsom_cc_applies(const vsom_ctx *c);
+int vsom_cc_begin(vsom_ctx *c, bool *on);
 int vsom_cc_stage(vsom_ctx *c);
 int vsom_cc_gather_map(vsom_ctx *c);
 int vsom_cc_ensure_update_scratch(vsom_ctx *c);

@@ -479,20 +479,21 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     }
 }
 
-__global__ void sl_reset_kernel(unsigned *scal)
+// copies {redo samples, candidates} of this call into the host-visible feedback words
+// ... and clears the counters of the OTHER scal set for the next search (the two sets alternate, so no launch is
+// needed to reset them: nobody touches the other set during this search)
+__global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsigned nrows, const unsigned *xflag,
+                                   unsigned *scal_next)
 {
     if (threadIdx.x < 8)
-        scal[threadIdx.x] = 0u;
+        scal_next[threadIdx.x] = 0u;
     if (threadIdx.x < 32) {
-        scal[16 + 32 * threadIdx.x] = 0u;     // candidate-count slots
-        scal[1024 + 32 * threadIdx.x] = 0u;   // max |M|^2 / max eps slots of the integer contraction (vsom_sl_i8.hip)
-        scal[2048 + 32 * threadIdx.x] = 0u;
+        scal_next[16 + 32 * threadIdx.x] = 0u;     // candidate-count slots
+        scal_next[1024 + 32 * threadIdx.x] = 0u;   // max |M|^2 / max eps slots of the integer contraction (vsom_sl_i8.hip)
+        scal_next[2048 + 32 * threadIdx.x] = 0u;
     }
-}
-
-// copies {redo samples, candidates} of this call into the host-visible feedback words
-__global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsigned nrows, const unsigned *xflag)
-{
+    if (threadIdx.x != 0)
+        return;
     unsigned cand = 0;
     for (int sl = 0; sl < 32; ++sl)
         cand += scal[16 + 32 * sl];
@@ -543,13 +544,15 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     }
     if (!c->sl_nrm) {
         VSOM_HIP_CHECK(hipMalloc(&c->sl_nrm, (size_t)c->N * sizeof(float)));
-        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 16384));  // 16 words + 3 x 32 line-sized slots + the chunk's data-kind flag
+        // two alternating sets of {16 words + 3 x 32 line-sized slots} (4096 words each) + the chunk's data-kind flag
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 3 * 16384));
+        VSOM_HIP_CHECK(hipMemsetAsync(c->sl_scal, 0, 3 * 16384, c->stream));
         VSOM_HIP_CHECK(hipHostMalloc(&c->sl_fb, 64));
         std::memset(c->sl_fb, 0, 64);
     }
     // scal: [0] max nrm bits, [1] non-finite flag, [2] redo count, [4] redo samples, [5] candidates
-    unsigned *scal = c->sl_scal;
-    hipLaunchKernelGGL(sl_reset_kernel, dim3(1), dim3(64), 0, c->stream, scal);
+    unsigned *scal = c->sl_scal + 4096 * c->sl_par, *scal_next = c->sl_scal + 4096 * (c->sl_par ^ 1);
+    c->sl_par ^= 1;
     // chunks of small non-negative integers (MNIST pixels): the contraction in exact integer arithmetic on the int8
     // matrix pipe (vsom_sl_i8.hip).  Whether a chunk is of that kind is a device-side fact: the host goes by the
     // feedback of the previous search (a chunk that is not is searched exactly, once, and the context returns to the
@@ -557,11 +560,9 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     if (c->sl_i8 && c->sl_fb && ((volatile unsigned *)c->sl_fb)[4] != 0u)
         c->sl_i8 = false;
     const bool i8 = c->sl_i8 && c->xpitch <= 4096;
-    unsigned *xflag = scal + 4000;
+    unsigned *xflag = c->sl_scal + 8192;
     dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
     if (i8) {
-        if (!c->xi_valid)
-            VSOM_HIP_CHECK(hipMemsetAsync(xflag, 0, 4, c->stream));
         int rc = launch_sl_i8(c, s0, s1, ldg, ntm, xflag);
         if (rc)
             return rc;
@@ -598,8 +599,8 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
                        (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(i8 ? 3.3 * u : 2.0 * g1),
                        (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, (const float *)nullptr, 0, 0, 0.f,
                        (unsigned)SL_CMAX, (const float *)c->sl_l1, i8 ? 2.0f : 0.f, (const unsigned *)xflag);
-    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
-                       i8 ? (const unsigned *)xflag : (const unsigned *)nullptr);
+    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(64), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
+                       i8 ? (const unsigned *)xflag : (const unsigned *)nullptr, scal_next);
     VSOM_HIP_CHECK(hipGetLastError());
     // exact-order redo of the listed samples (device-side count; blocks beyond it exit at once)
     return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2);
@@ -778,13 +779,14 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
     c->sl_list_cap = capL / sizeof(int);
     if (!c->sl_nrm) {
         VSOM_HIP_CHECK(hipMalloc(&c->sl_nrm, (size_t)c->N * sizeof(float)));
-        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 16384));
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_scal, 3 * 16384));
+        VSOM_HIP_CHECK(hipMemsetAsync(c->sl_scal, 0, 3 * 16384, c->stream));
         VSOM_HIP_CHECK(hipHostMalloc(&c->sl_fb, 64));
         std::memset(c->sl_fb, 0, 64);
     }
     // scal: [0] max nB bits, [1] non-finite flag, [2] redo count, [3] max A^2 bits, [4] redo samples
-    unsigned *scal = c->sl_scal;
-    hipLaunchKernelGGL(sl_reset_kernel, dim3(1), dim3(64), 0, c->stream, scal);
+    unsigned *scal = c->sl_scal + 4096 * c->sl_par, *scal_next = c->sl_scal + 4096 * (c->sl_par ^ 1);
+    c->sl_par ^= 1;
     hipLaunchKernelGGL(clr_node_feat_kernel, dim3((unsigned)c->N), dim3(256), 0, c->stream, c->map, (int)c->pitch,
                        (int)c->part_pitch, (int)P, (int)J, c->sl_fm, (int)Kp, (int)P32, (int)c->N, c->sl_nrm, scal);
     hipLaunchKernelGGL(clr_sample_feat_kernel, dim3((unsigned)nrows), dim3(256), 0, c->stream, c->XP, c->YP, (int)c->part_pitch,
@@ -809,8 +811,8 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
                        (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(1.0001 * ga), (float)(1.0001 * g2),
                        c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, c->Xs, (int)c->xpitch, (int)J, (float)(1.0001 * e1), 128u,
                        (const float *)nullptr, 0.f, (const unsigned *)nullptr);
-    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(1), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
-                       (const unsigned *)nullptr);
+    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(64), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
+                       (const unsigned *)nullptr, scal_next);
     VSOM_HIP_CHECK(hipGetLastError());
     return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2);
 }

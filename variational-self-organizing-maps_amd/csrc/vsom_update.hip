@@ -7,8 +7,7 @@
 //   map[i] = M ; sigmaMap[i] = sqrt(S / W) ; weightMap[i] = W             :870-875
 //
 // Split into
-//   bxy_kernel   : SomIndex(*this, lastBMU[j]) once per sample               (:847-849)
-//   cwp_kernel   : the neighbourhood chain per node: LUT lookup of w (the double exp is tabulated on
+//   cwp_kernel   : SomIndex(*this, lastBMU[j]) (:847-849) and the neighbourhood chain per node: LUT lookup of w (the double exp is tabulated on
 //                  the host over (|dx|,|dy|), bit-identical), the serial fp32 prefix sum W and
 //                  c = w/W -> cw[j][i] = (c, w).  Role-split workgroups: one wavefront only adds,
 //                  eight look up / divide / store.
@@ -31,17 +30,6 @@
 // (c,w) layout: pair-interleaved, one float4 {c_j, w_j, c_j+1, w_j+1} per node and sample pair at
 // [(j>>1)][node] -- the chain kernels stage it with 16-byte loads.
 
-__global__ void bxy_kernel(const u64 *__restrict__ lastbmu, int B, int W, int H,
-                           int2 *__restrict__ bxy)
-{
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= B)
-        return;
-    int x, y;
-    vsom_somindex(lastbmu[j], (u64)W, (u64)H, x, y);
-    bxy[j] = make_int2(x, y);
-}
-
 // Role-split neighbourhood chain: one workgroup (9 wavefronts) serves NW nodes and walks the chunk
 // in tiles of T samples (NW*T = 2048) through LDS.  Wavefront 0 does nothing but the serial part --
 // the fp32 prefix W_j = W_{j-1} + w_j of tile t (one LDS read, one add, one LDS write per sample);
@@ -51,7 +39,7 @@ __global__ void bxy_kernel(const u64 *__restrict__ lastbmu, int B, int W, int H,
 #define CWP_WT 512                               // worker threads
 #define CWP_THREADS (64 + CWP_WT)
 template <int NW, int T, bool LUT_LDS>
-__global__ __launch_bounds__(CWP_THREADS) void cwp_kernel(const int2 *__restrict__ bxy, int B, int n0, int n1,
+__global__ __launch_bounds__(CWP_THREADS) void cwp_kernel(const u64 *__restrict__ lastbmu, int B, int n0, int n1,
                                                           int W, int H, const float *__restrict__ lut,
                                                           int lutw, int luth, float2 *__restrict__ cw, int ldn,
                                                           float *__restrict__ weight)
@@ -85,7 +73,10 @@ __global__ __launch_bounds__(CWP_THREADS) void cwp_kernel(const int2 *__restrict
     auto load_bxy = [&](int t) {                 // workers: coordinates of tile t -> ring slot t%3
         if (t < ntiles && wt < T) {
             const int j = t * T + wt;
-            bL[(t % 3) * T + wt] = j < B ? bxy[j] : make_int2(0, 0);
+            int bx = 0, by = 0;
+            if (j < B)
+                vsom_somindex(lastbmu[j], (u64)W, (u64)H, bx, by);   // SomIndex(*this, lastBMU[j]) (Som.cpp:847-849)
+            bL[(t % 3) * T + wt] = make_int2(bx, by);
         }
     };
     // Both worker stages read everything first and write afterwards: the compiler does not move LDS
@@ -638,8 +629,6 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
     }
     {
         TimerScope ts(c, VSOM_T_CW);
-        hipLaunchKernelGGL(bxy_kernel, dim3((unsigned)((c->B + 255) / 256)), dim3(256), 0, c->stream,
-                           c->lastbmu, (int)c->B, (int)c->W, (int)c->H, c->bxy);
         // role-split kernel, 16 nodes per workgroup; the table in LDS only while it is small: what counts is how
         // many workgroups (worker wavefronts) a CU holds -- 40 KB of tiles each; a 64-KB table (128x128 map) would
         // leave one per CU.  Measured at C3: 64 nodes + LDS table 0.153 ms, 32 + global 0.142, 16 + global 0.121,
@@ -651,7 +640,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
         const void *fn = lds ? (const void *)cwp_kernel<nw, T, true> : (const void *)cwp_kernel<nw, T, false>;
         if (smem > 64 * 1024)
             VSOM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        const int2 *bxy = c->bxy;
+        const u64 *bxy = c->lastbmu;
         int B = (int)c->B, in0 = (int)n0, in1 = (int)n1, iW = (int)c->W, iH = (int)c->H, lw = (int)c->lut_w,
             lh = (int)c->lut_h, ildn = (int)ldn;
         const float *lut = c->lut;
