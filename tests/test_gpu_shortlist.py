@@ -288,3 +288,75 @@ def test_clr_shortlist_duplicates_zero_map_nan_and_inf_rows():
     idx, dist = _run(ctx, capi.BMU_SHORTLIST)
     assert beq(idx, lb_o) and beq(dist, sq_o)
     ctx.close()
+
+
+def test_integer_contraction_and_its_fallbacks():
+    """The shortlist's contraction runs in exact integer arithmetic on the int8 matrix pipe for chunks of small
+    non-negative integers (csrc/vsom_sl_i8.hip); whether a chunk is of that kind is a device-side fact.  One context
+    sees, in turn: uint8-valued chunks (integer contraction), a chunk with a non-integer / a negative / a 256 / a NaN
+    value (searched exactly this once: the host then returns to the fp32 contraction), uint8-valued chunks again (fp32
+    contraction now) -- and a second context whose model holds huge, tiny, denormal and exactly-zero rows (the digit
+    grid's scale is per row).  Indices and distances equal the oracle's bit for bit every time."""
+    W, H, J, B = 40, 36, 784, 260
+    rs = np.random.RandomState(11)
+    init = (gen.random_map(W * H, J, 42) * np.float32(120) + np.float32(110)).astype(np.float32)
+    o = po.OracleSom(W, H, J)
+    o.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_bmu_mode(capi.BMU_SHORTLIST)
+    ctx.set_state(map=init)
+
+    def check(X, tag):
+        ctx.upload_chunk(X)
+        idx, dist = ctx.bmu_batch()
+        lb_o, sq_o = _oracle_bmu(o, X)
+        assert beq(idx, lb_o) and beq(dist, sq_o), tag
+
+    Xa = gen.mnist_like(B, 3, J)
+    Xb = gen.mnist_like(B, 4, J)
+    Xb[:, 300:310] = 255.0                                       # the largest value of the grid
+    check(Xa, "uint8 a")
+    check(Xb, "uint8 b")
+    for k, bad in enumerate((0.5, -1.0, 256.0, np.nan, np.inf)):
+        Xc = gen.mnist_like(B, 5 + k, J)
+        Xc[17, 401] = bad
+        c2 = vsom_amd.Context(W, H, J)                           # a fresh context: the integer contraction is tried
+        c2.set_bmu_mode(capi.BMU_SHORTLIST)
+        c2.set_state(map=init)
+        for X, tag in ((Xa, "before"), (Xc, "odd value"), (Xa, "after 1"), (Xb, "after 2")):
+            c2.upload_chunk(X)
+            idx, dist = c2.bmu_batch()
+            lb_o, sq_o = _oracle_bmu(o, X)
+            assert beq(idx, lb_o) and beq(dist, sq_o), (bad, tag)
+        c2.close()
+    check(gen.blobs(B, J, 6, 1, 2, sigma=0.5), "float data")
+    check(Xa, "uint8 again (fp32 contraction)")
+    ctx.close()
+
+    # rows of very different magnitude, tiny / denormal / zero rows, a NaN row and node 0 NaN
+    init2 = init.copy()
+    init2[5] *= np.float32(1e6)
+    init2[6] *= np.float32(1e-9)
+    init2[7] = np.float32(3e-41) * rs.rand(J).astype(np.float32)
+    init2[8] = 0.0
+    init2[9, 100] = np.nan
+    init2[10] *= np.float32(1e15)
+    init2[11, ::7] = np.float32(1e-30)
+    o2 = po.OracleSom(W, H, J)
+    o2.set_state(map=init2)
+    c3 = vsom_amd.Context(W, H, J)
+    c3.set_bmu_mode(capi.BMU_SHORTLIST)
+    c3.set_state(map=init2)
+    for X in (Xa, Xb, np.zeros((40, J), np.float32)):
+        c3.upload_chunk(X)
+        idx, dist = c3.bmu_batch()
+        lb_o, sq_o = _oracle_bmu(o2, X)
+        assert beq(idx, lb_o) and beq(dist, sq_o)
+    init2[0, 3] = np.nan
+    o2.set_state(map=init2)
+    c3.set_state(map=init2)
+    c3.upload_chunk(Xa)
+    idx, dist = c3.bmu_batch()
+    lb_o, sq_o = _oracle_bmu(o2, Xa)
+    assert beq(idx, lb_o) and beq(dist, sq_o)
+    c3.close()
