@@ -67,41 +67,34 @@ __global__ __launch_bounds__(256) void sl_quant_x_kernel(const float *__restrict
 }
 
 // ---- model rows: |M|^2 (fp64 sum), live columns gathered, three 7-bit digits, row sums -------------------------------
-// one workgroup per node.  idx = live-column list of the compaction (null: identity), kp = contraction length
-// (device value kp_dev[2] when compacted).  q planes: [3][N][kp8].
+// one WAVEFRONT per node (4 per workgroup), no LDS, no barriers.  idx = live-column list of the compaction (null:
+// identity), kp = contraction length (device value kp_dev[2] when compacted).  q planes: [3][N][kp8].
 __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restrict__ map, int ldm, int Dp, int N,
                                                             const int *__restrict__ idx, int kp, const unsigned *__restrict__ kp_dev,
                                                             int kp8, signed char *__restrict__ q, float *__restrict__ nrm,
                                                             double *__restrict__ qscale, double *__restrict__ qcorr,
                                                             unsigned *__restrict__ scal)
 {
-    __shared__ float row[4096];
-    __shared__ double sd[4];
-    __shared__ float sf[4];
-    __shared__ int si[3][4];
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N)
+        return;
     if (kp_dev)
         kp = (int)kp_dev[2];
     const float *src = map + (size_t)n * ldm;
     double ss = 0.0;
-    for (int d = tid; d < Dp; d += 256) {               // rows are zero padded to Dp
-        const float v = src[d];
-        if (d < 4096)
-            row[d] = v;
-        ss += (double)v * (double)v;
+    for (int d = lane * 4; d < Dp; d += 256) {          // rows are zero padded to Dp, a multiple of 32
+        const float4 v = *reinterpret_cast<const float4 *>(src + d);
+        ss += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+        ss += (double)v.z * (double)v.z + (double)v.w * (double)v.w;
     }
     for (int off = 32; off > 0; off >>= 1)
         ss += __shfl_xor(ss, off);
-    if (lane == 0)
-        sd[wave] = ss;
-    __syncthreads();
-    const double tot = (sd[0] + sd[1]) + (sd[2] + sd[3]);
-    const float nf = (float)tot;                         // NaN rows stay NaN, overflow -> inf
+    const float nf = (float)ss;                          // NaN rows stay NaN, overflow -> inf
     // the row's largest live magnitude (non-finite values count as 0: such a row is excluded / redone anyway)
     float mx = 0.f;
-    for (int k = tid; k < kp; k += 256) {
+    for (int k = lane; k < kp; k += 64) {
         const int c = idx ? idx[k] : k;
-        float v = c >= 0 && c < Dp ? (c < 4096 ? row[c] : src[c]) : 0.f;
+        float v = c >= 0 && c < Dp ? src[c] : 0.f;
         v = fabsf(v);
         mx = (v <= 3.0e38f && v > mx) ? v : mx;
     }
@@ -109,10 +102,6 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
         const float o = __shfl_xor(mx, off);
         mx = o > mx ? o : mx;
     }
-    if (lane == 0)
-        sf[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(sf[0], sf[1]), fmaxf(sf[2], sf[3]));
     // s = 2^E with |M| / s < 64:  E = exponent(mx) - 5  (mx < 2^(exponent+1)); tiny rows: E >= -100
     int e = mx > 0.f ? (int)((__float_as_uint(mx) >> 23) & 0xFF) - 127 : -100;
     e = mx > 0.f && ((__float_as_uint(mx) >> 23) & 0xFF) == 0 ? -126 : e;      // denormal maximum
@@ -124,30 +113,40 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
     int r1 = 0, r2 = 0, r3 = 0;
     const size_t plane = (size_t)N * kp8;
     signed char *q1 = q + (size_t)n * kp8, *q2 = q1 + plane, *q3 = q2 + plane;
-    for (int k = tid; k < kp8; k += 256) {
-        int a = 0, b = 0, c3 = 0;
-        if (k < kp) {
-            const int c = idx ? idx[k] : k;
-            float v = c >= 0 && c < Dp ? (c < 4096 ? row[c] : src[c]) : 0.f;
-            v = fabsf(v) <= 3.0e38f ? v : 0.f;
-            float t = rintf(v * is1);                    // |v| / s < 64 unless the row is tiny (E clamped): clamp
-            t = fminf(fmaxf(t, -64.f), 64.f);
-            const float ra = v - t * s1;                 // exact
-            float t2 = rintf(ra * is2);
-            t2 = fminf(fmaxf(t2, -64.f), 64.f);
-            const float rb = ra - t2 * s2;               // exact
-            float t3 = rintf(rb * is3);
-            t3 = fminf(fmaxf(t3, -64.f), 64.f);
-            a = (int)t;
-            b = (int)t2;
-            c3 = (int)t3;
+    for (int k4 = lane * 4; k4 < kp8; k4 += 256) {      // four columns per lane and step: 4-byte stores
+        char4 o1, o2, o3;
+        signed char *p1 = reinterpret_cast<signed char *>(&o1), *p2 = reinterpret_cast<signed char *>(&o2),
+                    *p3 = reinterpret_cast<signed char *>(&o3);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k4 + u;
+            int a = 0, b = 0, c3 = 0;
+            if (k < kp) {
+                const int c = idx ? idx[k] : k;
+                float v = c >= 0 && c < Dp ? src[c] : 0.f;
+                v = fabsf(v) <= 3.0e38f ? v : 0.f;
+                float t = rintf(v * is1);                // |v| / s < 64 unless the row is tiny (E clamped): clamp
+                t = fminf(fmaxf(t, -64.f), 64.f);
+                const float ra = v - t * s1;             // exact
+                float t2 = rintf(ra * is2);
+                t2 = fminf(fmaxf(t2, -64.f), 64.f);
+                const float rb = ra - t2 * s2;           // exact
+                float t3 = rintf(rb * is3);
+                t3 = fminf(fmaxf(t3, -64.f), 64.f);
+                a = (int)t;
+                b = (int)t2;
+                c3 = (int)t3;
+            }
+            p1[u] = (signed char)a;
+            p2[u] = (signed char)b;
+            p3[u] = (signed char)c3;
+            r1 += a;
+            r2 += b;
+            r3 += c3;
         }
-        q1[k] = (signed char)a;
-        q2[k] = (signed char)b;
-        q3[k] = (signed char)c3;
-        r1 += a;
-        r2 += b;
-        r3 += c3;
+        *reinterpret_cast<char4 *>(q1 + k4) = o1;
+        *reinterpret_cast<char4 *>(q2 + k4) = o2;
+        *reinterpret_cast<char4 *>(q3 + k4) = o3;
     }
     for (int off = 32; off > 0; off >>= 1) {
         r1 += __shfl_xor(r1, off);
@@ -155,18 +154,9 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
         r3 += __shfl_xor(r3, off);
     }
     if (lane == 0) {
-        si[0][wave] = r1;
-        si[1][wave] = r2;
-        si[2][wave] = r3;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const long long R1 = (long long)si[0][0] + si[0][1] + si[0][2] + si[0][3];
-        const long long R2 = (long long)si[1][0] + si[1][1] + si[1][2] + si[1][3];
-        const long long R3 = (long long)si[2][0] + si[2][1] + si[2][2] + si[2][3];
         nrm[n] = nf;
         qscale[n] = (double)s3;                          // s 2^-14: multiplies 16384 I1 + 128 I2 + I3
-        qcorr[n] = 128.0 * (double)(R1 * 16384 + R2 * 128 + R3);   // the (x - 128) offset put back
+        qcorr[n] = 128.0 * (double)((long long)r1 * 16384 + (long long)r2 * 128 + (long long)r3);   // the (x - 128) offset put back
         const int slot = n & 31;
         if (nf == nf) {
             if (nf > 3.0e38f)
@@ -346,7 +336,7 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
         c->xi_valid = true;
     }
     const unsigned *kp_dev = compact ? (const unsigned *)c->cc_meta : nullptr;
-    hipLaunchKernelGGL(sl_prepare_i8_kernel, dim3((unsigned)c->N), dim3(256), 0, c->stream, c->map, (int)c->pitch,
+    hipLaunchKernelGGL(sl_prepare_i8_kernel, dim3((unsigned)((c->N + 3) / 4)), dim3(256), 0, c->stream, c->map, (int)c->pitch,
                        (int)c->part_pitch, (int)c->N, compact ? (const int *)c->cc_idx : (const int *)nullptr, (int)kmax, kp_dev,
                        (int)kp8, c->sl_q, c->sl_nrm, c->sl_qscale, c->sl_qcorr, scal);
     constexpr int MI = 2;
