@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
 // flight.  The contraction itself is ~0.06 ms of matrix-pipe time at C3; what the kernel waits for is its staging
 // loads (1.8 GB out of L2 at MI = 2, one chunk of 20 KB per workgroup in flight): measured at C3 -- 128 x 64 tiles, two
 // workgroups per CU 0.37 ms, three (154 VGPRs) 0.27 ms; 64 x 64 tiles, five per CU (2.8 GB) 0.30 ms; the fp64
-// epilogue and the tile minima cost nothing measurable.  (Next: a ring of LDS stages filled by global_load_lds.)
+// epilogue and the tile minima cost nothing measurable there.  (Big problems take the LDS-DMA ring kernel below.)
 #define IT_N 64
 #define IK 64
 #define ILD 80      // LDS row stride in bytes (64 + 16: conflict-free 16-byte fragment reads)
@@ -294,6 +294,154 @@ __global__ __launch_bounds__(256, MI == 1 ? 5 : 3) void sl_gemm_i8_kernel(const 
     }
 }
 
+// ---- the same contraction with big tiles and a ring of LDS stages filled by LDS-DMA ---------------------------------------
+// What the register-staged kernel above waits for is its staging loads (1.8 GB out of L2 at C3 with ONE 20 KB chunk per
+// workgroup in flight).  Here: workgroup tile 256 samples x 128 nodes (0.9 GB), 8 wavefronts of 64 x 64 (2 x 2 MFMA tiles x
+// three digits = 192 accumulator registers), K in chunks of 64 bytes through a ring of THREE 40 KB stages that
+// global_load_lds_dwordx4 fills without passing through registers -- two chunks in flight while one is consumed, one
+// barrier per chunk.  Measured at C3: 0.26 ms against 0.28 (`SQ_VALU_MFMA_BUSY_CYCLES`: 32 cycles per MFMA, the matrix pipe
+// 24 % busy; with one workgroup per CU the K loop and the fp64 epilogue -- ~2400 of the 2900 VALU instructions per
+// wavefront -- no longer overlap across workgroups, which eats most of what the staging gains).
+// A wave-instruction deposits 1 KB contiguously (16 rows x 64 B); the 16-byte pieces of a row are
+// stored XOR-swizzled (slot = piece ^ ((row >> 2) & 3), applied on the GLOBAL side: each lane picks the piece that belongs
+// into its slot), which makes the 16-byte fragment reads of 32 consecutive rows conflict-free without row padding.
+#define RT_S 256
+#define RT_N 128
+#define RNS 3
+#define RSTAGE 40960      // A 256 x 64 B | q1 128 x 64 B | q2 | q3
+__global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed char *__restrict__ xi, int s0, int s1,
+                                                                 const signed char *__restrict__ q, int N, int kp,
+                                                                 const unsigned *__restrict__ kp_dev, int kp8,
+                                                                 const float *__restrict__ nrm, const double *__restrict__ qscale,
+                                                                 const double *__restrict__ qcorr, float *__restrict__ G, int ldg,
+                                                                 float *__restrict__ tmin, int ntm)
+{
+    if (kp_dev)
+        kp = (int)kp_dev[2];
+    const int nchunks = (kp + IK - 1) / IK;             // columns past kp hold q = 0
+    extern __shared__ __attribute__((aligned(1024))) signed char ring[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int sbase = s0 + blockIdx.y * RT_S, nbase = blockIdx.x * RT_N;
+    const size_t plane = (size_t)N * kp8;
+
+    // loader: 40 units of 1 KB per stage (A: 16 units of 16 rows, each digit plane: 8), 5 per wavefront
+    const signed char *src[5];
+    int dst[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int id = wave * 5 + i;
+        const int rin = lane >> 2, slot = lane & 3;
+        if (id < 16) {
+            const int row = id * 16 + rin;
+            int sr = sbase + row;
+            sr = sr < s1 ? sr : s1 - 1;                  // rows past the chunk: re-read the last one (never stored)
+            src[i] = xi + (size_t)sr * kp8 + ((slot ^ ((row >> 2) & 3)) << 4);
+            dst[i] = id * 1024;
+        } else {
+            const int pl = (id - 16) >> 3, u = (id - 16) & 7;
+            const int row = u * 16 + rin;
+            int n = nbase + row;
+            n = n < N ? n : N - 1;
+            src[i] = q + pl * plane + (size_t)n * kp8 + ((slot ^ ((row >> 2) & 3)) << 4);
+            dst[i] = 16384 + pl * 8192 + u * 1024;
+        }
+    }
+    auto issue = [&](int c) {                            // chunk c -> stage c % RNS
+        const int sb = (c % RNS) * RSTAGE;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + (size_t)c * IK),
+                                             (__attribute__((address_space(3))) void *)(ring + sb + dst[i]), 16, 0, 0);
+    };
+
+    v16i acc[3][2][2];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[l][i][j][r] = 0;
+
+    issue(0);
+    if (nchunks > 1)
+        issue(1);
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks)
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // my 5 pieces of chunk c have landed (chunk c+1's may be in flight)
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                 // everybody's pieces of chunk c; everybody is done with chunk c-1
+        if (c + 2 < nchunks)
+            issue(c + 2);                                // into the stage chunk c-1 was read from
+        const signed char *st = ring + (c % RNS) * RSTAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v4i a[2], b[3][2];
+            const int P = ks * 2 + lh;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wm * 64 + i * 32 + lr;
+                a[i] = *reinterpret_cast<const v4i *>(st + r * 64 + ((P ^ ((r >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = wn * 64 + j * 32 + lr;
+                    b[l][j] = *reinterpret_cast<const v4i *>(st + 16384 + l * 8192 + r * 64 + ((P ^ ((r >> 2) & 3)) << 4));
+                }
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[l][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[l][j], acc[l][i][j], 0, 0, 0);
+        }
+    }
+    // epilogue as above; a wavefront's 64 columns are exactly one 64-node tile of `tmin`
+    const float inf = __uint_as_float(0x7F800000u);
+    double nm[2], sc[2], cr[2];
+    int col[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        col[j] = nbase + wn * 64 + j * 32 + lr;
+        const bool ok = col[j] < N;
+        nm[j] = ok ? (double)nrm[col[j]] : 0.0;
+        sc[j] = ok ? qscale[col[j]] : 0.0;
+        cr[j] = ok ? qcorr[col[j]] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = sbase + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float mn = inf;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double t = (double)acc[0][i][j][r] * 16384.0 + (double)acc[1][i][j][r] * 128.0 + (double)acc[2][i][j][r] + cr[j];
+                const float g = (float)(nm[j] - 2.0 * (sc[j] * t));
+                if (row < s1 && col[j] < N)
+                    G[(size_t)(row - s0) * ldg + col[j]] = g;
+                const float m = (col[j] < N && g == g) ? g : inf;       // exact minimum of the finite entries: NaN -> +inf
+                mn = m < mn ? m : mn;
+            }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) {     // the 32 lanes that share this row
+                const float o = __shfl_xor(mn, off);
+                mn = o < mn ? o : mn;
+            }
+            if (lr == 0 && row < s1)
+                tmin[(size_t)(row - s0) * ntm + blockIdx.x * 2 + wn] = mn;
+        }
+    }
+}
+
 // ---- host --------------------------------------------------------------------------------------------------------------
 // prepares the int8 images and computes G / tmin for samples [s0, s1) (ldg, ntm as the fp32 path lays them out: 64-node
 // tile minima); scal must have been reset
@@ -339,10 +487,22 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
     hipLaunchKernelGGL(sl_prepare_i8_kernel, dim3((unsigned)((c->N + 3) / 4)), dim3(256), 0, c->stream, c->map, (int)c->pitch,
                        (int)c->part_pitch, (int)c->N, compact ? (const int *)c->cc_idx : (const int *)nullptr, (int)kmax, kp_dev,
                        (int)kp8, c->sl_q, c->sl_nrm, c->sl_qscale, c->sl_qcorr, scal);
-    constexpr int MI = 2;
-    dim3 grid((unsigned)ntm, (unsigned)((s1 - s0 + 64 * MI - 1) / (64 * MI)));   // ntm 64-node tiles (the last may lie past N: minima +inf)
-    hipLaunchKernelGGL(sl_gemm_i8_kernel<MI>, grid, dim3(256), 0, c->stream, c->sl_xi, (int)s0, (int)s1, c->sl_q, (int)c->N,
-                       (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm);
+    // big maps and chunks: 256 x 128 tiles through the LDS-DMA ring; otherwise (few tiles: they would not fill the
+    // chip) 128 x 64 tiles staged through registers
+    const size_t big_tiles = ((size_t)c->N + RT_N - 1) / RT_N * ((s1 - s0 + RT_S - 1) / RT_S);
+    static bool ring_ok = hipFuncSetAttribute((const void *)sl_gemm_i8_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              RNS * RSTAGE) == hipSuccess;
+    if (ring_ok && big_tiles >= 1024) {
+        dim3 grid((unsigned)(ntm / 2), (unsigned)((s1 - s0 + RT_S - 1) / RT_S));   // ntm = 2 ceil(N / 128) 64-node tiles
+        hipLaunchKernelGGL(sl_gemm_i8_ring_kernel, grid, dim3(512), RNS * RSTAGE, c->stream, c->sl_xi, (int)s0, (int)s1, c->sl_q,
+                           (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, c->sl_G, (int)ldg,
+                           c->sl_tmin, (int)ntm);
+    } else {
+        constexpr int MI = 2;
+        dim3 grid((unsigned)ntm, (unsigned)((s1 - s0 + 64 * MI - 1) / (64 * MI)));   // ntm 64-node tiles (the last may lie past N: minima +inf)
+        hipLaunchKernelGGL(sl_gemm_i8_kernel<MI>, grid, dim3(256), 0, c->stream, c->sl_xi, (int)s0, (int)s1, c->sl_q, (int)c->N,
+                           (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm);
+    }
     VSOM_HIP_CHECK(hipGetLastError());
     return VSOM_OK;
 }
