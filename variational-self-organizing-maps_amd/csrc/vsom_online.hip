@@ -40,6 +40,9 @@ struct OnlineArgs {
     float *fstate;
     int N, W, H;
     int par;             // sample parity: which key / flag this sample uses
+    // chunk loop: the search launch of sample j also finishes sample j-1 (its extra workgroup, online_scan_kernel)
+    const float *pxa, *pxb;   // rows of the sample being finished
+    int do_scan, do_post;
 };
 
 // BMU of the sample from its scan results; a NaN distance at node 0 pins it to 0 (Som.cpp:293-299)
@@ -59,9 +62,29 @@ __device__ __forceinline__ u64 online_resolve(const u64 *state, int par)
 #define VSOM_SCAN_UNR 14
 #endif
 template <bool CLR>
-__global__ __launch_bounds__(256) void online_scan_kernel(OnlineArgs a)
+__device__ __forceinline__ void online_post(const OnlineArgs &a, const float *xa, const float *xb, u64 bmu, int lane, u64 *hits,
+                                            u64 *lastbmu_out, float *residual, float fB, int add_hit);
+
+// POSTWG: the chunk loop's form.  The LAST workgroup does not search: it finishes the PREVIOUS sample (residual and
+// distance of its BMU after the window update :946, addBmu, MSE, lastBMU) and re-arms that sample's key set -- 2-3 us of
+// dependent row reads that used to sit at the end of the window launch's critical path, now hidden beside the 9.6 us
+// search (the window launch of the previous sample has completed: kernel boundary; the next window launch has not
+// started).  After the last sample of a chunk the kernel is launched once more with do_scan = 0.
+template <bool CLR, bool POSTWG>
+__global__ __launch_bounds__(256) void online_scan_kernel(OnlineArgs a, u64 *hits, u64 *lastbmu_out, float fB, int add_hit)
 {
     __shared__ u64 skey[4];
+    if (POSTWG && blockIdx.x == gridDim.x - 1) {
+        if (a.do_post && threadIdx.x < 64) {
+            const u64 bmu = online_resolve(a.state, a.par ^ 1);
+            online_post<CLR>(a, a.pxa, a.pxb, bmu, (int)threadIdx.x, hits, lastbmu_out, nullptr, fB, add_hit);
+            if (threadIdx.x < ONL_SLOTS)
+                *online_slot(a.state, a.par ^ 1, (int)threadIdx.x) = ~0ull;   // the key set of the sample after this one
+        }
+        return;
+    }
+    if (POSTWG && !a.do_scan)
+        return;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int node = gid >> 3, k = threadIdx.x & 7;
     const int nc = node < a.N ? node : a.N - 1;
@@ -273,16 +296,16 @@ __device__ __forceinline__ void online_window(u64 bmu, int W, int H, double sigm
 
 // residual / distance of the BMU after the update (:946), addBmu, MSE, lastBMU
 template <bool CLR>
-__device__ __forceinline__ void online_post(const OnlineArgs &a, u64 bmu, int lane, u64 *hits, u64 *lastbmu_out,
-                                            float *residual, float fB, int add_hit)
+__device__ __forceinline__ void online_post(const OnlineArgs &a, const float *xa, const float *xb, u64 bmu, int lane, u64 *hits,
+                                            u64 *lastbmu_out, float *residual, float fB, int add_hit)
 {
     const int k = lane & 7;
     const float *ma = a.d.ma + (size_t)bmu * a.d.ldm, *mb = a.d.mb + (size_t)bmu * a.d.ldm;
     if (residual) {
         for (int d = lane; d < a.d.L; d += 64)
-            residual[d] = vsom_resid<CLR>(a.d.xa[d], CLR ? a.d.xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
+            residual[d] = vsom_resid<CLR>(xa[d], CLR ? xb[d] : 0.f, ma[d], CLR ? mb[d] : 0.f);
     }
-    float dist = vsom_group_dist_lat<CLR>(a.d.xa, a.d.xb, ma, mb, a.d.L, k);
+    float dist = vsom_group_dist_lat<CLR>(xa, xb, ma, mb, a.d.L, k);
     if (lane == 0) {
         a.fstate[0] = dist;
         float q = dist / fB;                 // residual.squaredNorm() / epochSize  (:1167)
@@ -295,7 +318,7 @@ __device__ __forceinline__ void online_post(const OnlineArgs &a, u64 bmu, int la
 
 // one workgroup per node of the (maximal) window; nodes outside the actual window exit.  The
 // workgroup of the BMU node finishes the sample (post step) once its own update is visible.
-template <int KIND>
+template <int KIND, bool POST>
 __global__ __launch_bounds__(256) void online_window_kernel(
     OnlineArgs a, const float *__restrict__ xs, const float *__restrict__ xp, const float *__restrict__ yp,
     const double *__restrict__ lutd, int lutw, int D, int P, int ppitch, int pitch, double eta, double sigma,
@@ -317,11 +340,11 @@ __global__ __launch_bounds__(256) void online_window_kernel(
     const double h = lutd[(size_t)dy * lutw + dx];   // calculateNeighbourhoodWeight(i,j,bx,by,sigma) :915
     online_node_update<KIND, true>(n, h, threadIdx.x, blockDim.x, xs, xp, yp, D, P, ppitch, pitch, eta, decay_fn,
                                    map, Smap, sigmap, weight);
-    if (n != (size_t)bmu)        // the BMU always lies inside its own window (sigma > 1)
-        return;
+    if (!POST || n != (size_t)bmu)   // (chunk loop: the next search launch finishes the sample; the BMU always lies inside
+        return;                      //  its own window, sigma > 1)
     __syncthreads();             // this workgroup's writes of the BMU row are visible to its wave 0
     if (threadIdx.x < 64) {
-        online_post<CLR>(a, bmu, threadIdx.x, hits, lastbmu_out, residual, fB, add_hit);
+        online_post<CLR>(a, a.d.xa, a.d.xb, bmu, threadIdx.x, hits, lastbmu_out, residual, fB, add_hit);
         if (threadIdx.x < ONL_SLOTS)
             *online_slot(a.state, a.par ^ 1, (int)threadIdx.x) = ~0ull;   // arm the next sample's key (nobody reads it during this launch)
     }
@@ -376,13 +399,13 @@ __global__ __launch_bounds__(1024) void online_small_kernel(
                                         eta, decay_fn, map, Smap, sigmap, weight);
         if (n == (size_t)bmu) {        // the wavefront that rewrote the BMU's row finishes the sample while
             __threadfence_block();     // the others update their nodes
-            online_post<CLR>(a, bmu, lane, hits, lastbmu_io, residual, fB, add_hit);
+            online_post<CLR>(a, a.d.xa, a.d.xb, bmu, lane, hits, lastbmu_io, residual, fB, add_hit);
         }
     }
     // sigma < 0.4 truncates the window to nothing (:899-903): the BMU is not updated, the sample still counts
     const bool inside = (u64)bx >= startX && (u64)bx < endX && (u64)by >= startY && (u64)by < endY;
     if (!inside && wave == 0)
-        online_post<CLR>(a, bmu, lane, hits, lastbmu_io, residual, fB, add_hit);
+        online_post<CLR>(a, a.d.xa, a.d.xb, bmu, lane, hits, lastbmu_io, residual, fB, add_hit);
 }
 
 __global__ void online_init_kernel(u64 *state, float *fstate, int keep_mse)
@@ -429,14 +452,22 @@ static int ensure_lutd(vsom_ctx *c, double sigma, const double **out, int *lutw)
 }
 
 // enqueue one trainSingle on sample rows (xs / xp / yp), lastBMU in/out at `lastbmu_dev`
+// chunk = true: the chunk loop's pipelined form (sigma > 1) -- this search launch also finishes the PREVIOUS sample
+// (rows pxs / pxp / pyp, lastBMU out at lastbmu_dev - 1; j = 0: nothing to finish) and the window launch leaves its own
+// sample unfinished; the caller ends the chunk with enqueue_chunk_tail
 static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const float *yp,
                           double eta, double sigma, int decay_fn, u64 *lastbmu_dev,
                           float *residual_dev, float fB, int add_hit, const double *lutd, int lutw, int par,
-                          float *fstate = nullptr)
+                          float *fstate = nullptr, bool chunk = false, const float *pxs = nullptr, const float *pxp = nullptr,
+                          const float *pyp = nullptr)
 {
     OnlineArgs a;
     a.par = par & 1;
     const bool clr = c->transform == VSOM_CLR;
+    a.pxa = clr ? pxp : pxs;
+    a.pxb = clr ? pyp : pxs;
+    a.do_scan = 1;
+    a.do_post = chunk && pxs != nullptr;
     a.d.xa = clr ? xp : xs;
     a.d.xb = clr ? yp : xs;
     a.d.ldx = 0;
@@ -451,11 +482,19 @@ static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const f
     a.H = (int)c->H;
 
     if (sigma > 1) {   // SIGMA_SWITCH_TO_LOCAL (SOM.hpp:37, Som.cpp:891)
-        dim3 grid((unsigned)(((size_t)c->N * 8 + 255) / 256));
-        if (clr)
-            hipLaunchKernelGGL(online_scan_kernel<true>, grid, dim3(256), 0, c->stream, a);
-        else
-            hipLaunchKernelGGL(online_scan_kernel<false>, grid, dim3(256), 0, c->stream, a);
+        dim3 grid((unsigned)(((size_t)c->N * 8 + 255) / 256) + (chunk ? 1u : 0u));   // + the workgroup that finishes sample j-1
+        u64 *lb_prev = chunk && lastbmu_dev ? lastbmu_dev - 1 : nullptr;
+        if (chunk) {
+            if (clr)
+                hipLaunchKernelGGL((online_scan_kernel<true, true>), grid, dim3(256), 0, c->stream, a, c->hits, lb_prev, fB, add_hit);
+            else
+                hipLaunchKernelGGL((online_scan_kernel<false, true>), grid, dim3(256), 0, c->stream, a, c->hits, lb_prev, fB, add_hit);
+        } else {
+            if (clr)
+                hipLaunchKernelGGL((online_scan_kernel<true, false>), grid, dim3(256), 0, c->stream, a, c->hits, lb_prev, fB, add_hit);
+            else
+                hipLaunchKernelGGL((online_scan_kernel<false, false>), grid, dim3(256), 0, c->stream, a, c->hits, lb_prev, fB, add_hit);
+        }
     } else {
         // sigma <= 1: one fused launch (local search + <=6x6 window + post)
 #define LAUNCH_SMALL(KIND)                                                                                  \
@@ -479,17 +518,54 @@ static int enqueue_single(vsom_ctx *c, const float *xs, const float *xp, const f
     int bs = L >= 256 ? 256 : ((L + 63) / 64) * 64;
     if (bs < 64)
         bs = 64;
-#define LAUNCH_WIN(KIND)                                                                                    \
-    hipLaunchKernelGGL(online_window_kernel<KIND>, wgrid, dim3(bs), 0, c->stream, a, xs, xp, yp, lutd, lutw,   \
+#define LAUNCH_WIN(KIND, POST)                                                                              \
+    hipLaunchKernelGGL((online_window_kernel<KIND, POST>), wgrid, dim3(bs), 0, c->stream, a, xs, xp, yp, lutd, lutw, \
                        (int)c->D, (int)c->part_len, (int)c->part_pitch, (int)c->pitch, eta, sigma, decay_fn, \
                        c->map, c->S, c->sigma, c->weight, c->hits, lastbmu_dev, residual_dev, fB, add_hit)
-    if (c->transform == VSOM_CLR)
-        LAUNCH_WIN(VSOM_CLR);
-    else if (c->transform == VSOM_MEDIAN)
-        LAUNCH_WIN(VSOM_MEDIAN);
-    else
-        LAUNCH_WIN(VSOM_STANDARD);
+    if (chunk) {
+        if (c->transform == VSOM_CLR)
+            LAUNCH_WIN(VSOM_CLR, false);
+        else if (c->transform == VSOM_MEDIAN)
+            LAUNCH_WIN(VSOM_MEDIAN, false);
+        else
+            LAUNCH_WIN(VSOM_STANDARD, false);
+    } else {
+        if (c->transform == VSOM_CLR)
+            LAUNCH_WIN(VSOM_CLR, true);
+        else if (c->transform == VSOM_MEDIAN)
+            LAUNCH_WIN(VSOM_MEDIAN, true);
+        else
+            LAUNCH_WIN(VSOM_STANDARD, true);
+    }
 #undef LAUNCH_WIN
+    return VSOM_OK;
+}
+
+// end of a pipelined chunk (sigma > 1): finish its last sample (rows pxs / pxp / pyp, parity par_last); no search
+static int enqueue_chunk_tail(vsom_ctx *c, const float *pxs, const float *pxp, const float *pyp, u64 *lastbmu_last, float fB,
+                              int par_last)
+{
+    OnlineArgs a;
+    const bool clr = c->transform == VSOM_CLR;
+    a.par = (par_last & 1) ^ 1;      // the post workgroup works on parity par ^ 1
+    a.d.xa = a.pxa = clr ? pxp : pxs;
+    a.d.xb = a.pxb = clr ? pyp : pxs;
+    a.d.ldx = 0;
+    a.d.ma = c->map;
+    a.d.mb = clr ? c->map + c->part_pitch : c->map;
+    a.d.ldm = (int)c->pitch;
+    a.d.L = (int)c->part_len;
+    a.state = c->onl_state;
+    a.fstate = c->onl_f;
+    a.N = (int)c->N;
+    a.W = (int)c->W;
+    a.H = (int)c->H;
+    a.do_scan = 0;
+    a.do_post = 1;
+    if (clr)
+        hipLaunchKernelGGL((online_scan_kernel<true, true>), dim3(1), dim3(256), 0, c->stream, a, c->hits, lastbmu_last, fB, 1);
+    else
+        hipLaunchKernelGGL((online_scan_kernel<false, true>), dim3(1), dim3(256), 0, c->stream, a, c->hits, lastbmu_last, fB, 1);
     return VSOM_OK;
 }
 
@@ -561,10 +637,13 @@ int vsom_find_bmu(vsom_ctx *c, const float *v_host, uint64_t *bmu_out, float *di
     a.H = (int)c->H;
     VSOM_HIP_CHECK(hipMemsetAsync(c->onl_state, 0xFF, ONL_SLOTS * 16 * sizeof(u64), c->stream));   // arm the keys of parity 0
     dim3 grid((unsigned)(((size_t)c->N * 8 + 255) / 256));
+    a.pxa = a.pxb = nullptr;
+    a.do_scan = 1;
+    a.do_post = 0;
     if (clr)
-        hipLaunchKernelGGL(online_scan_kernel<true>, grid, dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((online_scan_kernel<true, false>), grid, dim3(256), 0, c->stream, a, (u64 *)nullptr, (u64 *)nullptr, 1.f, 0);
     else
-        hipLaunchKernelGGL(online_scan_kernel<false>, grid, dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((online_scan_kernel<false, false>), grid, dim3(256), 0, c->stream, a, (u64 *)nullptr, (u64 *)nullptr, 1.f, 0);
     VSOM_HIP_CHECK(hipGetLastError());
     u64 *st = reinterpret_cast<u64 *>(c->v_pinned + xs_n + 3 * pp + 32);   // image of onl_state (8-byte aligned: pitches are multiples of 32 floats)
     VSOM_HIP_CHECK(hipMemcpyAsync(st, c->onl_state, ONL_STATE_BYTES, hipMemcpyDeviceToHost, c->stream));
@@ -605,15 +684,23 @@ int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay
         hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f,
                            first_chunk ? 0 : 1);
         const float fB = (float)c->B;
+        const bool pipelined = sigma > 1;     // the search launch of sample j finishes sample j-1 (online_scan_kernel)
+        const float *pxs = nullptr, *pxp = nullptr, *pyp = nullptr;
         for (size_t j = 0; j < c->B; ++j) {
             const float *xs = c->Xs + j * c->xpitch;
             const float *xp = c->XP ? c->XP + j * c->part_pitch : nullptr;
             const float *yp = c->YP ? c->YP + j * c->part_pitch : nullptr;
             rc = enqueue_single(c, xs, xp, yp, eta, sigma, decay_fn, c->lastbmu + j, nullptr, fB, 1,
-                                lutd, lutw, (int)(j & 1));
+                                lutd, lutw, (int)(j & 1), nullptr, pipelined, pxs, pxp, pyp);
             if (rc)
                 return rc;
+            pxs = xs;
+            pxp = xp;
+            pyp = yp;
         }
+        if (pipelined && c->B > 0 &&
+            (rc = enqueue_chunk_tail(c, pxs, pxp, pyp, c->lastbmu + (c->B - 1), fB, (int)((c->B - 1) & 1))))
+            return rc;
         VSOM_HIP_CHECK(hipGetLastError());
     }
     // vsom_get_mse reports the chunk's MSE for callers that passed mse_out = NULL (asynchronous use)
