@@ -213,6 +213,21 @@ __device__ __forceinline__ void online_node_update(size_t n, double h, int tid, 
                                                    double eta, int decay_fn, float *map, float *Smap, float *sigmap,
                                                    float *weight)
 {
+    float *M = map + n * pitch, *S = Smap + n * pitch, *sg = sigmap + n * pitch;
+    // workgroup form, Standard / Median: this thread's first four elements are requested BEFORE the barrier below, so that
+    // weightMap[n], the table entry h and the rows travel in ONE memory round trip (the barrier waits for all of them)
+    constexpr bool PRE = BLOCK_SYNC && KIND != VSOM_CLR;
+    float px[4], pm[4], ps[4];
+    if (PRE) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = tid + u * nthr;
+            const bool ok = d < D;
+            px[u] = ok ? xs[d] : 0.f;
+            pm[u] = ok ? M[d] : 0.f;
+            ps[u] = ok ? S[d] : 0.f;
+        }
+    }
     const float wold = weight[n];
     float wnew, scM;
     if (decay_fn == VSOM_EXPONENTIAL) {
@@ -230,7 +245,6 @@ __device__ __forceinline__ void online_node_update(size_t n, double h, int tid, 
     if (tid == 0)
         weight[n] = wnew;
 
-    float *M = map + n * pitch, *S = Smap + n * pitch, *sg = sigmap + n * pitch;
     if (KIND == VSOM_CLR) {
         for (int p = tid; p < P; p += nthr) {
             const float x1 = xp[p], y1 = yp[p];
@@ -259,9 +273,10 @@ __device__ __forceinline__ void online_node_update(size_t n, double h, int tid, 
             sg[ppitch + p] = sqrtf(fabsf(SB / twf));
         }
     } else {
-        for (int d = tid; d < D; d += nthr) {
-            const float x = xs[d];
-            float m = M[d];
+        for (int d = tid, u = 0; d < D; d += nthr, ++u) {
+            const float x = PRE && u < 4 ? px[u < 4 ? u : 0] : xs[d];
+            float m = PRE && u < 4 ? pm[u < 4 ? u : 0] : M[d];
+            const float s_old = PRE && u < 4 ? ps[u < 4 ? u : 0] : S[d];
             float dl = x - m;                                // Stepper :912
             if (KIND == VSOM_MEDIAN)
                 dl = onl_sign(dl);
@@ -271,8 +286,8 @@ __device__ __forceinline__ void online_node_update(size_t n, double h, int tid, 
             if (KIND == VSOM_MEDIAN)
                 dl2 = onl_sign(dl2);
             float pr = dl * dl2;
-            float u = hf * pr;
-            float s = S[d] + u;                              // :941
+            float uu = hf * pr;
+            float s = s_old + uu;                            // :941
             M[d] = m;
             S[d] = s;
             sg[d] = sqrtf(fabsf(s / twf));                   // :942
