@@ -54,7 +54,8 @@ for cfg, (tag, kern) in KERNEL.items():
         cyc = v["GRBM_GUI_ACTIVE"] / 8.0
         ent["valu_insts_per_launch"] = v["SQ_INSTS_VALU"]
         ent["valu_issue_busy"] = round(v["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc, 4)
-        if v.get("GRBM_GUI_ACTIVE@us", 0) > 0:
+        # (launches of a few microseconds: the counter window and the traced duration do not cover the same interval)
+        if v.get("GRBM_GUI_ACTIVE@us", 0) > 100:
             ent["sustained_clock_ghz"] = round(cyc / v["GRBM_GUI_ACTIVE@us"] / 1e3, 3)
             ent["clock_note"] = "cycles of the launch (GRBM_GUI_ACTIVE / 8) over its duration under the counter pass"
     if "TCC_HIT" in v and "TCC_MISS" in v:
