@@ -97,6 +97,10 @@ def parse():
     ap.add_argument("--arith", choices=["strict", "sigma", "contracted"], default="strict",
                     help="arithmetic of the update chains for `value` (the others are reported beside it)")
     ap.add_argument("--no-other-arith", action="store_true", help="skip the second (other-arithmetic) timed run")
+    ap.add_argument("--data", choices=list(DATA_VARIANTS), default="uint8_sparse",
+                    help="c2 / c3: what the rows hold for `value` (default: the raw uint8-valued pixels of the reference's "
+                         "MNIST loader); the other two are timed in the same run and reported as `data_variants`")
+    ap.add_argument("--no-data-variants", action="store_true", help="skip the timed runs on the other data kinds")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--nchunks", type=int, default=4, help="distinct resident chunks cycled over")
@@ -135,8 +139,23 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def make_data(cfg, n, seed):
+DATA_VARIANTS = ("uint8_sparse", "float_sparse", "float_dense")
+DATA_TEXT = {
+    "uint8_sparse": ("raw MNIST-like pixels 0..255 as MnistDataLoader.cpp:73-75 yields them (the headline): integer "
+                     "contraction on one int8 digit per sample value, dead columns retired, zero-quad form"),
+    "float_sparse": ("the same pixels normalised to [0,1] (x/255, float-valued): three-digit integer contraction, dead "
+                     "columns retired, zero-quad form"),
+    "float_dense": ("signed dense float rows (8 blobs, unit sigma 0.5): none of the exact data-dependent shortcuts applies "
+                    "-- no dead column, no all-zero quad, no uint8 digit"),
+}
+
+
+def make_data(cfg, n, seed, variant="uint8_sparse"):
     import gen
+    if cfg["data"] == "mnist" and variant == "float_dense":
+        return gen.float_dense(n, seed=seed + 4, dim=cfg["dim"])
+    if cfg["data"] == "mnist" and variant == "float_sparse":
+        return (make_data(cfg, n, seed) / np.float32(255.0)).astype(np.float32)
     if cfg["data"] == "mnist":
         d = os.environ.get("VSOM_MNIST_DIR")
         if d:       # the real training images when the IDX files are at hand (none in the build image)
@@ -149,11 +168,12 @@ def make_data(cfg, n, seed):
     return gen.correlated(n, cfg["dim"], seed)
 
 
-def make_map(cfg, depth):
+def make_map(cfg, depth, variant="uint8_sparse"):
     import gen
     n = cfg["map"] * cfg["map"]
-    if cfg["data"] == "mnist":
-        return gen.random_map(n, depth, seed=42, scale=1.0) * np.float32(100.0) + np.float32(100.0)
+    if cfg["data"] == "mnist" and variant != "float_dense":
+        m = gen.random_map(n, depth, seed=42, scale=1.0) * np.float32(100.0) + np.float32(100.0)
+        return m if variant == "uint8_sparse" else (m / np.float32(255.0)).astype(np.float32)
     return gen.random_map(n, depth, seed=42)
 
 
@@ -305,7 +325,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = vsom_amd.Context(W, H, J, tr, device=local_rank)
     D = ctx.depth
-    init_map = make_map(cfg, D)
+    init_map = make_map(cfg, D, args.data)
     ctx.set_state(map=init_map)
     eng = vdist.HipEngine(ctx, dev, stream)      # the context adopts `stream`; collectives run on it too
     trainer = vdist.ShardedBatchTrainer(eng, rank if sharded else 0, world if sharded else 1)
@@ -318,20 +338,22 @@ def main():
     Bcfg = cfg["chunk"]
 
     class Split:
-        def __init__(self, kind):
+        def __init__(self, kind, variant=None):
             self.kind = kind
+            variant = variant or args.data
+            self.variant = variant
             if not sharded:
                 self.Bper, self.Bglob, self.lo = Bcfg, Bcfg, 0
-                self.own_host = [make_data(cfg, Bcfg, seed=3 + i) for i in range(args.nchunks)]
+                self.own_host = [make_data(cfg, Bcfg, 3 + i, variant) for i in range(args.nchunks)]
             elif kind == "strong":
                 lo, hi = vdist.shard_bounds(Bcfg, world, rank)
                 if Bcfg % world:
                     raise SystemExit("--scaling strong needs the chunk to divide by the number of GPUs")
                 self.Bper, self.Bglob, self.lo = hi - lo, Bcfg, lo
-                self.own_host = [np.ascontiguousarray(make_data(cfg, Bcfg, seed=3 + i)[lo:hi]) for i in range(args.nchunks)]
+                self.own_host = [np.ascontiguousarray(make_data(cfg, Bcfg, 3 + i, variant)[lo:hi]) for i in range(args.nchunks)]
             else:
                 self.Bper, self.Bglob, self.lo = Bcfg, Bcfg * world, Bcfg * rank
-                self.own_host = [make_data(cfg, Bcfg, seed=3 + i + 1000 * rank) for i in range(args.nchunks)]
+                self.own_host = [make_data(cfg, Bcfg, 3 + i + 1000 * rank, variant) for i in range(args.nchunks)]
             self.own = [torch.from_numpy(c).to(dev) for c in self.own_host]
             self.full = torch.empty((self.Bglob, J), dtype=torch.float32, device=dev) if sharded else None
 
@@ -416,6 +438,20 @@ def main():
             dto, tmo = timed(split, 2, args.steps)
             others.append((name, dto, tmo))
         ctx.set_update_mode(mode_of[args.arith])
+
+    # the same step on rows of the other kinds (strict or whatever --arith says; its own chunks, its own start map)
+    variants = []
+    if cfg["data"] == "mnist" and not online and world == 1 and not args.no_data_variants and args.host_chunks == "off":
+        for vname in DATA_VARIANTS:
+            if vname == args.data:
+                continue
+            spv = Split("single", vname)
+            torch.cuda.synchronize()
+            ctx.set_state(map=make_map(cfg, D, vname))
+            dtv, tmv = timed(spv, 3, args.steps)
+            variants.append((vname, spv, dtv, tmv, ctx.shortlist_stats()))
+            del spv.own
+        ctx.set_state(map=init_map)
 
     other_split = None
     if sharded and not args.no_other_scaling:
@@ -555,6 +591,24 @@ def main():
                     "value": round(steps * units_of(split) / dto, 3), "ms_per_step": round(dto / steps * 1e3, 4),
                     "update_avg_launch_ms": ro.get("avg_launch_ms"), "update_achieved_tflops": ro.get("achieved"),
                     "update_frac_of_peak": ro.get("frac")})
+        if variants or cfg["data"] == "mnist":
+            out["data"] = "synthetic"
+            out["data_kind"] = {"name": split.variant, "note": DATA_TEXT[split.variant]}
+        if variants:
+            out["data_variants"] = []
+            for vname, spv, dtv, tmv, slv in variants:
+                rv = roofline_for(tmv, spv)
+                lv, cv = gen.column_occupancy(spv.own_host[0])
+                out["data_variants"].append({
+                    "data": vname, "note": DATA_TEXT[vname],
+                    "value": round(steps * units_of(spv) / dtv, 3), "ms_per_step": round(dtv / steps * 1e3, 4),
+                    "vs_headline": round(dt / dtv, 4),
+                    "bmu_ms": round(tmv["bmu"][0] / steps, 4), "update_ms": round(tmv["update"][0] / steps, 4),
+                    "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in tmv.items()},
+                    "live_columns": lv,
+                    "roofline": {k: rv.get(k) for k in ("achieved", "frac", "frac_executed", "avg_launch_ms",
+                                                         "executed_basis")},
+                    "bmu_shortlist_last": slv})
         if other_split is not None:
             sp2, dt2, tm2 = other_split
             out[sp2.kind + "_scaling"] = {

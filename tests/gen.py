@@ -92,6 +92,18 @@ def mnist_like(n, seed=3, dim=784):
     return out
 
 
+def float_sparse(n, seed=3, dim=784):
+    """The MNIST-like pixels normalised to [0, 1] -- what a caller who divides by 255 hands over: float-valued (no
+    uint8 shortcut of the search applies), same dead columns and zero quads as mnist_like."""
+    return (mnist_like(n, seed=seed, dim=dim) / np.float32(255.0)).astype(np.float32)
+
+
+def float_dense(n, seed=7, dim=784):
+    """Signed dense float rows with structure (8 blobs, centres U(-1,1)^dim, unit sigma 0.5): no dead column, no
+    all-zero quad, no uint8 shortcut -- none of the exact data-dependent shortcuts of the batch step applies."""
+    return blobs(n, dim, 8, 1, seed, sigma=0.5)
+
+
 def mnist_idx(directory, n, offset=0, dim=784):
     """n rows of the real MNIST training images (IDX3, big-endian header magic 0x803; file name as
     extern/mnistReader/mnist_reader.hpp:281), raw 0..255 floats as MnistDataLoader.cpp:73-75 yields them;

@@ -43,6 +43,13 @@ def test_single_gpu_line_small_shape():
     occ = d["config"]["column_occupancy"]
     assert 0 < occ["live"] <= occ["columns"] == 784
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the same step on rows that are not uint8-valued: normalised pixels and signed dense rows
+    assert d["data_kind"]["name"] == "uint8_sparse"
+    dv = {v["data"]: v for v in d["data_variants"]}
+    assert set(dv) == {"float_sparse", "float_dense"}
+    for v in dv.values():
+        assert v["value"] > 0 and v["bmu_ms"] > 0 and v["update_ms"] > 0 and 0 < v["roofline"]["frac_executed"] <= v["roofline"]["frac"]
+    assert dv["float_dense"]["live_columns"] == 784 and dv["float_sparse"]["live_columns"] == occ["live"]
 
 
 def test_self_launch_two_ranks_on_one_device():

@@ -291,11 +291,11 @@ def test_clr_shortlist_duplicates_zero_map_nan_and_inf_rows():
 
 
 def test_integer_contraction_and_its_fallbacks():
-    """The shortlist's contraction runs in exact integer arithmetic on the int8 matrix pipe for chunks of small
-    non-negative integers (csrc/vsom_sl_i8.hip); whether a chunk is of that kind is a device-side fact.  One context
-    sees, in turn: uint8-valued chunks (integer contraction), a chunk with a non-integer / a negative / a 256 / a NaN
-    value (searched exactly this once: the host then returns to the fp32 contraction), uint8-valued chunks again (fp32
-    contraction now) -- and a second context whose model holds huge, tiny, denormal and exactly-zero rows (the digit
+    """The shortlist's contraction runs in exact integer arithmetic on the int8 matrix pipe (csrc/vsom_sl_i8.hip): one
+    digit per sample value for chunks of small non-negative integers, three for any other chunk; which kind a chunk is
+    is a device-side fact the kernels read.  One context sees, in turn: uint8-valued chunks, a chunk with a non-integer /
+    a negative / a 256 / a NaN / an inf value (general kind; the NaN / inf SAMPLE is redone exactly), uint8-valued
+    chunks again -- and a second context whose model holds huge, tiny, denormal and exactly-zero rows (the digit
     grid's scale is per row).  Indices and distances equal the oracle's bit for bit every time."""
     W, H, J, B = 40, 36, 784, 260
     rs = np.random.RandomState(11)
@@ -330,7 +330,7 @@ def test_integer_contraction_and_its_fallbacks():
             assert beq(idx, lb_o) and beq(dist, sq_o), (bad, tag)
         c2.close()
     check(gen.blobs(B, J, 6, 1, 2, sigma=0.5), "float data")
-    check(Xa, "uint8 again (fp32 contraction)")
+    check(Xa, "uint8 again")
     ctx.close()
 
     # rows of very different magnitude, tiny / denormal / zero rows, a NaN row and node 0 NaN
@@ -347,7 +347,12 @@ def test_integer_contraction_and_its_fallbacks():
     c3 = vsom_amd.Context(W, H, J)
     c3.set_bmu_mode(capi.BMU_SHORTLIST)
     c3.set_state(map=init2)
-    for X in (Xa, Xb, np.zeros((40, J), np.float32)):
+    # consecutive searches in ONE context alternate the two counter sets (the maxima of |M|^2, eps and |M|_1 the
+    # pruning bound needs must be those of THIS search: ADVICE r4); dim samples make the |x|^2 part of the bound
+    # negligible, so a stale or empty set would prune the true BMU of the rows scaled by 1e6 / 1e15
+    Xdim = np.zeros((64, J), np.float32)
+    Xdim[np.arange(64), rs.randint(0, J, 64)] = rs.randint(1, 4, 64).astype(np.float32)
+    for X in (Xa, Xdim, Xb, Xdim, np.zeros((40, J), np.float32), Xdim / np.float32(3)):
         c3.upload_chunk(X)
         idx, dist = c3.bmu_batch()
         lb_o, sq_o = _oracle_bmu(o2, X)
@@ -360,3 +365,66 @@ def test_integer_contraction_and_its_fallbacks():
     lb_o, sq_o = _oracle_bmu(o2, Xa)
     assert beq(idx, lb_o) and beq(dist, sq_o)
     c3.close()
+
+
+def test_general_kind_integer_contraction():
+    """Chunks that are NOT uint8-valued take the three-digit form of the integer contraction (csrc/vsom_sl_i8.hip):
+    normalised pixels, signed dense rows, rows of very different scale inside one chunk (the digit grid is per sample),
+    rows with one huge outlier, denormal / zero rows, rows holding NaN / inf / overflowing values (redone exactly) --
+    against a trained-looking map, a map with rows of very different magnitude, and the all-zero map an empty chunk
+    leaves (Som.cpp:840-875; every distance equal, node 0 stays: the select kernel's shortcut), also with NaN nodes."""
+    W, H, J, B = 40, 36, 784, 300
+    rs = np.random.RandomState(5)
+    Xs = gen.float_sparse(B, 3, J)
+    Xd = gen.float_dense(B, 7, J)
+    Xm = Xd.copy()
+    Xm[0::5] *= np.float32(1e-6)
+    Xm[1::5] *= np.float32(1e5)
+    Xm[2::5] *= np.float32(1e-30)
+    Xm[3, :] = 0.0
+    Xm[8, 17] = np.float32(1e9)                  # one outlier: every other value of the row falls below the grid
+    Xm[13, :] = np.float32(1e-42) * rs.randint(0, 9, J).astype(np.float32)   # denormals
+    Xbad = Xs.copy()
+    Xbad[4, 100] = np.nan
+    Xbad[9, 7] = np.inf
+    Xbad[11, 300] = -np.inf
+    Xbad[14, 5] = np.float32(3e38)
+    Xbad[19, :] = np.float32(2e19)               # |x|^2 overflows
+    init = (gen.random_map(W * H, J, 42) * np.float32(0.4) + np.float32(0.45)).astype(np.float32)
+    smooth = np.repeat(gen.float_sparse(W * H // 4, 9, J), 4, axis=0) * np.float32(0.9) + init * np.float32(0.02)
+    wild = init.copy()
+    wild[5] *= np.float32(1e6)
+    wild[6] *= np.float32(1e-9)
+    wild[7] = np.float32(3e-41) * rs.rand(J).astype(np.float32)
+    wild[8] = 0.0
+    wild[9, 100] = np.nan
+    wild[11, ::7] = np.float32(-1e-30)
+    zero = np.zeros_like(init)
+    zero_nan = zero.copy()
+    zero_nan[3, 2] = np.nan
+    zero_nan0 = zero.copy()
+    zero_nan0[0, 0] = np.nan
+    almost = zero.copy()
+    almost[700, 3] = np.float32(1e-44)           # NOT an all-zero map: the shortcut must not fire
+    negz = -zero
+    o = po.OracleSom(W, H, J)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_bmu_mode(capi.BMU_SHORTLIST)
+    for mname, m in (("init", init), ("smooth", smooth.astype(np.float32)), ("wild", wild), ("zero", zero),
+                     ("zero+nan", zero_nan), ("zero, node 0 nan", zero_nan0), ("almost zero", almost), ("-0", negz)):
+        o.set_state(map=m)
+        ctx.set_state(map=m)
+        for xname, X in (("sparse", Xs), ("dense", Xd), ("mixed scales", Xm), ("non-finite", Xbad),
+                         ("uint8", gen.mnist_like(B, 3, J)), ("tiny", Xs * np.float32(1e-20))):
+            ctx.upload_chunk(X)
+            idx, dist = ctx.bmu_batch()
+            lb_o, sq_o = _oracle_bmu(o, X)
+            assert beq(idx, lb_o) and beq(dist, sq_o), (mname, xname)
+    # the pruning does prune on a realistic map (the contraction is not silently handing everything to the exact kernel)
+    o.set_state(map=smooth.astype(np.float32))
+    ctx.set_state(map=smooth.astype(np.float32))
+    ctx.upload_chunk(Xs)
+    ctx.bmu_batch()
+    st = ctx.shortlist_stats()
+    assert st["redo_samples"] == 0 and st["candidates"] < 64 * B, st
+    ctx.close()

@@ -23,7 +23,7 @@ fi
 objs=()
 for f in vsom_capi vsom_bmu vsom_shortlist vsom_update vsom_online vsom_tiny vsom_group vsom_compact vsom_xq vsom_sl_i8; do
   o="$here/$f.o"
-  if [ ! -f "$o" ] || [ "$here/$f.hip" -nt "$o" ] || [ "$here/vsom_internal.hpp" -nt "$o" ] || [ "$here/vsom_device.hpp" -nt "$o" ] || [ "$here/../../include/vsom_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$here/$f.hip" -nt "$o" ] || [ "$here/vsom_internal.hpp" -nt "$o" ] || [ "$here/vsom_device.hpp" -nt "$o" ] || [ "$here/vsom_digits.hpp" -nt "$o" ] || [ "$here/../../include/vsom_hip.h" -nt "$o" ]; then
     $HIPCC $FLAGS -c "$here/$f.hip" -o "$o" &
   fi
   objs+=("$o")

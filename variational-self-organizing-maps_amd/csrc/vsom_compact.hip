@@ -91,59 +91,6 @@ __global__ __launch_bounds__(256) void cc_gather_rows_kernel(const float *__rest
     }
 }
 
-// the chunk's rows gathered onto the live columns (one workgroup per row, four columns per thread) and, when the integer
-// shortlist is in use (xi != null; vsom_sl_i8.hip), in the same pass their int8 image x - 128, |x|_1 and the chunk's
-// "not uint8 data" flag -- what sl_quant_x_kernel would compute from Xc
-__global__ __launch_bounds__(256) void cc_gather_chunk_kernel(const float *__restrict__ src, int lds_, float *__restrict__ dst,
-                                                              int ldd, const int *__restrict__ idx, int nrows,
-                                                              signed char *__restrict__ xi, int kp8, float *__restrict__ l1,
-                                                              unsigned *__restrict__ xflag)
-{
-    __shared__ float ssum[4];
-    const int row = blockIdx.x;
-    if (row >= nrows)
-        return;
-    const float *s = src + (size_t)row * lds_;
-    float sum = 0.f;
-    bool bad = false;
-    for (int k4 = threadIdx.x * 4; k4 < (xi ? kp8 : ldd); k4 += 1024) {
-        float vv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (k4 < ldd) {                                  // ldd is a multiple of 32
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = idx[k4 + u];
-                vv[u] = c >= 0 ? s[c] : 0.f;
-            }
-            *reinterpret_cast<float4 *>(dst + (size_t)row * ldd + k4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        }
-        if (xi) {
-            char4 q;
-            signed char *qq = reinterpret_cast<signed char *>(&q);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float f = vv[u];
-                const bool ok = f >= 0.f && f <= 255.f && f == rintf(f);      // NaN fails the comparisons
-                bad |= !ok;
-                const int iv = ok ? (int)f : 0;
-                sum += (float)iv;
-                qq[u] = (signed char)(iv - 128);
-            }
-            *reinterpret_cast<char4 *>(xi + (size_t)row * kp8 + k4) = q;
-        }
-    }
-    if (!xi)
-        return;
-    for (int off = 32; off > 0; off >>= 1)
-        sum += __shfl_xor(sum, off);
-    if (__ballot(bad) && (threadIdx.x & 63) == 0)
-        atomicOr(xflag, 1u);
-    if ((threadIdx.x & 63) == 0)
-        ssum[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        l1[row] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);       // exact: integers below 2^24
-}
-
 // model rows back in the reference's layout: live column d <- compacted column inv[d] (map: the chain's M;
 // sigmaMap: sqrt(S / W), Som.cpp:873), dead column <- +0, or NaN when the node's first coefficient is 0/0
 // (header); the padding columns of the rows are put to zero as sigma_finalize_kernel does
@@ -268,16 +215,11 @@ int vsom_cc_stage(vsom_ctx *c)
 {
     hipLaunchKernelGGL(cc_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->cc_flags, (int)c->D, (int)c->cpitch, c->cc_idx,
                        c->cc_inv, c->cc_meta, c->cc_fb);
-    // with the integer shortlist's buffers in place (vsom_sl_i8.hip allocates them at the first search) the same pass
-    // writes the chunk's int8 image
-    const uint32_t kp8 = (c->cpitch + 63) / 64 * 64;
-    const bool xi = c->sl_i8 && c->sl_xi && c->sl_kp8 == kp8 && (size_t)c->Bcap * kp8 <= c->sl_xi_cap && c->sl_scal;
-    hipLaunchKernelGGL(cc_gather_chunk_kernel, dim3((unsigned)c->B), dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->Xc,
-                       (int)c->cpitch, c->cc_idx, (int)c->B, xi ? c->sl_xi : (signed char *)nullptr, (int)kp8,
-                       xi ? c->sl_l1 : (float *)nullptr, xi ? c->sl_scal + 8192 : (unsigned *)nullptr);
-    VSOM_HIP_CHECK(hipGetLastError());
+    // the chunk's rows gathered onto the live columns; with the integer shortlist's buffers in place (vsom_sl_i8.hip
+    // allocates them at the first search) the same pass writes the chunk's int8 images
+    if (int rc = launch_sl_gather_quant(c))
+        return rc;
     c->cc_valid = true;
-    c->xi_valid = xi;
     return VSOM_OK;
 }
 

@@ -1,0 +1,46 @@
+// vsom_digits.hpp -- the base-128 digit grid of the integer shortlist contraction (vsom_sl_i8.hip), shared by the
+// kernels that quantise model rows and sample rows.
+//
+// A row with largest finite magnitude mx gets the scale s = 2^E, E = exponent(mx) - 5, so that |v| / s < 64, and
+// every value is written as   v = s (d1 + d2/128 + d3/16384) + r   with integer digits d_l in [-64, 64] and
+// |r| <= s 2^-15.  The residuals between the steps are differences of a value and its rounding to a coarser power-of-two
+// grid: exact in fp32.  Rows too small for the grid (E < -100) keep E = -100; their bound is the magnitude itself.
+#pragma once
+#include "vsom_device.hpp"
+
+// slots of one counter set `scal` (unsigned words; layout: vsom_shortlist.hip): 32 line-sized slots per quantity
+#define SLI_NMAX(slot) (1024 + 32 * (slot))     // max |M_n|^2 over the finite rows
+#define SLI_EMAX(slot) (2048 + 32 * (slot))     // max eps_n: digit residual bound of a model row (>= s_n 2^-15)
+#define SLI_L1MAX(slot) (3072 + 32 * (slot))    // max |M_n|_1 over the contracted columns
+#define SLI_NONZERO 6                           // some model value is not +-0 (NaN counts)
+
+// scale 2^E, its inverse and the residual bound eps of a row whose largest finite magnitude is mx
+__device__ __forceinline__ void sl_row_scale(float mx, float &s1, float &is1, float &eps)
+{
+    int e = mx > 0.f ? (int)((__float_as_uint(mx) >> 23) & 0xFF) - 127 : -100;
+    e = mx > 0.f && ((__float_as_uint(mx) >> 23) & 0xFF) == 0 ? -126 : e;      // denormal maximum
+    int E = e - 5;                                       // mx < 2^(e+1)  ->  mx / 2^E < 64
+    E = E < -100 ? -100 : E;
+    s1 = __uint_as_float((unsigned)(E + 127) << 23);
+    is1 = __uint_as_float((unsigned)(127 - E) << 23);
+    // eps >= s 2^-15 in every case (callers bound s by eps 2^15): a row below the grid is bounded by its magnitude
+    eps = e - 5 < -100 ? fmaxf(mx, 0x1.0p-115f) : s1 * 0x1.0p-15f;
+}
+
+// the three digits of v on the grid of scale s1 (non-finite values count as 0: such a row is excluded / redone)
+__device__ __forceinline__ void sl_digits3(float v, float s1, float is1, int &a, int &b, int &c)
+{
+    const float s2 = s1 * 0.0078125f, is2 = is1 * 128.f, is3 = is2 * 128.f;      // s / 128 (exact), 128 / s, 16384 / s
+    v = fabsf(v) <= 3.0e38f ? v : 0.f;
+    float t = rintf(v * is1);
+    t = fminf(fmaxf(t, -64.f), 64.f);
+    const float ra = v - t * s1;                         // exact
+    float t2 = rintf(ra * is2);
+    t2 = fminf(fmaxf(t2, -64.f), 64.f);
+    const float rb = ra - t2 * s2;                       // exact
+    float t3 = rintf(rb * is3);
+    t3 = fminf(fmaxf(t3, -64.f), 64.f);
+    a = (int)t;
+    b = (int)t2;
+    c = (int)t3;
+}

@@ -92,7 +92,6 @@ struct vsom_ctx {
     signed char *sl_q = nullptr; double *sl_qscale = nullptr, *sl_qcorr = nullptr;
     uint32_t sl_kp8 = 0;
     bool xi_valid = false;          // sl_xi / sl_l1 describe the staged chunk
-    bool sl_i8 = true;              // try the integer contraction (cleared when a chunk turns out not to be uint8 data)
     int sl_par = 0;                 // which of the two scal sets the next search uses
     int sl_skip = 0;
     unsigned sl_seq_seen = 0;       // feedback sequence number already acted on
@@ -188,6 +187,7 @@ int vsom_cc_stage(vsom_ctx *c);
 int vsom_cc_gather_map(vsom_ctx *c);
 int vsom_cc_ensure_update_scratch(vsom_ctx *c);
 int vsom_cc_expand(vsom_ctx *c, size_t n0, size_t nloc);
+int launch_sl_gather_quant(vsom_ctx *c);                         // vsom_sl_i8.hip: rows onto the live columns (+ int8 images)
 int vsom_xq_ensure(vsom_ctx *c);                                 // vsom_xq.hip
 bool vsom_tiny_applies(const vsom_ctx *c);                        // vsom_tiny.hip
 int launch_tiny_epoch(vsom_ctx *c, double sigma, int is_first);   // whole batch epoch, one workgroup

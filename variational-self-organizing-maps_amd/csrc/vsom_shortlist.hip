@@ -30,7 +30,7 @@
 // exactly those samples (its workgroups beyond the list length exit at once).  The redo fraction
 // is fed back to the host through pinned memory so that AUTO mode can stop using the shortlist on
 // maps where it does not prune (very smooth maps early in training).
-#include "vsom_device.hpp"
+#include "vsom_digits.hpp"
 #include <cstring>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void sl_norm_kernel(const float *__restrict__ 
     const float4 *row = reinterpret_cast<const float4 *>(map + (size_t)nc * ldm);
     const int n4 = Dp >> 2;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    bool nz = false;
     // 8 independent 16-byte loads in flight per lane (the kernel is a single pass over the map and
     // was latency-bound at 4)
     int q = sub;
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void sl_norm_kernel(const float *__restrict__ 
             s1 = s1 + v[u].y * v[u].y;
             s2 = s2 + v[u].z * v[u].z;
             s3 = s3 + v[u].w * v[u].w;
+            nz |= !(v[u].x == 0.f) || !(v[u].y == 0.f) || !(v[u].z == 0.f) || !(v[u].w == 0.f);
         }
     }
     for (; q < n4; q += 16) {
@@ -70,7 +72,10 @@ __global__ __launch_bounds__(256) void sl_norm_kernel(const float *__restrict__ 
         s1 = s1 + v.y * v.y;
         s2 = s2 + v.z * v.z;
         s3 = s3 + v.w * v.w;
+        nz |= !(v.x == 0.f) || !(v.y == 0.f) || !(v.z == 0.f) || !(v.w == 0.f);
     }
+    if (__ballot(nz && node < N) && (threadIdx.x & 63) == 0 && scal[SLI_NONZERO] == 0u)
+        atomicOr(&scal[SLI_NONZERO], 1u);        // some model value is not +-0 (sl_select_kernel: an all-zero map keeps node 0)
     float s = (s0 + s1) + (s2 + s3);
     for (int off = 8; off > 0; off >>= 1)
         s = s + __shfl_xor(s, off);
@@ -295,8 +300,8 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
                                                         unsigned *__restrict__ redo_count, int *__restrict__ redo_list,
                                                         unsigned *__restrict__ stats,
                                                         const float *__restrict__ xraw, int ldxr, int J, float c_e1,
-                                                        unsigned cmax, const float *__restrict__ l1x, float c_l1,
-                                                        const unsigned *__restrict__ xflag)
+                                                        unsigned cmax, const float *__restrict__ l1x, unsigned lstride,
+                                                        float c_l1, const unsigned *__restrict__ xflag)
 {
     __shared__ unsigned cand[SL_CMAX];
     __shared__ unsigned s_cnt;
@@ -347,20 +352,27 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         for (int off = 32; off > 0; off >>= 1)
             nx = nx + __shfl_xor(nx, off);
     }
-    // integer contraction (vsom_sl_i8.hip, c_l1 > 0): the maxima of |M|^2 and of the digit residual eps sit in 32
-    // line-sized slots each; the approximation error is c_l1 |x|_1 eps_max + c_g1 (nMmax + |x|^2)
-    float nmax = __uint_as_float(scal[0]), epsmax = 0.f;
+    // integer contraction (vsom_sl_i8.hip, c_l1 > 0): the maxima of |M|^2, of the digit residual eps and of |M|_1 sit
+    // in 32 line-sized slots each; the approximation error is c_l1 (e_s L1Mmax + l1eff_s eps_max) + c_g1 (nMmax + |x|^2),
+    // with (e_s, l1eff_s) = (0, |x|_1) for a chunk of the uint8 kind (`xflag` clear) and the digit-grid terms otherwise
+    float nmax = __uint_as_float(scal[0]), epsmax = 0.f, l1mmax = 0.f;
     if (c_l1 > 0.f) {
-        unsigned nb = scal[1024 + 32 * (lane & 31)], eb = scal[2048 + 32 * (lane & 31)];
+        unsigned nb = scal[SLI_NMAX(lane & 31)], eb = scal[SLI_EMAX(lane & 31)], lb = scal[SLI_L1MAX(lane & 31)];
         for (int off = 16; off > 0; off >>= 1) {
-            const unsigned o1 = (unsigned)__shfl_xor((int)nb, off), o2 = (unsigned)__shfl_xor((int)eb, off);
+            const unsigned o1 = (unsigned)__shfl_xor((int)nb, off), o2 = (unsigned)__shfl_xor((int)eb, off),
+                           o3 = (unsigned)__shfl_xor((int)lb, off);
             nb = o1 > nb ? o1 : nb;
             eb = o2 > eb ? o2 : eb;
+            lb = o3 > lb ? o3 : lb;
         }
         nmax = __uint_as_float(nb);                      // non-negative floats: the bit patterns order like the values
         epsmax = __uint_as_float(eb);
+        l1mmax = __uint_as_float(lb);
     }
-    bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f) || !(cx <= 3.0e38f) || (c_l1 > 0.f && xflag[0] != 0u);
+    bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f) || !(cx <= 3.0e38f);
+    // an all-zero map (what the epoch over an EMPTY chunk leaves, Som.cpp:840-875 -- every chunked MnistDataLoader pass
+    // ends with one): every distance is the same sum over x in the same order, strict `<` keeps node 0 (Som.cpp:293-304)
+    const bool zero_map = scal[SLI_NONZERO] == 0u;
     float m = __uint_as_float(0x7F800000u);
     for (int i = lane; i < ntm; i += 64) {
         float v = tm[i];
@@ -371,7 +383,7 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         m = o < m ? o : m;
     }
     __syncthreads();   // s_cnt = 0 visible
-    if (!bad) {
+    if (!bad && !zero_map) {
         float T;
         if (CLR) {
             // "CLR shortlist" below: Q bounds sum_p (A x')^2 + B^2 + y'^2 for every node
@@ -389,8 +401,11 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         } else {
             // T_s = 4*g1*(nMmax+nx) + 2.1*g2*(m + nx + 2*g1*(nMmax+nx)), inflated by 1.05 (header)
             float ea = c_g1 * (nmax + nx);                   // c_g1 = 2*g1 (fp32 chain) / 3.3u (integer contraction)
-            if (c_l1 > 0.f)
-                ea = ea + 1.001f * c_l1 * l1x[s] * epsmax;
+            if (c_l1 > 0.f) {
+                const bool gen = xflag[0] != 0u;
+                const float l1e = l1x[(gen ? 2 * (size_t)lstride : 0) + s], es = gen ? l1x[3 * (size_t)lstride + s] : 0.f;
+                ea = ea + 1.001f * c_l1 * (l1e * epsmax + es * l1mmax);
+            }
             float dj = m + nx;
             dj = dj + ea;
             dj = dj > 0.f ? dj : 0.f;
@@ -489,8 +504,9 @@ __global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsi
         scal_next[threadIdx.x] = 0u;
     if (threadIdx.x < 32) {
         scal_next[16 + 32 * threadIdx.x] = 0u;     // candidate-count slots
-        scal_next[1024 + 32 * threadIdx.x] = 0u;   // max |M|^2 / max eps slots of the integer contraction (vsom_sl_i8.hip)
-        scal_next[2048 + 32 * threadIdx.x] = 0u;
+        scal_next[SLI_NMAX(threadIdx.x)] = 0u;     // max |M|^2 / eps / |M|_1 slots of the integer contraction (vsom_sl_i8.hip)
+        scal_next[SLI_EMAX(threadIdx.x)] = 0u;
+        scal_next[SLI_L1MAX(threadIdx.x)] = 0u;
     }
     if (threadIdx.x != 0)
         return;
@@ -507,7 +523,7 @@ __global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsi
 
 // host side ------------------------------------------------------------------------------------
 int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount);
-int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *xflag);   // vsom_sl_i8.hip
+int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag);   // vsom_sl_i8.hip
 
 static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1);
 
@@ -553,17 +569,14 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     // scal: [0] max nrm bits, [1] non-finite flag, [2] redo count, [4] redo samples, [5] candidates
     unsigned *scal = c->sl_scal + 4096 * c->sl_par, *scal_next = c->sl_scal + 4096 * (c->sl_par ^ 1);
     c->sl_par ^= 1;
-    // chunks of small non-negative integers (MNIST pixels): the contraction in exact integer arithmetic on the int8
-    // matrix pipe (vsom_sl_i8.hip).  Whether a chunk is of that kind is a device-side fact: the host goes by the
-    // feedback of the previous search (a chunk that is not is searched exactly, once, and the context returns to the
-    // fp32 contraction)
-    if (c->sl_i8 && c->sl_fb && ((volatile unsigned *)c->sl_fb)[4] != 0u)
-        c->sl_i8 = false;
-    const bool i8 = c->sl_i8 && c->xpitch <= 4096;
+    // the contraction in exact integer arithmetic on the int8 matrix pipe (vsom_sl_i8.hip): one digit per sample value
+    // for chunks of small non-negative integers (MNIST pixels), three for any other data -- which of the two is a
+    // device-side fact of the staged chunk (`xflag`) that the kernels read; nothing is decided here
+    const bool i8 = c->xpitch <= 4096;
     unsigned *xflag = c->sl_scal + 8192;
     dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
     if (i8) {
-        int rc = launch_sl_i8(c, s0, s1, ldg, ntm, xflag);
+        int rc = launch_sl_i8(c, s0, s1, ldg, ntm, scal, xflag);
         if (rc)
             return rc;
     } else {
@@ -598,7 +611,7 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     hipLaunchKernelGGL(sl_select_kernel<false>, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0,
                        (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(i8 ? 3.3 * u : 2.0 * g1),
                        (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, (const float *)nullptr, 0, 0, 0.f,
-                       (unsigned)SL_CMAX, (const float *)c->sl_l1, i8 ? 2.0f : 0.f, (const unsigned *)xflag);
+                       (unsigned)SL_CMAX, (const float *)c->sl_l1, (unsigned)c->Bcap, i8 ? 2.0f : 0.f, (const unsigned *)xflag);
     hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(64), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
                        i8 ? (const unsigned *)xflag : (const unsigned *)nullptr, scal_next);
     VSOM_HIP_CHECK(hipGetLastError());
@@ -672,10 +685,12 @@ __global__ __launch_bounds__(256) void clr_node_feat_kernel(const float *__restr
     const float *A = map + (size_t)n * ldm, *Bv = A + ppitch;
     float *f = Fm + (size_t)n * Kp;
     float sb = 0.f, amax = 0.f;
-    bool inf = false, nan = false;
+    bool inf = false, nan = false, nzero = false;
     for (int p = threadIdx.x; p < P32; p += 256) {
         const float a = p < P ? A[p] : 0.f, b = p < P ? Bv[p] : 0.f;
         f[p] = a;
+        if (!(a == 0.f) || !(b == 0.f))
+            nzero = true;
         const float a2 = a * a, b2 = b * b;
         sb = sb + b2;
         nan |= (a2 != a2) || (b2 != b2);
@@ -724,6 +739,8 @@ __global__ __launch_bounds__(256) void clr_node_feat_kernel(const float *__restr
         atomicOr(&sflag[0], 1);
     if (nan)
         atomicOr(&sflag[1], 1);
+    if (__ballot(nzero) && (threadIdx.x & 63) == 0 && scal[SLI_NONZERO] == 0u)
+        atomicOr(&scal[SLI_NONZERO], 1u);        // (an all-zero A / B map: every residual is -y', node 0 stays)
     if ((threadIdx.x & 63) == 0) {
         ssum[threadIdx.x >> 6] = sb;
         smax[threadIdx.x >> 6] = amax;
@@ -810,7 +827,7 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
     hipLaunchKernelGGL(sl_select_kernel<true>, dim3((unsigned)nrows), dim3(256), xy_bytes, c->stream, a, (int)s0, (int)s1, (int)c->N,
                        (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(1.0001 * ga), (float)(1.0001 * g2),
                        c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, c->Xs, (int)c->xpitch, (int)J, (float)(1.0001 * e1), 128u,
-                       (const float *)nullptr, 0.f, (const unsigned *)nullptr);
+                       (const float *)nullptr, 0u, 0.f, (const unsigned *)nullptr);
     hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(64), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
                        (const unsigned *)nullptr, scal_next);
     VSOM_HIP_CHECK(hipGetLastError());

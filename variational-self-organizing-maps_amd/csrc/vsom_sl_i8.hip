@@ -1,69 +1,135 @@
 // vsom_sl_i8.hip -- the shortlist contraction of Som::findBmu (Som.cpp:291-309; vsom_shortlist.hip) on the INTEGER
-// matrix pipe, for chunks whose samples are small non-negative integers (MNIST: MnistDataLoader.cpp:73-75 yields the raw
-// pixel values 0..255 as floats).
+// matrix pipe, for ANY finite fp32 chunk (round 5; round 4 covered uint8-valued chunks only).
 //
 // The matrix pipe only PRUNES: G[s][n] ~ |M_n|^2 - 2 <x_s, M_n> with a proven error bound, every returned index and
-// distance comes from the exact-order evaluation of sl_select_kernel.  Here the approximation is computed in exact
-// integer arithmetic instead of an fp32 MFMA chain, 10x faster on the matrix pipe (v_mfma_i32_32x32x32_i8 runs 32x the
-// multiply-adds per cycle of v_mfma_f32_32x32x2_f32; three of them per product) and with a TIGHTER bound:
-//   * model rows: M_nk = s_n (q1 + q2/128 + q3/16384)_nk + r_nk, s_n a power of two >= 2^-5 max_k |M_nk|... chosen so
-//     that q1 = rint(M/s) lies in [-64, 64]; the residuals are formed exactly in fp32 (differences of a value and its
-//     rounding to a coarser grid), q2, q3 in [-64, 64], |r_nk| <= s_n 2^-15 =: eps_n            (sl_prepare_i8_kernel)
-//   * samples: x_sk integer in [0, 255]  ->  int8 (x - 128); the offset is put back with the row sums of q (exact)
-//   * <x, M^> = s_n 2^-14 [ 16384 I1 + 128 I2 + I3 ],  I_l = sum_k x_k q_l,nk exact in int32; the combination, the
-//     offset term, the scale and |M|^2 - 2 <x, M^> are evaluated in fp64 (exact up to the final rounding to fp32)
-// Bound:  |G - (|M_n|^2 - 2 <x, M_n>)| <= 2 |x|_1 eps_n + u (|M_n|^2 from its fp64 sum) + u |G|
-//                                      <= 2 |x|_1 eps_max + 3.1 u (nMmax + |x|^2)               (u = 2^-24)
-// which sl_select_kernel uses in place of the fp32 chain's 2 g1 (nMmax + |x|^2), g1 = (32 + K/32 + 3) u: at C3
-// (K = 672 live columns, |x|_1 ~ 2e4, max |M| ~ 255) about 5 against 70.
-// A chunk that is not of that kind (quant_x raises a flag) is searched by the exact-order kernel this once, and the
-// host returns to the fp32 contraction for the context (vsom_shortlist.hip).
-#include "vsom_device.hpp"
+// distance comes from the exact-order evaluation of sl_select_kernel.  The approximation is computed in exact integer
+// arithmetic (v_mfma_i32_32x32x32_i8 runs 32x the multiply-adds per cycle of v_mfma_f32_32x32x2_f32):
+//   * model rows: M_nk = s_n (q1 + q2/128 + q3/16384)_nk + r_nk, s_n a power of two with |M_nk| / s_n < 64, digits in
+//     [-64, 64], |r_nk| <= s_n 2^-15 =: eps_n (vsom_digits.hpp; sl_prepare_i8_kernel)
+//   * samples, one of two kinds -- a device-side fact of the staged chunk (`xflag`, written by sl_quant_rows_kernel), so
+//     nothing is decided on the host and a stream may change kind with every chunk:
+//       uint8 kind   every value an integer in [0, 255] (MnistDataLoader.cpp:73-75 yields raw pixels): ONE int8 plane
+//                    x - 128, exact; the offset is put back with the row sums of q.  3 integer products per element.
+//       general kind any other finite data (normalised pixels, REAL columns of SqliteDataLoader.cpp:481-548): per sample
+//                    the same digit grid, x_sk = t_s (p1 + p2/128 + p3/16384)_sk + rho_sk, |rho_sk| <= t_s 2^-15 =: e_s.
+//                    The six digit products of weight >= 2^-14 go to three accumulator sets (weights 1, 2^-7, 2^-14);
+//                    the three lighter ones (p2 q3, p3 q2, p3 q3) are DROPPED and bounded.
+//   * <x^, M^> = t_s s_n 2^-14 [ 16384 A0 + 128 A1 + A2 ],  A_w exact in int32; the combination, the offset term, the
+//     scales and |M|^2 - 2 <x^, M^> are evaluated in fp64 (exact up to the final rounding to fp32)
+// Bound (u = 2^-24, a_s = sum_k |p2| + |p3| of the sample, K = contracted columns):
+//   |<x,M> - approx| <= |<rho, M>| + |<x^, r>| + dropped
+//                    <= e_s |M_n|_1 + (|x_s|_1 + K e_s) eps_n + t_s s_n 64 (2^-21 + 2^-28) a_s
+//                    <= e_s L1Mmax + l1eff_s eps_max,      l1eff_s := |x_s|_1 + K e_s + 1.01 t_s a_s   (s_n <= 2^15 eps_n)
+//   |G - (|M_n|^2 - 2 <x, M_n>)| <= 2 (e_s L1Mmax + l1eff_s eps_max) + 3.1 u (nMmax + |x|^2)
+// (uint8 kind: e_s = 0, l1eff_s = |x_s|_1 -- round 4's bound) which sl_select_kernel uses in place of the fp32 chain's
+// 2 g1 (nMmax + |x|^2), g1 = (32 + K/32 + 3) u.
+// Samples holding NaN / inf / overflowing values are redone exactly through the |x|^2 test of the select kernel.
+#include "vsom_digits.hpp"
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-// scal slots (unsigned words): see vsom_shortlist.hip; 32 line-sized slots each for max nrm / max eps
-#define SLI_NMAX(slot) (1024 + 32 * (slot))
-#define SLI_EMAX(slot) (1024 + 1024 + 32 * (slot))
-
-// ---- samples: int8 image, |x|_1, "is this uint8 data" --------------------------------------------------------------
-// one wavefront per row; xi row pitch kp8 bytes, columns past the row's length hold x = 0 (-128)
-__global__ __launch_bounds__(256) void sl_quant_x_kernel(const float *__restrict__ X, int ldx, int B, int kp8,
-                                                         signed char *__restrict__ xi, float *__restrict__ l1,
-                                                         unsigned *__restrict__ xflag)
+// ---- samples: both int8 images, the per-sample bound terms, the chunk's kind -----------------------------------------
+// One workgroup per row.  src = the staged rows; idx = the compaction's live-column list (then dst = the row gathered onto
+// them, vsom_compact.hip) or null (identity: the padded row itself).  Planes of xi: [0] x - 128 (uint8 kind), [1..3] the
+// three digits (general kind), row pitch kp8 bytes, columns past the row's length hold x = 0.  lx: [0] |x|_1 of the
+// uint8 image (exact), [1] t_s, [2] l1eff_s, [3] e_s (header), each `lstride` floats.  xflag |= 1 when some value of
+// the chunk is not an integer in [0, 255].
+__global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restrict__ src, int lds_, float *__restrict__ dst,
+                                                            int ldd, const int *__restrict__ idx, int nrows,
+                                                            signed char *__restrict__ xi, size_t xplane, int kp8,
+                                                            float *__restrict__ lx, size_t lstride, unsigned *__restrict__ xflag)
 {
-    const int row = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= B)
+    __shared__ float ssum[4], smax[4], sl1[4];
+    __shared__ int sa[4];
+    const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (row >= nrows)
         return;
-    const float *x = X + (size_t)row * ldx;
-    signed char *o = xi + (size_t)row * kp8;
-    float sum = 0.f;
+    const float *s = src + (size_t)row * lds_;
+    auto value = [&](int k) -> float {                   // column k of the (gathered) row; ldd is a multiple of 32
+        if (k >= ldd)
+            return 0.f;
+        const int c = idx ? idx[k] : k;
+        return c >= 0 ? s[c] : 0.f;
+    };
+    const int kend = xi ? kp8 : ldd;
+    float sum = 0.f, mx = 0.f, l1f = 0.f;
     bool bad = false;
-    for (int k4 = lane * 4; k4 < kp8; k4 += 256) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k4 < ldx)                                   // ldx is a multiple of 32
-            v = *reinterpret_cast<const float4 *>(x + k4);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-        char4 q;
-        signed char *qq = reinterpret_cast<signed char *>(&q);
+    for (int k4 = threadIdx.x * 4; k4 < kend; k4 += 1024) {
+        const float vv[4] = {value(k4), value(k4 + 1), value(k4 + 2), value(k4 + 3)};
+        if (dst && k4 < ldd)
+            *reinterpret_cast<float4 *>(dst + (size_t)row * ldd + k4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (xi) {
+            char4 q;
+            signed char *qq = reinterpret_cast<signed char *>(&q);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float f = vv[u];
+                const bool ok = f >= 0.f && f <= 255.f && f == rintf(f);      // NaN fails the comparisons
+                bad |= !ok;
+                const int iv = ok ? (int)f : 0;
+                sum += (float)iv;                        // exact: integers, total < 2^24 for rows up to 65536 values
+                qq[u] = (signed char)(iv - 128);
+                const float af = fabsf(f);
+                const bool fin = af <= 3.0e38f;
+                mx = (fin && af > mx) ? af : mx;
+                l1f += fin ? af : 0.f;
+            }
+            *reinterpret_cast<char4 *>(xi + (size_t)row * kp8 + k4) = q;
+        }
+    }
+    if (!xi)
+        return;
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        l1f += __shfl_xor(l1f, off);
+        const float o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    // (one atomic per chunk, not per wavefront: 16384 same-address atomics take 0.13 ms; a stale read only repeats it)
+    if (__ballot(bad) && lane == 0 && __atomic_load_n(xflag, __ATOMIC_RELAXED) == 0u)
+        atomicOr(xflag, 1u);
+    if (lane == 0) {
+        ssum[wave] = sum;
+        smax[wave] = mx;
+        sl1[wave] = l1f;
+    }
+    __syncthreads();
+    mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    float t1, it1, es;
+    sl_row_scale(mx, t1, it1, es);
+    int asum = 0;
+    for (int k4 = threadIdx.x * 4; k4 < kp8; k4 += 1024) {
+        char4 o1, o2, o3;
+        signed char *p1 = reinterpret_cast<signed char *>(&o1), *p2 = reinterpret_cast<signed char *>(&o2),
+                    *p3 = reinterpret_cast<signed char *>(&o3);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float f = vv[u];
-            const bool ok = f >= 0.f && f <= 255.f && f == rintf(f);      // NaN fails the comparisons
-            bad |= !ok;
-            const int iv = ok ? (int)f : 0;
-            sum += (float)iv;                            // exact: integers, total < 2^24 for rows up to 65536 values
-            qq[u] = (signed char)(iv - 128);
+            int a, b, c3;
+            sl_digits3(value(k4 + u), t1, it1, a, b, c3);
+            p1[u] = (signed char)a;
+            p2[u] = (signed char)b;
+            p3[u] = (signed char)c3;
+            asum += (b < 0 ? -b : b) + (c3 < 0 ? -c3 : c3);
         }
-        *reinterpret_cast<char4 *>(o + k4) = q;
+        signed char *o = xi + xplane + (size_t)row * kp8 + k4;
+        *reinterpret_cast<char4 *>(o) = o1;
+        *reinterpret_cast<char4 *>(o + xplane) = o2;
+        *reinterpret_cast<char4 *>(o + 2 * xplane) = o3;
     }
     for (int off = 32; off > 0; off >>= 1)
-        sum += __shfl_xor(sum, off);
-    if (__ballot(bad) && lane == 0)
-        atomicOr(xflag, 1u);
+        asum += __shfl_xor(asum, off);
     if (lane == 0)
-        l1[row] = sum;
+        sa[wave] = asum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lx[row] = (ssum[0] + ssum[1]) + (ssum[2] + ssum[3]);                 // exact: integers below 2^24
+        lx[lstride + row] = t1;
+        const float l1 = ((sl1[0] + sl1[1]) + (sl1[2] + sl1[3])) * 1.001f;   // fp32 sum of <= 4096 magnitudes, rounded up
+        const float at = (float)(sa[0] + sa[1] + sa[2] + sa[3]);             // exact: < 2^24
+        lx[2 * lstride + row] = (l1 + (float)kp8 * es + 1.01f * t1 * at) * 1.001f;
+        lx[3 * lstride + row] = es;
+    }
 }
 
 // ---- model rows: |M|^2 (fp64 sum), live columns gathered, three 7-bit digits, row sums -------------------------------
@@ -82,34 +148,34 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
         kp = (int)kp_dev[2];
     const float *src = map + (size_t)n * ldm;
     double ss = 0.0;
+    bool nz = false;
     for (int d = lane * 4; d < Dp; d += 256) {          // rows are zero padded to Dp, a multiple of 32
         const float4 v = *reinterpret_cast<const float4 *>(src + d);
         ss += (double)v.x * (double)v.x + (double)v.y * (double)v.y;
         ss += (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+        nz |= !(v.x == 0.f) || !(v.y == 0.f) || !(v.z == 0.f) || !(v.w == 0.f);
     }
     for (int off = 32; off > 0; off >>= 1)
         ss += __shfl_xor(ss, off);
     const float nf = (float)ss;                          // NaN rows stay NaN, overflow -> inf
-    // the row's largest live magnitude (non-finite values count as 0: such a row is excluded / redone anyway)
-    float mx = 0.f;
+    // the row's largest live magnitude and |M_n|_1 over the live columns (non-finite values count as 0: such a row is
+    // excluded / redone anyway)
+    float mx = 0.f, l1 = 0.f;
     for (int k = lane; k < kp; k += 64) {
         const int c = idx ? idx[k] : k;
         float v = c >= 0 && c < Dp ? src[c] : 0.f;
         v = fabsf(v);
-        mx = (v <= 3.0e38f && v > mx) ? v : mx;
+        const bool fin = v <= 3.0e38f;
+        mx = (fin && v > mx) ? v : mx;
+        l1 += fin ? v : 0.f;
     }
     for (int off = 32; off > 0; off >>= 1) {
         const float o = __shfl_xor(mx, off);
         mx = o > mx ? o : mx;
+        l1 += __shfl_xor(l1, off);
     }
-    // s = 2^E with |M| / s < 64:  E = exponent(mx) - 5  (mx < 2^(exponent+1)); tiny rows: E >= -100
-    int e = mx > 0.f ? (int)((__float_as_uint(mx) >> 23) & 0xFF) - 127 : -100;
-    e = mx > 0.f && ((__float_as_uint(mx) >> 23) & 0xFF) == 0 ? -126 : e;      // denormal maximum
-    int E = e - 5;
-    E = E < -100 ? -100 : E;
-    const float s1 = __uint_as_float((unsigned)(E + 127) << 23), is1 = __uint_as_float((unsigned)(127 - E) << 23);
-    const float s2 = s1 * 0.0078125f, s3 = s2 * 0.0078125f;                     // s / 128, s / 16384 (exact)
-    const float is2 = is1 * 128.f, is3 = is2 * 128.f;
+    float s1, is1, eps;
+    sl_row_scale(mx, s1, is1, eps);
     int r1 = 0, r2 = 0, r3 = 0;
     const size_t plane = (size_t)N * kp8;
     signed char *q1 = q + (size_t)n * kp8, *q2 = q1 + plane, *q3 = q2 + plane;
@@ -123,19 +189,7 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
             int a = 0, b = 0, c3 = 0;
             if (k < kp) {
                 const int c = idx ? idx[k] : k;
-                float v = c >= 0 && c < Dp ? src[c] : 0.f;
-                v = fabsf(v) <= 3.0e38f ? v : 0.f;
-                float t = rintf(v * is1);                // |v| / s < 64 unless the row is tiny (E clamped): clamp
-                t = fminf(fmaxf(t, -64.f), 64.f);
-                const float ra = v - t * s1;             // exact
-                float t2 = rintf(ra * is2);
-                t2 = fminf(fmaxf(t2, -64.f), 64.f);
-                const float rb = ra - t2 * s2;           // exact
-                float t3 = rintf(rb * is3);
-                t3 = fminf(fmaxf(t3, -64.f), 64.f);
-                a = (int)t;
-                b = (int)t2;
-                c3 = (int)t3;
+                sl_digits3(c >= 0 && c < Dp ? src[c] : 0.f, s1, is1, a, b, c3);
             }
             p1[u] = (signed char)a;
             p2[u] = (signed char)b;
@@ -153,9 +207,11 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
         r2 += __shfl_xor(r2, off);
         r3 += __shfl_xor(r3, off);
     }
+    if (__ballot(nz) && lane == 0 && scal[SLI_NONZERO] == 0u)
+        atomicOr(&scal[SLI_NONZERO], 1u);                // (an all-zero map -- what an empty chunk leaves -- skips the refinement)
     if (lane == 0) {
         nrm[n] = nf;
-        qscale[n] = (double)s3;                          // s 2^-14: multiplies 16384 I1 + 128 I2 + I3
+        qscale[n] = (double)s1 * 0x1.0p-14;              // s 2^-14: multiplies 16384 A0 + 128 A1 + A2
         qcorr[n] = 128.0 * (double)((long long)r1 * 16384 + (long long)r2 * 128 + (long long)r3);   // the (x - 128) offset put back
         const int slot = n & 31;
         if (nf == nf) {
@@ -164,41 +220,46 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
             else
                 atomicMax(&scal[SLI_NMAX(slot)], __float_as_uint(nf));
         }
-        // eps_n = s 2^-15, or the whole magnitude of a row too small for the digit grid (E clamped)
-        const float eps = e - 5 < -100 ? mx : s1 * 3.0517578125e-05f;
         atomicMax(&scal[SLI_EMAX(slot)], __float_as_uint(eps));
+        atomicMax(&scal[SLI_L1MAX(slot)], __float_as_uint(l1 * 1.001f));     // fp32 sum of <= 4096 magnitudes, rounded up
     }
 }
 
-// ---- G = |M|^2 - 2 <x, M^>, tile minima -----------------------------------------------------------------------------
-// workgroup tile (64 MI) samples x 64 nodes, wavefront tile (32 MI) x 32 (MI MFMA tiles of 32 x 32), three int32
-// accumulator sets (the digits), K streamed through LDS in chunks of 64 bytes with the next chunk's global loads in
-// flight.  The contraction itself is ~0.06 ms of matrix-pipe time at C3; what the kernel waits for is its staging
-// loads (1.8 GB out of L2 at MI = 2, one chunk of 20 KB per workgroup in flight): measured at C3 -- 128 x 64 tiles, two
-// workgroups per CU 0.37 ms, three (154 VGPRs) 0.27 ms; 64 x 64 tiles, five per CU (2.8 GB) 0.30 ms; the fp64
-// epilogue and the tile minima cost nothing measurable there.  (Big problems take the LDS-DMA ring kernel below.)
+// ---- G = |M|^2 - 2 <x^, M^>, tile minima ----------------------------------------------------------------------------
+// XD = sample planes (1: uint8 kind, 3: general kind), chosen at run time from the chunk's flag: the kernels below hold
+// both bodies.  Accumulator set w collects the digit products of weight 128^-w: (sample plane pl) x (model plane l),
+// pl + l = w <= 2.
+
+// epilogue value (C/D layout of the 32 x 32 MFMA tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)),
+// in fp64: exact up to the final rounding to fp32
+__device__ __forceinline__ float sl_i8_value(int a0, int a1, int a2, double cr, double sc, double nm)
+{
+    const double t = (double)a0 * 16384.0 + (double)a1 * 128.0 + (double)a2 + cr;
+    return (float)(nm - 2.0 * (sc * t));
+}
+
+// workgroup tile (64 MI) samples x 64 nodes, wavefront tile (32 MI) x 32 (MI MFMA tiles of 32 x 32), K streamed through
+// LDS in chunks of 64 bytes with the next chunk's global loads in flight.  For problems too small to fill the chip with
+// the ring kernel's 256 x 128 tiles.
 #define IT_N 64
 #define IK 64
 #define ILD 80      // LDS row stride in bytes (64 + 16: conflict-free 16-byte fragment reads)
-template <int MI>
-__global__ __launch_bounds__(256, MI == 1 ? 5 : 3) void sl_gemm_i8_kernel(const signed char *__restrict__ xi, int s0, int s1, const signed char *__restrict__ q,
-                                                            int N, int kp, const unsigned *__restrict__ kp_dev, int kp8,
-                                                            const float *__restrict__ nrm, const double *__restrict__ qscale,
-                                                            const double *__restrict__ qcorr, float *__restrict__ G, int ldg,
-                                                            float *__restrict__ tmin, int ntm)
+template <int MI, int XD>
+__device__ __forceinline__ void sl_gemm_i8_body(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
+                                                const signed char *__restrict__ q, int N, int kp, int kp8,
+                                                const float *__restrict__ nrm, const double *__restrict__ qscale,
+                                                const double *__restrict__ qcorr, const float *__restrict__ xscale,
+                                                float *__restrict__ G, int ldg, float *__restrict__ tmin, int ntm,
+                                                signed char *As, signed char *Bs, float *smin)
 {
-    if (kp_dev)
-        kp = (int)kp_dev[2];
     const int k64 = (kp + IK - 1) / IK * IK;             // <= kp8; columns past kp hold q = 0
     constexpr int IT_S = 64 * MI;
-    __shared__ __attribute__((aligned(16))) signed char As[IT_S * ILD];
-    __shared__ __attribute__((aligned(16))) signed char Bs[3][IT_N * ILD];
-    __shared__ float smin[2][IT_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
     const int sbase = s0 + blockIdx.y * IT_S, nbase = blockIdx.x * IT_N;
     const size_t plane = (size_t)N * kp8;
+    const signed char *xbase = XD == 1 ? xi : xi + xplane;        // plane 0: uint8 image; planes 1..3: digits
 
     v16i acc[3][MI];
 #pragma unroll
@@ -209,15 +270,17 @@ __global__ __launch_bounds__(256, MI == 1 ? 5 : 3) void sl_gemm_i8_kernel(const 
             for (int r = 0; r < 16; ++r)
                 acc[l][i][r] = 0;
 
-    // staging: A tile (64 MI) rows x 64 B = 256 MI pieces of 16 B (MI per thread); B tiles 3 x 64 rows x 64 B = 768 pieces (3)
-    v4i pa[MI], pb[3];
+    // staging: A planes XD x (64 MI) rows x 64 B (XD MI 16-byte pieces per thread); B tiles 3 x 64 rows x 64 B (3)
+    v4i pa[XD][MI], pb[3];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int f = tid + 256 * i, r = f >> 2, c = (f & 3) * 16;
-            const int s = sbase + r;
-            pa[i] = s < s1 ? *reinterpret_cast<const v4i *>(xi + (size_t)s * kp8 + k0 + c) : v4i{0, 0, 0, 0};
-        }
+        for (int pl = 0; pl < XD; ++pl)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int f = tid + 256 * i, r = f >> 2, c = (f & 3) * 16;
+                const int s = sbase + r;
+                pa[pl][i] = s < s1 ? *reinterpret_cast<const v4i *>(xbase + pl * xplane + (size_t)s * kp8 + k0 + c) : v4i{0, 0, 0, 0};
+            }
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
             const int r = tid >> 2, c = (tid & 3) * 16;
@@ -229,48 +292,52 @@ __global__ __launch_bounds__(256, MI == 1 ? 5 : 3) void sl_gemm_i8_kernel(const 
     for (int k0 = 0; k0 < k64; k0 += IK) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int f = tid + 256 * i, r = f >> 2, c = (f & 3) * 16;
-            *reinterpret_cast<v4i *>(&As[r * ILD + c]) = pa[i];
-        }
+        for (int pl = 0; pl < XD; ++pl)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int f = tid + 256 * i, r = f >> 2, c = (f & 3) * 16;
+                *reinterpret_cast<v4i *>(&As[(pl * IT_S + r) * ILD + c]) = pa[pl][i];
+            }
 #pragma unroll
         for (int l = 0; l < 3; ++l) {
             const int r = tid >> 2, c = (tid & 3) * 16;
-            *reinterpret_cast<v4i *>(&Bs[l][r * ILD + c]) = pb[l];
+            *reinterpret_cast<v4i *>(&Bs[(l * IT_N + r) * ILD + c]) = pb[l];
         }
         __syncthreads();
         if (k0 + IK < k64)
             gload(k0 + IK);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            v4i a[MI], b[3];
+            v4i a[XD][MI], b[3];
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-                a[i] = *reinterpret_cast<const v4i *>(&As[(wm * 32 * MI + i * 32 + lr) * ILD + ks * 32 + 16 * lh]);
-#pragma unroll
-            for (int l = 0; l < 3; ++l)
-                b[l] = *reinterpret_cast<const v4i *>(&Bs[l][(wn * 32 + lr) * ILD + ks * 32 + 16 * lh]);
-#pragma unroll
-            for (int l = 0; l < 3; ++l)
+            for (int pl = 0; pl < XD; ++pl)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
-                    acc[l][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[l], acc[l][i], 0, 0, 0);
+                    a[pl][i] = *reinterpret_cast<const v4i *>(&As[(pl * IT_S + wm * 32 * MI + i * 32 + lr) * ILD + ks * 32 + 16 * lh]);
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+                b[l] = *reinterpret_cast<const v4i *>(&Bs[(l * IT_N + wn * 32 + lr) * ILD + ks * 32 + 16 * lh]);
+#pragma unroll
+            for (int pl = 0; pl < XD; ++pl)
+#pragma unroll
+                for (int l = 0; l + pl < 3; ++l)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[pl + l][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pl][i], b[l], acc[pl + l][i], 0, 0, 0);
         }
     }
-    // epilogue (C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)), in fp64: exact up to the
-    // final rounding to fp32
     const float inf = __uint_as_float(0x7F800000u);
     const int col = nbase + wn * 32 + lr;
     const bool cok = col < N;
-    const double nm = cok ? (double)nrm[col] : 0.0, sc = cok ? qscale[col] : 0.0, cr = cok ? qcorr[col] : 0.0;
+    const double nm = cok ? (double)nrm[col] : 0.0, sc = cok ? qscale[col] : 0.0, cr = cok && XD == 1 ? qcorr[col] : 0.0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int lrow = wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int row = sbase + lrow;
-            const double t = (double)acc[0][i][r] * 16384.0 + (double)acc[1][i][r] * 128.0 + (double)acc[2][i][r] + cr;
-            const float g = (float)(nm - 2.0 * (sc * t));
+            const double rs = XD == 1 ? 1.0 : (double)xscale[row < s1 ? row : s1 - 1];
+            const float g = sl_i8_value(acc[0][i][r], acc[1][i][r], acc[2][i][r], cr, sc * rs, nm);
             if (row < s1 && cok)
                 G[(size_t)(row - s0) * ldg + col] = g;
             // exact minimum of the finite entries of this row over the workgroup's 64 nodes: NaN -> +inf
@@ -281,79 +348,106 @@ __global__ __launch_bounds__(256, MI == 1 ? 5 : 3) void sl_gemm_i8_kernel(const 
                 mn = o < mn ? o : mn;
             }
             if (lr == 0)
-                smin[wn][lrow] = mn;
+                smin[wn * IT_S + lrow] = mn;
         }
     }
     __syncthreads();
     if (tid < IT_S) {
         const int row = sbase + tid;
         if (row < s1) {
-            const float a0 = smin[0][tid], a1 = smin[1][tid];
+            const float a0 = smin[tid], a1 = smin[IT_S + tid];
             tmin[(size_t)(row - s0) * ntm + blockIdx.x] = a1 < a0 ? a1 : a0;
         }
     }
 }
 
-// ---- the same contraction with big tiles and a ring of LDS stages filled by LDS-DMA ---------------------------------------
-// What the register-staged kernel above waits for is its staging loads (1.8 GB out of L2 at C3 with ONE 20 KB chunk per
-// workgroup in flight).  Here: workgroup tile 256 samples x 128 nodes (0.9 GB), 8 wavefronts of 64 x 64 (2 x 2 MFMA tiles x
-// three digits = 192 accumulator registers), K in chunks of 64 bytes through a ring of THREE 40 KB stages that
-// global_load_lds_dwordx4 fills without passing through registers -- two chunks in flight while one is consumed, one
-// barrier per chunk.  Measured at C3: 0.26 ms against 0.28 (`SQ_VALU_MFMA_BUSY_CYCLES`: 32 cycles per MFMA, the matrix pipe
-// 24 % busy; with one workgroup per CU the K loop and the fp64 epilogue -- ~2400 of the 2900 VALU instructions per
-// wavefront -- no longer overlap across workgroups, which eats most of what the staging gains).
-// A wave-instruction deposits 1 KB contiguously (16 rows x 64 B); the 16-byte pieces of a row are
-// stored XOR-swizzled (slot = piece ^ ((row >> 2) & 3), applied on the GLOBAL side: each lane picks the piece that belongs
-// into its slot), which makes the 16-byte fragment reads of 32 consecutive rows conflict-free without row padding.
-#define RT_S 256
-#define RT_N 128
-#define RNS 3
-#define RSTAGE 40960      // A 256 x 64 B | q1 128 x 64 B | q2 | q3
-__global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed char *__restrict__ xi, int s0, int s1,
-                                                                 const signed char *__restrict__ q, int N, int kp,
-                                                                 const unsigned *__restrict__ kp_dev, int kp8,
-                                                                 const float *__restrict__ nrm, const double *__restrict__ qscale,
-                                                                 const double *__restrict__ qcorr, float *__restrict__ G, int ldg,
-                                                                 float *__restrict__ tmin, int ntm)
+// one kernel per kind (the general body needs the registers of two workgroups per CU, the uint8 body runs three): both
+// are launched, the one whose kind the chunk is not exits at once
+template <int MI, int XD>
+__global__ __launch_bounds__(256, XD == 1 ? 3 : 2) void sl_gemm_i8_kernel(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
+                                                            const signed char *__restrict__ q, int N, int kp,
+                                                            const unsigned *__restrict__ kp_dev, int kp8,
+                                                            const float *__restrict__ nrm, const double *__restrict__ qscale,
+                                                            const double *__restrict__ qcorr, const float *__restrict__ xscale,
+                                                            float *__restrict__ G, int ldg, float *__restrict__ tmin, int ntm,
+                                                            const unsigned *__restrict__ xflag)
 {
+    if ((xflag[0] != 0u) != (XD == 3))   // wavefront-uniform (a scalar load)
+        return;
     if (kp_dev)
         kp = (int)kp_dev[2];
+    __shared__ __attribute__((aligned(16))) signed char As[XD * 64 * MI * ILD];
+    __shared__ __attribute__((aligned(16))) signed char Bs[3 * IT_N * ILD];
+    __shared__ float smin[2 * 64 * MI];
+    sl_gemm_i8_body<MI, XD>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, As, Bs, smin);
+}
+
+// ---- the same contraction with big tiles and a ring of LDS stages filled by LDS-DMA ---------------------------------------
+// What the register-staged kernel above waits for is its staging loads.  Here: workgroup tile 256 samples x 128 nodes,
+// 8 wavefronts of 64 x 64 (2 x 2 MFMA tiles x three accumulator sets = 192 accumulator registers), K in chunks of 64
+// bytes through a ring of LDS stages that global_load_lds_dwordx4 fills without passing through registers, one barrier
+// per chunk.  uint8 kind: stage = A 16 KB | q1 | q2 | q3 8 KB each = 40 KB, ring of THREE (two chunks in flight while one
+// is consumed), 12 MFMAs per wavefront and half chunk.  General kind: stage = three sample planes + three model planes =
+// 72 KB, ring of TWO (24 MFMAs per half chunk cover the one chunk in flight).
+// A wave-instruction deposits 1 KB contiguously (16 rows x 64 B); the 16-byte pieces of a row are stored XOR-swizzled
+// (slot = piece ^ ((row >> 2) & 3), applied on the GLOBAL side: each lane picks the piece that belongs into its slot),
+// which makes the 16-byte fragment reads of 32 consecutive rows conflict-free without row padding.
+#define RT_S 256
+#define RT_N 128
+#define RING_BYTES 147456      // max(3 x 40960, 2 x 73728)
+template <int XD>
+__device__ __forceinline__ void sl_gemm_i8_ring_body(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
+                                                     const signed char *__restrict__ q, int N, int kp, int kp8,
+                                                     const float *__restrict__ nrm, const double *__restrict__ qscale,
+                                                     const double *__restrict__ qcorr, const float *__restrict__ xscale,
+                                                     float *__restrict__ G, int ldg, float *__restrict__ tmin, int ntm,
+                                                     signed char *ring)
+{
+    constexpr int NS = XD == 1 ? 3 : 2;                  // ring depth
+    constexpr int AU = 16 * XD;                          // 1 KB units of the sample planes per stage (16 rows each)
+    constexpr int UNITS = AU + 24;                       // + 3 model planes x 8 units
+    constexpr int UPW = UNITS / 8;                       // per wavefront: 5 / 9
+    constexpr int STAGE = UNITS * 1024, QOFF = AU * 1024;
+    static_assert(UNITS % 8 == 0 && NS * STAGE <= RING_BYTES, "ring layout");
     const int nchunks = (kp + IK - 1) / IK;             // columns past kp hold q = 0
-    extern __shared__ __attribute__((aligned(1024))) signed char ring[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
     const int sbase = s0 + blockIdx.y * RT_S, nbase = blockIdx.x * RT_N;
     const size_t plane = (size_t)N * kp8;
+    const signed char *xbase = XD == 1 ? xi : xi + xplane;
 
-    // loader: 40 units of 1 KB per stage (A: 16 units of 16 rows, each digit plane: 8), 5 per wavefront
-    const signed char *src[5];
-    int dst[5];
+    // per lane: 32-bit offsets from a wavefront-uniform base (unit ids are per wavefront), so that the loads take the
+    // scalar-base + vector-offset form and the addresses cost one register each
+    unsigned soff[UPW];
+    int dst[UPW];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int id = wave * 5 + i;
+    for (int i = 0; i < UPW; ++i) {
+        const int id = wave * UPW + i;
         const int rin = lane >> 2, slot = lane & 3;
-        if (id < 16) {
-            const int row = id * 16 + rin;
+        if (id < AU) {
+            const int pl = id >> 4, row = (id & 15) * 16 + rin;
             int sr = sbase + row;
             sr = sr < s1 ? sr : s1 - 1;                  // rows past the chunk: re-read the last one (never stored)
-            src[i] = xi + (size_t)sr * kp8 + ((slot ^ ((row >> 2) & 3)) << 4);
+            soff[i] = (unsigned)(pl * xplane + (size_t)sr * kp8 + ((slot ^ ((row >> 2) & 3)) << 4));
             dst[i] = id * 1024;
         } else {
-            const int pl = (id - 16) >> 3, u = (id - 16) & 7;
+            const int pl = (id - AU) >> 3, u = (id - AU) & 7;
             const int row = u * 16 + rin;
             int n = nbase + row;
             n = n < N ? n : N - 1;
-            src[i] = q + pl * plane + (size_t)n * kp8 + ((slot ^ ((row >> 2) & 3)) << 4);
-            dst[i] = 16384 + pl * 8192 + u * 1024;
+            soff[i] = (unsigned)(pl * plane + (size_t)n * kp8 + ((slot ^ ((row >> 2) & 3)) << 4));
+            dst[i] = QOFF + pl * 8192 + u * 1024;
         }
     }
-    auto issue = [&](int c) {                            // chunk c -> stage c % RNS
-        const int sb = (c % RNS) * RSTAGE;
+    auto issue = [&](int c) {                            // chunk c -> stage c % NS
+        const int sb = (c % NS) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + (size_t)c * IK),
+        for (int i = 0; i < UPW; ++i) {
+            const signed char *base = (wave * UPW + i < AU ? xbase : q) + (size_t)c * IK;      // uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + soff[i]),
                                              (__attribute__((address_space(3))) void *)(ring + sb + dst[i]), 16, 0, 0);
+        }
     };
 
     v16i acc[3][2][2];
@@ -367,44 +461,50 @@ __global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed ch
                 for (int r = 0; r < 16; ++r)
                     acc[l][i][j][r] = 0;
 
-    issue(0);
-    if (nchunks > 1)
-        issue(1);
+#pragma unroll
+    for (int c = 0; c < NS - 1; ++c)
+        if (c < nchunks)
+            issue(c);
     for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks)
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // my 5 pieces of chunk c have landed (chunk c+1's may be in flight)
+        // my pieces of chunk c have landed (the NS - 2 chunks behind it may still be in flight)
+        if (NS == 3 && c + 1 < nchunks)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                 // everybody's pieces of chunk c; everybody is done with chunk c-1
-        if (c + 2 < nchunks)
-            issue(c + 2);                                // into the stage chunk c-1 was read from
-        const signed char *st = ring + (c % RNS) * RSTAGE;
+        if (c + NS - 1 < nchunks)
+            issue(c + NS - 1);                           // into the stage chunk c-1 was read from
+        const signed char *st = ring + (c % NS) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            v4i a[2], b[3][2];
+            v4i a[XD][2], b[3][2];
             const int P = ks * 2 + lh;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wm * 64 + i * 32 + lr;
-                a[i] = *reinterpret_cast<const v4i *>(st + r * 64 + ((P ^ ((r >> 2) & 3)) << 4));
-            }
+            for (int pl = 0; pl < XD; ++pl)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = wm * 64 + i * 32 + lr;
+                    a[pl][i] = *reinterpret_cast<const v4i *>(st + pl * 16384 + r * 64 + ((P ^ ((r >> 2) & 3)) << 4));
+                }
 #pragma unroll
             for (int l = 0; l < 3; ++l)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int r = wn * 64 + j * 32 + lr;
-                    b[l][j] = *reinterpret_cast<const v4i *>(st + 16384 + l * 8192 + r * 64 + ((P ^ ((r >> 2) & 3)) << 4));
+                    b[l][j] = *reinterpret_cast<const v4i *>(st + QOFF + l * 8192 + r * 64 + ((P ^ ((r >> 2) & 3)) << 4));
                 }
 #pragma unroll
-            for (int l = 0; l < 3; ++l)
+            for (int pl = 0; pl < XD; ++pl)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int l = 0; l + pl < 3; ++l)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[l][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[l][j], acc[l][i][j], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[pl + l][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pl][i], b[l][j], acc[pl + l][i][j], 0, 0, 0);
         }
     }
-    // epilogue as above; a wavefront's 64 columns are exactly one 64-node tile of `tmin`
+    // epilogue; a wavefront's 64 columns are exactly one 64-node tile of `tmin`
     const float inf = __uint_as_float(0x7F800000u);
     double nm[2], sc[2], cr[2];
     int col[2];
@@ -414,18 +514,18 @@ __global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed ch
         const bool ok = col[j] < N;
         nm[j] = ok ? (double)nrm[col[j]] : 0.0;
         sc[j] = ok ? qscale[col[j]] : 0.0;
-        cr[j] = ok ? qcorr[col[j]] : 0.0;
+        cr[j] = ok && XD == 1 ? qcorr[col[j]] : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = sbase + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const double rs = XD == 1 ? 1.0 : (double)xscale[row < s1 ? row : s1 - 1];
             float mn = inf;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const double t = (double)acc[0][i][j][r] * 16384.0 + (double)acc[1][i][j][r] * 128.0 + (double)acc[2][i][j][r] + cr[j];
-                const float g = (float)(nm[j] - 2.0 * (sc[j] * t));
+                const float g = sl_i8_value(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], cr[j], sc[j] * rs, nm[j]);
                 if (row < s1 && col[j] < N)
                     G[(size_t)(row - s0) * ldg + col[j]] = g;
                 const float m = (col[j] < N && g == g) ? g : inf;       // exact minimum of the finite entries: NaN -> +inf
@@ -442,14 +542,27 @@ __global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed ch
     }
 }
 
-// ---- host --------------------------------------------------------------------------------------------------------------
-// prepares the int8 images and computes G / tmin for samples [s0, s1) (ldg, ntm as the fp32 path lays them out: 64-node
-// tile minima); scal must have been reset
-int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *xflag)
+__global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
+                                                                 const signed char *__restrict__ q, int N, int kp,
+                                                                 const unsigned *__restrict__ kp_dev, int kp8,
+                                                                 const float *__restrict__ nrm, const double *__restrict__ qscale,
+                                                                 const double *__restrict__ qcorr, const float *__restrict__ xscale,
+                                                                 float *__restrict__ G, int ldg, float *__restrict__ tmin, int ntm,
+                                                                 const unsigned *__restrict__ xflag)
 {
-    const bool compact = c->cc_valid;
-    const uint32_t kmax = compact ? c->cpitch : c->xpitch;
-    const uint32_t kp8 = (kmax + 63) / 64 * 64;
+    if (kp_dev)
+        kp = (int)kp_dev[2];
+    extern __shared__ __attribute__((aligned(1024))) signed char ring[];
+    if (xflag[0] != 0u)          // wavefront-uniform (a scalar load)
+        sl_gemm_i8_ring_body<3>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring);
+    else
+        sl_gemm_i8_ring_body<1>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring);
+}
+
+// ---- host --------------------------------------------------------------------------------------------------------------
+// buffers of the int8 images: model planes for N rows, sample planes for Bcap rows of kp8 bytes
+static int sl_i8_ensure(vsom_ctx *c, uint32_t kp8)
+{
     if (!c->sl_q || c->sl_kp8 != kp8) {
         if (c->sl_q) {
             VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -472,17 +585,47 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
             VSOM_HIP_CHECK(hipFree(c->sl_l1));
         }
         c->sl_xi = nullptr;
-        VSOM_HIP_CHECK(hipMalloc(&c->sl_xi, (size_t)c->Bcap * kp8));
-        VSOM_HIP_CHECK(hipMalloc(&c->sl_l1, (size_t)c->Bcap * sizeof(float)));
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_xi, (size_t)4 * c->Bcap * kp8));             // [0] x - 128, [1..3] digits
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_l1, (size_t)4 * c->Bcap * sizeof(float)));   // |x|_1, t_s, l1eff_s, e_s
         c->sl_xi_cap = (size_t)c->Bcap * kp8;
         c->xi_valid = false;
     }
-    unsigned *scal = c->sl_scal;
-    if (!c->xi_valid) {      // once per staged chunk
-        hipLaunchKernelGGL(sl_quant_x_kernel, dim3((unsigned)((c->B + 3) / 4)), dim3(256), 0, c->stream,
-                           compact ? c->Xc : c->Xs, (int)kmax, (int)c->B, (int)kp8, c->sl_xi, c->sl_l1, xflag);
+    return VSOM_OK;
+}
+
+// the compaction's gather pass (vsom_compact.hip): the staged rows onto the live columns and -- once the integer
+// shortlist's buffers exist (the first search of a context allocates them) -- their int8 images in the same pass
+int launch_sl_gather_quant(vsom_ctx *c)
+{
+    const uint32_t kp8 = (c->cpitch + 63) / 64 * 64;
+    const bool xi = c->sl_xi && c->sl_kp8 == kp8 && (size_t)c->Bcap * kp8 <= c->sl_xi_cap && c->sl_scal;
+    hipLaunchKernelGGL(sl_quant_rows_kernel, dim3((unsigned)c->B), dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->Xc,
+                       (int)c->cpitch, (const int *)c->cc_idx, (int)c->B, xi ? c->sl_xi : (signed char *)nullptr,
+                       (size_t)c->Bcap * kp8, (int)kp8, xi ? c->sl_l1 : (float *)nullptr, (size_t)c->Bcap,
+                       xi ? c->sl_scal + 8192 : (unsigned *)nullptr);
+    VSOM_HIP_CHECK(hipGetLastError());
+    c->xi_valid = xi;
+    return VSOM_OK;
+}
+
+// prepares the int8 images and computes G / tmin for samples [s0, s1) (ldg, ntm as the fp32 path lays them out: 64-node
+// tile minima); scal = the counter set THIS search's select / feedback kernels read (the two sets alternate,
+// vsom_shortlist.hip), already reset
+int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag)
+{
+    const bool compact = c->cc_valid;
+    const uint32_t kmax = compact ? c->cpitch : c->xpitch;
+    const uint32_t kp8 = (kmax + 63) / 64 * 64;
+    if (int rc = sl_i8_ensure(c, kp8))
+        return rc;
+    const size_t xplane = (size_t)c->Bcap * kp8;
+    if (!c->xi_valid) {      // once per staged chunk (the compaction's gather pass does it when the buffers exist)
+        hipLaunchKernelGGL(sl_quant_rows_kernel, dim3((unsigned)c->B), dim3(256), 0, c->stream, compact ? c->Xc : c->Xs, (int)kmax,
+                           (float *)nullptr, (int)kmax, (const int *)nullptr, (int)c->B, c->sl_xi, xplane, (int)kp8, c->sl_l1,
+                           (size_t)c->Bcap, xflag);
         c->xi_valid = true;
     }
+    const float *xscale = c->sl_l1 + c->Bcap;
     const unsigned *kp_dev = compact ? (const unsigned *)c->cc_meta : nullptr;
     hipLaunchKernelGGL(sl_prepare_i8_kernel, dim3((unsigned)((c->N + 3) / 4)), dim3(256), 0, c->stream, c->map, (int)c->pitch,
                        (int)c->part_pitch, (int)c->N, compact ? (const int *)c->cc_idx : (const int *)nullptr, (int)kmax, kp_dev,
@@ -490,18 +633,28 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
     // big maps and chunks: 256 x 128 tiles through the LDS-DMA ring; otherwise (few tiles: they would not fill the
     // chip) 128 x 64 tiles staged through registers
     const size_t big_tiles = ((size_t)c->N + RT_N - 1) / RT_N * ((s1 - s0 + RT_S - 1) / RT_S);
-    static bool ring_ok = hipFuncSetAttribute((const void *)sl_gemm_i8_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              RNS * RSTAGE) == hipSuccess;
-    if (ring_ok && big_tiles >= 1024) {
+    // the attribute is per DEVICE (a group drives several from one process): raised on every launch, as launch_phase2 does
+    bool ring_ok = false;
+    if (big_tiles >= 1024) {
+        ring_ok = hipFuncSetAttribute((const void *)sl_gemm_i8_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      RING_BYTES) == hipSuccess;
+        if (!ring_ok)
+            (void)hipGetLastError();
+    }
+    if (ring_ok) {
         dim3 grid((unsigned)(ntm / 2), (unsigned)((s1 - s0 + RT_S - 1) / RT_S));   // ntm = 2 ceil(N / 128) 64-node tiles
-        hipLaunchKernelGGL(sl_gemm_i8_ring_kernel, grid, dim3(512), RNS * RSTAGE, c->stream, c->sl_xi, (int)s0, (int)s1, c->sl_q,
-                           (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, c->sl_G, (int)ldg,
-                           c->sl_tmin, (int)ntm);
+        hipLaunchKernelGGL(sl_gemm_i8_ring_kernel, grid, dim3(512), RING_BYTES, c->stream, c->sl_xi, xplane, (int)s0, (int)s1,
+                           c->sl_q, (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, xscale, c->sl_G,
+                           (int)ldg, c->sl_tmin, (int)ntm, (const unsigned *)xflag);
     } else {
         constexpr int MI = 2;
         dim3 grid((unsigned)ntm, (unsigned)((s1 - s0 + 64 * MI - 1) / (64 * MI)));   // ntm 64-node tiles (the last may lie past N: minima +inf)
-        hipLaunchKernelGGL(sl_gemm_i8_kernel<MI>, grid, dim3(256), 0, c->stream, c->sl_xi, (int)s0, (int)s1, c->sl_q, (int)c->N,
-                           (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm);
+        hipLaunchKernelGGL((sl_gemm_i8_kernel<MI, 1>), grid, dim3(256), 0, c->stream, c->sl_xi, xplane, (int)s0, (int)s1, c->sl_q,
+                           (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, xscale, c->sl_G, (int)ldg,
+                           c->sl_tmin, (int)ntm, (const unsigned *)xflag);
+        hipLaunchKernelGGL((sl_gemm_i8_kernel<MI, 3>), grid, dim3(256), 0, c->stream, c->sl_xi, xplane, (int)s0, (int)s1, c->sl_q,
+                           (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, xscale, c->sl_G, (int)ldg,
+                           c->sl_tmin, (int)ntm, (const unsigned *)xflag);
     }
     VSOM_HIP_CHECK(hipGetLastError());
     return VSOM_OK;

@@ -59,6 +59,14 @@ public:
     virtual size_t getDepth() const noexcept = 0;
     virtual bool isAtStartOfDataStream() const noexcept = 0;
 
+    // [MI355X build] optional fast path of DataSet::loadNextDataFromStream (the step right before the hot path:
+    // the reference reloads every chunk every epoch, Som.cpp:737,1157).  peekFlat: this loader can write a chunk
+    // straight into a caller's buffer, and `rows` is what the NEXT load() would return.  loadFlat: write those rows
+    // (row-major, getDepth() floats each; every value valid) into dst, advance the stream exactly as load() does and
+    // leave `data` empty.  A loader that overrides neither keeps the reference's contract: load() fills `data`.
+    virtual bool peekFlat(size_t &rows) { (void)rows; return false; }
+    virtual size_t loadFlat(float *dst, size_t rows) { (void)dst; (void)rows; return 0; }
+
 protected:
     std::optional<size_t> m_maxLoadCount;
     size_t m_currentIndex;
@@ -71,6 +79,8 @@ public:
     ArrayDataLoader(const float *rows, size_t nrows, size_t depth,
                     std::optional<size_t> maxLoadCount = std::nullopt);
     size_t load() override;
+    bool peekFlat(size_t &rows) override;
+    size_t loadFlat(float *dst, size_t rows) override;
     std::vector<RowData> getPreview(size_t count) override;
     bool open(const char *) override { return true; }
     std::vector<std::string> findAllColumns() override { return getNames(); }
@@ -105,6 +115,8 @@ class MnistDataLoader : public IDataLoader {
 public:
     MnistDataLoader(std::optional<size_t> maxLoadCount = std::nullopt, bool verbose = false);
     size_t load() override;
+    bool peekFlat(size_t &rows) override;
+    size_t loadFlat(float *dst, size_t rows) override;
     std::vector<RowData> getPreview(size_t count) override;
     bool open(const char *path) override;
     std::vector<std::string> findAllColumns() override { return _names; }
@@ -127,6 +139,8 @@ protected:
     bool _verbose;
     mutable std::vector<unsigned char> _img, _lab;   // file bytes, kept between loads
     std::vector<RowData> readRows(size_t skip, size_t limit) const;
+    size_t rowsAvailable(size_t skip, size_t limit) const;     // rows readRows(skip, limit) would return
+    void convertRows(size_t skip, size_t nrows, float *flat, std::vector<RowData> *rows) const;
 };
 
 // ----- SqliteDataLoader ------------------------------------------------------------------------
@@ -250,6 +264,7 @@ private:
     Pinned m_flat[2];
     int m_cur = 0;
     mutable bool m_rowsBuilt = true;
+    bool m_fromFlat = false;      // the current chunk came through IDataLoader::loadFlat (the loader's `data` is empty)
     void ensureRows() const;
 };
 

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -205,6 +206,41 @@ size_t ArrayDataLoader::load()
     return n;
 }
 
+// rows straight into the caller's (pinned) buffer: one copy instead of a heap object per row and two copies
+bool ArrayDataLoader::peekFlat(size_t &rows)
+{
+    const size_t chunk = m_maxLoadCount.value_or(m_nrows);
+    rows = std::min(m_currentIndex + chunk, m_nrows) - m_currentIndex;
+    return true;
+}
+
+size_t ArrayDataLoader::loadFlat(float *dst, size_t rows)
+{
+    const size_t chunk = m_maxLoadCount.value_or(m_nrows);
+    const size_t end = std::min(m_currentIndex + chunk, m_nrows);
+    const size_t n = std::min(rows, end - m_currentIndex);
+    data.clear();
+    const float *src = &m_rows[m_currentIndex * m_depth];
+    const size_t total = n * m_depth;
+    // a 12.8 MB chunk is ~1 ms of one core's memcpy: a few threads bring it well under the device step it hides behind
+    const size_t nthreads = total >= (1u << 20) ? std::min<size_t>(4, std::max(1u, std::thread::hardware_concurrency())) : 1;
+    if (nthreads <= 1) {
+        std::memcpy(dst, src, total * sizeof(float));
+    } else {
+        std::vector<std::thread> pool;
+        const size_t per = (total + nthreads - 1) / nthreads;
+        for (size_t t = 0; t < nthreads; ++t) {
+            const size_t a = t * per, b = std::min(total, a + per);
+            if (a < b)
+                pool.emplace_back([=] { std::memcpy(dst + a, src + a, (b - a) * sizeof(float)); });
+        }
+        for (auto &th : pool)
+            th.join();
+    }
+    m_currentIndex = end >= m_nrows ? 0 : end;   // wrap: the stream is back at its start
+    return n;
+}
+
 std::vector<RowData> ArrayDataLoader::getPreview(size_t count)
 {
     std::vector<RowData> out;
@@ -251,6 +287,18 @@ void DataSet::ensureRows() const
     valid.reserve(n);
     allData.reserve(n);
     size_t cur = 0;
+    if (m_fromFlat) {             // the chunk came through IDataLoader::loadFlat: rows from the staging copy, all valid
+        const float *flat = m_flat[m_cur].p;
+        for (; cur < n; ++cur) {
+            Eigen::VectorXf v((Eigen::Index)depth);
+            std::memcpy(v.data(), flat + cur * depth, depth * sizeof(float));
+            data.push_back(std::move(v));
+            valid.emplace_back(depth, 1);
+            allData.push_back(DataRow{&data.back(), &valid.back(), &lastBMU[cur]});
+        }
+        m_rowsBuilt = true;
+        return;
+    }
     for (auto &row : _loader.data) {
         if (cur >= n)
             break;
@@ -284,7 +332,7 @@ std::vector<Eigen::VectorXf> DataSet::getPreviewData(size_t count) const
 Eigen::VectorXf DataSet::getData(size_t i) const
 {
     ensureRows();
-    if (_loader.data.size() > i && data.size() > i)
+    if ((m_fromFlat ? n : _loader.data.size()) > i && data.size() > i)
         return data[i];
     return Eigen::VectorXf::Zero((Eigen::Index)_loader.getDepth());
 }
@@ -386,7 +434,7 @@ void DataSet::Pinned::reserve(size_t nfloats)
 // the reference passes DataSet by value (SOM.hpp:78-82); the copy owns its row views and staging
 DataSet::DataSet(const DataSet &o)
     : data{o.data}, valid{o.valid}, index{o.index}, lastBMU{o.lastBMU}, _loader{o._loader}, depth{o.depth}, n{o.n},
-      loadedNumberOfChunks{o.loadedNumberOfChunks}, _verbose{o._verbose}, m_rowsBuilt{o.m_rowsBuilt}
+      loadedNumberOfChunks{o.loadedNumberOfChunks}, _verbose{o._verbose}, m_rowsBuilt{o.m_rowsBuilt}, m_fromFlat{o.m_fromFlat}
 {
     if (m_rowsBuilt) {
         allData.reserve(o.allData.size());
@@ -405,29 +453,40 @@ void DataSet::loadNextDataFromStream()
 {
     if (_loader.isAtStartOfDataStream())
         loadedNumberOfChunks = 0;
-    const size_t numberOfRows = _loader.load();
-    n = numberOfRows;
+    // the other pinned buffer: an asynchronous copy of the previous chunk may still read the current one
+    m_cur ^= 1;
     depth = _loader.getDepth();
+    size_t numberOfRows = 0, peek = 0;
+    if (_loader.peekFlat(peek)) {
+        // the loader writes the chunk straight into the pinned staging buffer (no per-row heap objects, one copy);
+        // the reference's per-row containers are still built on first use (ensureRows)
+        m_flat[m_cur].reserve(peek * depth);
+        numberOfRows = _loader.loadFlat(m_flat[m_cur].p, peek);
+        m_fromFlat = true;
+    } else {
+        numberOfRows = _loader.load();
+        depth = _loader.getDepth();
+        m_fromFlat = false;
+        m_flat[m_cur].reserve(numberOfRows * depth);
+        float *flat = m_flat[m_cur].p;
+        size_t cur = 0;
+        for (auto &row : _loader.data) {
+            if (cur >= numberOfRows)
+                break;
+            const size_t have = std::min<size_t>((size_t)row.values.size(), depth);
+            std::memcpy(flat + cur * depth, row.values.data(), have * sizeof(float));
+            for (size_t d = have; d < depth; ++d)
+                flat[cur * depth + d] = 0.f;
+            ++cur;
+        }
+    }
+    n = numberOfRows;
     lastBMU.assign(numberOfRows, 0);
-    m_rowsBuilt = false;          // data / valid / allData are rebuilt from the loader on first use
+    m_rowsBuilt = false;          // data / valid / allData are rebuilt on first use
     index.resize(numberOfRows);
     for (size_t k = 0; k < index.size(); ++k)
         index[k] = k;
     shuffle();
-    // the other pinned buffer: an asynchronous copy of the previous chunk may still read the current one
-    m_cur ^= 1;
-    m_flat[m_cur].reserve(numberOfRows * depth);
-    float *flat = m_flat[m_cur].p;
-    size_t cur = 0;
-    for (auto &row : _loader.data) {
-        if (cur >= numberOfRows)
-            break;
-        const size_t have = std::min<size_t>((size_t)row.values.size(), depth);
-        std::memcpy(flat + cur * depth, row.values.data(), have * sizeof(float));
-        for (size_t d = have; d < depth; ++d)
-            flat[cur * depth + d] = 0.f;
-        ++cur;
-    }
     ++loadedNumberOfChunks;
     if (_verbose)
         std::cout << "Loaded " << loadedNumberOfChunks << " number of chunks\n";
@@ -435,7 +494,7 @@ void DataSet::loadNextDataFromStream()
 
 void DataSet::display() const
 {
-    std::cout << "Number of samples: " << _loader.data.size() << "\nVector length: " << _loader.getDepth() << "\n";
+    std::cout << "Number of samples: " << (m_fromFlat ? n : _loader.data.size()) << "\nVector length: " << _loader.getDepth() << "\n";
 }
 size_t DataSet::vectorLength() const { return _loader.getDepth(); }
 // the reference shuffles an index vector that nothing reads (DataSet.cpp:143-146,173-176): order = load order

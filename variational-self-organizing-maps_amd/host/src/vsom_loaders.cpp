@@ -106,43 +106,48 @@ size_t amount_to_read(size_t limit, size_t skip, size_t count)
 
 }   // namespace
 
-std::vector<RowData> MnistDataLoader::readRows(size_t skip, size_t limit) const
+// rows readRows(skip, limit) returns; reads the two files on first use (the reference re-reads both on every
+// load(); the bytes are kept after the first read here -- open() drops them -- which changes nothing unless the files
+// are rewritten during training)
+size_t MnistDataLoader::rowsAvailable(size_t skip, size_t limit) const
 {
-    std::vector<RowData> out;
-    // the reference re-reads both files on every load(); the bytes are kept after the first read here
-    // (open() drops them), which changes nothing unless the files are rewritten during training
     if (_img.empty() || _lab.empty()) {
         _img = read_idx(_filePath + "/train-images-idx3-ubyte", 0x803);
         _lab = read_idx(_filePath + "/train-labels-idx1-ubyte", 0x801);
     }
-    const auto &img = _img;
-    const auto &lab = _lab;
-    if (img.empty() || lab.empty())
-        return out;
-    const size_t icount = be32(img.data() + 4), rows = be32(img.data() + 8), cols = be32(img.data() + 12);
-    const size_t lcount = be32(lab.data() + 4);
-    const size_t px = rows * cols;
+    if (_img.empty() || _lab.empty())
+        return 0;
+    const size_t icount = be32(_img.data() + 4), lcount = be32(_lab.data() + 4);
     size_t ni = amount_to_read(limit, skip, icount), nl = amount_to_read(limit, skip, lcount);
     // never past the buffers (a no-limit read after a skip is clipped; the reference would over-read)
     ni = std::min(ni, icount > skip ? icount - skip : 0);
     nl = std::min(nl, lcount > skip ? lcount - skip : 0);
-    const size_t nrows = std::min(ni, nl);   // std::transform over images, zipped with labels (:61-64)
-    out.resize(nrows);
-    const size_t depth = px + 10;
-    // rows are independent: a few host threads convert a chunk (4096 x 794 values plus two heap objects
-    // per row is several milliseconds on one core -- as long as the device step it has to hide behind)
+    return std::min(ni, nl);   // std::transform over images, zipped with labels (:61-64)
+}
+
+// rows [skip, skip + nrows) as 784 raw pixel values + the one-hot label, into a contiguous buffer (`flat`) or into
+// the reference's per-row containers (`rows`).  Rows are independent: a few host threads convert a chunk (4096 x 794
+// values is several milliseconds on one core -- as long as the device step it has to hide behind)
+void MnistDataLoader::convertRows(size_t skip, size_t nrows, float *flat, std::vector<RowData> *rows) const
+{
+    const size_t px = be32(_img.data() + 8) * be32(_img.data() + 12), depth = px + 10;
     auto convert = [&](size_t r0, size_t r1) {
         for (size_t r = r0; r < r1; ++r) {
-            RowData &row = out[r];
-            row.values = Eigen::VectorXf((Eigen::Index)depth);
-            float *dst = row.values.data();
-            const unsigned char *src = img.data() + 16 + (skip + r) * px;
+            float *dst;
+            if (rows) {
+                RowData &row = (*rows)[r];
+                row.values = Eigen::VectorXf((Eigen::Index)depth);
+                row.valid.assign(depth, 1);
+                dst = row.values.data();
+            } else {
+                dst = flat + r * depth;
+            }
+            const unsigned char *src = _img.data() + 16 + (skip + r) * px;
             for (size_t d = 0; d < px; ++d)
                 dst[d] = (float)src[d];                               // raw 0..255, un-normalised (:73-75)
-            const unsigned label = lab[8 + skip + r];
+            const unsigned label = _lab[8 + skip + r];
             for (size_t k = 0; k < 10; ++k)
                 dst[px + k] = (label == k) ? 1.0f : 0.0f;             // one-hot label (:66-71)
-            row.valid.assign(depth, 1);
         }
     };
     const size_t nthreads = nrows >= 512 ? std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency())) : 1;
@@ -159,7 +164,36 @@ std::vector<RowData> MnistDataLoader::readRows(size_t skip, size_t limit) const
         for (auto &th : pool)
             th.join();
     }
+}
+
+std::vector<RowData> MnistDataLoader::readRows(size_t skip, size_t limit) const
+{
+    std::vector<RowData> out;
+    const size_t nrows = rowsAvailable(skip, limit);
+    if (nrows == 0)
+        return out;
+    out.resize(nrows);
+    convertRows(skip, nrows, nullptr, &out);
     return out;
+}
+
+bool MnistDataLoader::peekFlat(size_t &rows)
+{
+    rows = rowsAvailable(m_currentIndex, m_maxLoadCount.value_or(0));
+    return true;
+}
+
+size_t MnistDataLoader::loadFlat(float *dst, size_t rows)
+{
+    const size_t n = std::min(rows, rowsAvailable(m_currentIndex, m_maxLoadCount.value_or(0)));
+    data.clear();
+    if (n)
+        convertRows(m_currentIndex, n, dst, nullptr);
+    if (n == 0 || n >= 60000)     // MnistDataLoader.cpp:53-55
+        m_currentIndex = 0;
+    else
+        m_currentIndex += n;
+    return n;
 }
 
 size_t MnistDataLoader::load()

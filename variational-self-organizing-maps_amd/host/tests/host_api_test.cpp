@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <memory>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -116,6 +118,95 @@ static int perf_mnist(const std::string &folder)
     return 0;
 }
 
+// `host_api_test perf_e2e array <rows.f32> <nrows> <depth> <chunk>` / `perf_e2e mnist <folder> <chunk>`:
+// Som::train(..., BatchMap) through the reference API on a 128x128 map, one JSON line per run with the wall time
+// of the call, the device time of the same epochs (the library's per-phase HIP-event spans on the context's
+// stream: staging, search, neighbourhood prefix, chains, expansion -- the side stream's bmuHits / MSE launch runs
+// beside them) and their ratio.  Runs: three times ONE epoch (every epoch a full search: Som.cpp:738 passes
+// i == 0) and a five-epoch schedule (one full-search epoch, four local).  VSOM_UPDATE_MODE selects the arithmetic.
+static int perf_e2e(int argc, char **argv)
+{
+    const std::string kind = argv[2];
+    std::unique_ptr<IDataLoader> loader;
+    std::vector<float> rows;
+    size_t nrows = 0, depth = 0, chunk = 4096;
+    if (kind == "array" && argc > 6) {
+        nrows = std::stoul(argv[4]);
+        depth = std::stoul(argv[5]);
+        chunk = std::stoul(argv[6]);
+        rows.resize(nrows * depth);
+        std::ifstream f(argv[3], std::ios::binary);
+        f.read((char *)rows.data(), (std::streamsize)(rows.size() * 4));
+        if (!f) {
+            std::fprintf(stderr, "cannot read %s\n", argv[3]);
+            return 2;
+        }
+        loader = std::make_unique<ArrayDataLoader>(rows.data(), nrows, depth, chunk);
+    } else if (kind == "mnist" && argc > 4) {
+        chunk = std::stoul(argv[4]);
+        auto m = std::make_unique<MnistDataLoader>(chunk);
+        m->open(argv[3]);
+        nrows = 60000;
+        loader = std::move(m);
+    } else {
+        std::fprintf(stderr, "usage: perf_e2e array <rows.f32> <nrows> <depth> <chunk> | perf_e2e mnist <folder> <chunk>\n");
+        return 2;
+    }
+    DataSet ds(*loader);
+    Som som{128, 128, ds, Transformation::Standard(loader->getNames())};
+    som.randomInitialize(42, 1);
+    const char *arith = std::getenv("VSOM_UPDATE_MODE");
+    std::cout.setstate(std::ios_base::failbit);
+    som.train(ds, 1, 0.0, 0.0, 40.0, 0.05, Som::WeigthDecayFunction::BatchMap);        // warm-up: allocations, code objects
+    // host side alone: what one pass of the loader + DataSet staging costs (no device work in flight)
+    double host_ms = 0;
+    size_t host_chunks = 0;
+    {
+        ds.resetStreamLoadPosition();
+        const auto h0 = std::chrono::steady_clock::now();
+        do {
+            ds.loadNextDataFromStream();
+            ++host_chunks;
+        } while (!ds.hasReadWholeDataStream());
+        host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count();
+        ds.resetStreamLoadPosition();
+    }
+    static const char *const names[VSOM_T_COUNT] = {"stage", "bmu", "finish", "cw", "update", "online", "sigma"};
+    auto run = [&](const char *what, size_t epochs, double sigma0) {
+        float ms[VSOM_T_COUNT];
+        uint32_t cnt[VSOM_T_COUNT];
+        vsom_get_timing(som.context(), ms, cnt, 1);
+        vsom_enable_timing(som.context(), 1);
+        const auto t0 = std::chrono::steady_clock::now();
+        som.train(ds, epochs, 0.0, 0.0, sigma0, 0.05, Som::WeigthDecayFunction::BatchMap);
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        vsom_get_timing(som.context(), ms, cnt, 1);
+        vsom_enable_timing(som.context(), 0);
+        double dev = 0;
+        for (int i = 0; i < VSOM_T_COUNT; ++i)
+            if (i != VSOM_T_FINISH)
+                dev += ms[i];
+        std::cout.clear();
+        std::printf("{\"e2e\": \"%s\", \"loader\": \"%s\", \"arithmetic\": \"%s\", \"rows\": %zu, \"depth\": %zu, \"chunk\": %zu, "
+                    "\"epochs\": %zu, \"wall_ms_per_epoch\": %.3f, \"device_ms_per_epoch\": %.3f, \"device_over_wall\": %.4f, "
+                    "\"samples_per_s\": %.0f, \"device_only_samples_per_s\": %.0f, \"host_load_ms_per_epoch\": %.3f, \"chunks_per_epoch\": %zu",
+                    what, kind.c_str(), arith ? arith : "strict", nrows, som.getDepth(), chunk, epochs, wall / epochs, dev / epochs,
+                    dev / wall, nrows * epochs / wall * 1e3, nrows * epochs / dev * 1e3, host_ms, host_chunks);
+        for (int i = 0; i < VSOM_T_COUNT; ++i)
+            if (cnt[i])
+                std::printf(", \"%s_ms\": %.3f", names[i], ms[i] / epochs);
+        std::printf("}\n");
+        std::fflush(stdout);
+        std::cout.setstate(std::ios_base::failbit);
+    };
+    for (int r = 0; r < 3; ++r)
+        run("one epoch per call (full search)", 1, 40.0);
+    run("five-epoch schedule (1 full + 4 local)", 5, 40.0);
+    run("five-epoch schedule (1 full + 4 local)", 5, 40.0);
+    std::cout.clear();
+    return 0;
+}
+
 // `host_api_test mnist <folder> <outdir>`: BASELINE configuration 2's plumbing at test size -- IDX files
 // -> MnistDataLoader (chunked) -> DataSet -> Som::train(BatchMap); the dump is compared with the oracle
 // run on the same rows and chunk boundaries (tests/test_gpu_host_cpp.py)
@@ -139,6 +230,8 @@ int main(int argc, char **argv)
         return perf_tiny();
     if (argc > 2 && std::string(argv[1]) == "perf_mnist")
         return perf_mnist(argv[2]);
+    if (argc > 2 && std::string(argv[1]) == "perf_e2e")
+        return perf_e2e(argc, argv);
     if (argc > 3 && std::string(argv[1]) == "mnist")
         return mnist(argv[2], argv[3]);
     const std::string out = argc > 1 ? argv[1] : ".";
