@@ -101,6 +101,9 @@ def parse():
                     help="c2 / c3: what the rows hold for `value` (default: the raw uint8-valued pixels of the reference's "
                          "MNIST loader); the other two are timed in the same run and reported as `data_variants`")
     ap.add_argument("--no-data-variants", action="store_true", help="skip the timed runs on the other data kinds")
+    ap.add_argument("--no-stage-ahead", action="store_true",
+                    help="N = 1 batch steps: stage every chunk at the start of its own step (rounds 1-4) instead of beside "
+                         "the chains of the previous step (vsom_stage_next_device / vsom_commit_chunk)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--nchunks", type=int, default=4, help="distinct resident chunks cycled over")
@@ -370,8 +373,20 @@ def main():
         if args.host_chunks == "overlap":
             ctx.prefetch_chunk(pinned[0].array)
 
+    # N = 1 batch steps are software-pipelined the way the C++ drivers are (Som::trainBatchSom in host/src/vsom_host.cpp):
+    # the staging kernels of chunk i+1 (rows, live columns, int8 images: map-independent) are enqueued right after the
+    # epoch of chunk i and run beside its chains; the step then starts with a commit that launches nothing
+    pipelined = (not online and not sharded and args.host_chunks == "off" and not args.no_stage_ahead)
+
     def step(sp, i):
         with torch.cuda.stream(stream):
+            if pipelined:
+                ctx.commit_chunk()                                   # chunk i (staged during step i-1)
+                eng._bind_chunk()
+                trainer.epoch(sigma, is_first)
+                nxt = sp.own[(i + 1) % len(sp.own)]
+                ctx.stage_next_device(nxt.data_ptr(), nxt.shape[0])
+                return
             if online:
                 # Som::trainBasicSom's sample loop over one staged chunk (Som.cpp:1159-1171)
                 eng.load_chunk_device(sp.own[i % len(sp.own)])
@@ -395,13 +410,21 @@ def main():
             if args.host_chunks == "overlap":
                 ctx.prefetch_chunk(pinned[(i + 1) % len(pinned)].array)   # H2D of chunk i+1 beside this epoch
 
-    def timed(sp, nwarm, nsteps):
+    # HIP events of the library's kernel groups (vsom_enable_timing_of): the timed region carries the DOMINANT group's
+    # events only -- every timed group puts two event records between kernels that otherwise run back to back (~5 us of
+    # idle device each; twelve of them were 1.4 % of a C3 step) -- and a short second pass with all groups gives the
+    # per-phase breakdown (`kernel_ms_per_step`)
+    dominant = "online" if online else "update"
+
+    def timed(sp, nwarm, nsteps, groups=(dominant,)):
+        if pipelined:
+            ctx.stage_next_device(sp.own[0].data_ptr(), sp.own[0].shape[0])   # the chunk of step 0
         for i in range(nwarm):
             step(sp, i)
         trainer.flush()
         torch.cuda.synchronize()
         ctx.get_timing(reset=True)
-        ctx.enable_timing(True)
+        ctx.enable_timing(True, groups=groups)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -428,6 +451,8 @@ def main():
     dt, timing = timed(split, args.warmup, args.steps)
     mse = float(ctx.get_mse())
     sl_stats = ctx.shortlist_stats() if not online else None
+    bsteps = max(1, min(args.steps, 10))
+    _, breakdown = timed(split, 1, bsteps, groups=capi.TIMER_NAMES)      # every group timed: the per-phase figures
 
     others = []
     if not args.no_other_arith and not online and capi.has_contracted(tr):   # Median / CLR have one arithmetic
@@ -449,7 +474,9 @@ def main():
             torch.cuda.synchronize()
             ctx.set_state(map=make_map(cfg, D, vname))
             dtv, tmv = timed(spv, 3, args.steps)
-            variants.append((vname, spv, dtv, tmv, ctx.shortlist_stats()))
+            slv = ctx.shortlist_stats()
+            _, tbv = timed(spv, 1, bsteps, groups=capi.TIMER_NAMES)
+            variants.append((vname, spv, dtv, tmv, slv, tbv))
             del spv.own
         ctx.set_state(map=init_map)
 
@@ -502,7 +529,7 @@ def main():
             else:
                 flops = 6.0 * n_nodes_rank * D * sp.Bglob
             ach = flops / upd_avg_s / 1e12 if upd_avg_s > 0 else 0.0
-            chain_small = ((n_nodes_rank + 63) // 64) * ((D + 13) // 14) <= 448      # VSOM_CHAIN_MAX_WAVES
+            chain_small = bool(capi.lib().vsom_small_map_chains(ctx._h, n_nodes_rank))
             kern = {capi.STANDARD: ("update_chain3_kernel (small-map phase-2 chains)" if chain_small else
                                     "vsom_update_{std,sfma,fma}_nt4_gfx950 (phase-2 mean/sigma^2 chains, hand-scheduled)"),
                     capi.MEDIAN: ("update_chain3_kernel<median> (small-map phase-2 chains)" if chain_small else
@@ -558,6 +585,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "update_arithmetic": arith,
+            "staging": ("chunk i+1 staged beside the chains of chunk i (vsom_stage_next_device + vsom_commit_chunk; every step "
+                        "still stages exactly one chunk)" if pipelined else "every chunk staged at the start of its own step"),
             "backend": ({"nccl": "nccl (RCCL)", "gloo": "gloo (CPU rehearsal of the N > 1 flow, not RCCL)"}[backend]
                         if backend else "none (1 GPU)"),
             "collective_ranks": coll_ranks,
@@ -578,7 +607,10 @@ def main():
                                        (f"{world} independent replicas (the online path is sequential in samples)"
                                         if world > 1 else "1 GPU"))},
             "roofline": roof,
-            "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in timing.items()},
+            "kernel_ms_per_step": {k: round(v[0] / bsteps, 4) for k, v in breakdown.items()},
+            "kernel_ms_note": (f"from a second pass of {bsteps} steps with every kernel group timed (its event records cost "
+                               "idle device time, so its steps are slower than `ms_per_step`); the timed region of `value` "
+                               f"carries the events of the dominant group ('{dominant}') only"),
             "mse_last": mse,
             "bmu_shortlist_last": sl_stats,
         }
@@ -596,15 +628,15 @@ def main():
             out["data_kind"] = {"name": split.variant, "note": DATA_TEXT[split.variant]}
         if variants:
             out["data_variants"] = []
-            for vname, spv, dtv, tmv, slv in variants:
+            for vname, spv, dtv, tmv, slv, tbv in variants:
                 rv = roofline_for(tmv, spv)
                 lv, cv = gen.column_occupancy(spv.own_host[0])
                 out["data_variants"].append({
                     "data": vname, "note": DATA_TEXT[vname],
                     "value": round(steps * units_of(spv) / dtv, 3), "ms_per_step": round(dtv / steps * 1e3, 4),
                     "vs_headline": round(dt / dtv, 4),
-                    "bmu_ms": round(tmv["bmu"][0] / steps, 4), "update_ms": round(tmv["update"][0] / steps, 4),
-                    "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in tmv.items()},
+                    "bmu_ms": round(tbv["bmu"][0] / bsteps, 4), "update_ms": round(tmv["update"][0] / steps, 4),
+                    "kernel_ms_per_step": {k: round(v[0] / bsteps, 4) for k, v in tbv.items()},
                     "live_columns": lv,
                     "roofline": {k: rv.get(k) for k in ("achieved", "frac", "frac_executed", "avg_launch_ms",
                                                          "executed_basis")},
@@ -614,7 +646,7 @@ def main():
             out[sp2.kind + "_scaling"] = {
                 "scaling": sp2.kind, "value": round(steps * units_of(sp2) / dt2, 3), "unit": "samples/s",
                 "ms_per_step": round(dt2 / steps * 1e3, 4), "chunk_per_gpu": sp2.Bper, "chunk_total": sp2.Bglob,
-                "kernel_ms_per_step": {k: round(v[0] / steps, 4) for k, v in tm2.items()},
+                "update_ms_per_step": round(tm2[dominant][0] / steps, 4),
                 "note": ("every rank owns a full 4096-row chunk: one step is a 4096*N-row trainBatchSomEpoch, a different "
                          "algorithmic step from BASELINE config 3 (each chunk overwrites the map, Som.cpp:870)"
                          if sp2.kind == "weak" else "the 4096-row chunk of BASELINE config 3 shared out over the ranks")}

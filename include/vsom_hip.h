@@ -168,8 +168,20 @@ int vsom_set_chunk_device(vsom_ctx *ctx, const float *x_dev, size_t B);
 int vsom_host_alloc(void **out, size_t bytes);   /* pinned host memory */
 int vsom_host_free(void *p);
 int vsom_prefetch_chunk(vsom_ctx *ctx, const float *x_host, size_t B);
+/* Staging ahead (round 5): when the call directly follows an asynchronous batch epoch on the current chunk
+ * (vsom_batch_epoch_async / vsom_batch_phase2_async, Standard / Median on a map large enough for the lane = node
+ * chain kernels but small enough that their launch leaves workgroup slots idle -- at most two rounds of the chip's
+ * resident workgroups, e.g. 64x64x784; bigger launches lose more to the company than the overlap saves), the
+ * prefetched chunk's staging kernels are enqueued too -- on the copy stream, after the point of the
+ * epoch from which nothing reads the current chunk's sample rows any more -- so that they run BESIDE the epoch's
+ * chains and vsom_commit_chunk launches nothing.  Between such a prefetch and its commit the current chunk's
+ * sample rows are gone: lastBMU, the MSE and the model state of the current chunk stay readable, a search or a
+ * distance call on it does not (commit first).  In every other situation the staging happens at commit, as before. */
 int vsom_prefetch_wait(vsom_ctx *ctx);
 int vsom_commit_chunk(vsom_ctx *ctx);
+/* the same for a next chunk that ALREADY lives in HBM (x_dev must stay valid until vsom_commit_chunk has been called):
+ * staged beside the running epoch when that is possible now, else at vsom_commit_chunk */
+int vsom_stage_next_device(vsom_ctx *ctx, const float *x_dev, size_t B);
 /* DataSet::getLastBMU (DataSet.cpp:60-69) */
 int vsom_get_last_bmu(vsom_ctx *ctx, uint64_t *out_host);
 int vsom_set_last_bmu(vsom_ctx *ctx, const uint64_t *in_host);
@@ -292,8 +304,15 @@ size_t vsom_chunk_size(const vsom_ctx *ctx);
  * of the staged CHUNK buffer */
 uint32_t vsom_pitch(const vsom_ctx *ctx);
 uint32_t vsom_chunk_pitch(const vsom_ctx *ctx);
+/* 1 when phase 2 over a shard of `nodes` nodes takes the small-map chain kernel (lane = (node, dim pair),
+   update_chain3_kernel) instead of the lane = node kernels -- for reports that name the dominant kernel */
+int vsom_small_map_chains(const vsom_ctx *ctx, size_t nodes);
 /* per-kernel-group HIP-event timing on the context stream */
 int vsom_enable_timing(vsom_ctx *ctx, int on);
+/* the same for the groups whose bit (1u << VSOM_T_*) is set only: every timed group puts two event records between
+ * kernels that otherwise run back to back (~5 us of idle device each on this chip), so a measurement of a whole step
+ * times the one group it needs */
+int vsom_enable_timing_of(vsom_ctx *ctx, uint32_t group_mask);
 /* accumulated milliseconds and launch counts since the last reset (synchronises) */
 int vsom_get_timing(vsom_ctx *ctx, float *ms_out /*[VSOM_T_COUNT]*/,
                     uint32_t *count_out /*[VSOM_T_COUNT]*/, int reset);

@@ -64,6 +64,95 @@ def test_pipelined_chunks_match_oracle(pinned, tr, J):
         b.free()
 
 
+@pytest.mark.parametrize("source", ["host", "device"])
+@pytest.mark.parametrize("tr", [po.STANDARD, po.MEDIAN])
+def test_chunks_staged_beside_the_running_epoch_match_oracle(source, tr):
+    """On a map large enough for the lane = node chain kernels a prefetch that follows an asynchronous epoch also
+    STAGES the next chunk -- on the copy stream, beside the chains of the current one (include/vsom_hip.h "Staging
+    ahead"; lastBMU and the compaction's column record are double-buffered).  Chunks of different sizes, with and
+    without dead columns / the compaction (>= 1024 rows), uint8-valued and float-valued, one larger than every buffer
+    (staged at commit instead), first-epoch and local searches: every epoch is the oracle's bit for bit, and the
+    current chunk's lastBMU / MSE stay readable between prefetch and commit."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")                # the runtime libvsom_hip.so already runs on (plain device buffers)
+    W, H, J = 48, 48, 196
+    sizes = [1100, 1280, 77, 1100, 1500, 1024, 2200, 1100]
+    kinds = ["u8", "u8", "u8", "f", "dense", "u8", "f", "u8"]
+    chunks = []
+    for i, (b, k) in enumerate(zip(sizes, kinds)):
+        x = gen.mnist_like(b, seed=30 + i, dim=J)
+        if k == "f":
+            x = (x / np.float32(255)).astype(np.float32)
+        elif k == "dense":
+            x = gen.blobs(b, J, 5, 1, 40 + i, sigma=0.5)
+        chunks.append(x)
+    init = (gen.random_map(W * H, J, seed=42) * np.float32(100) + np.float32(100)).astype(np.float32)
+    orc = po.OracleSom(W, H, J, tr)
+    orc.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    ctx.set_state(map=init)
+    keep = []
+
+    def give(i):
+        if source == "host":
+            pb = capi.PinnedBuffer(chunks[i].shape)
+            pb.array[...] = chunks[i]
+            keep.append(pb)
+            ctx.prefetch_chunk(pb.array)
+        else:
+            x = np.ascontiguousarray(chunks[i])
+            ptr = C.c_void_p()
+            assert hip.hipMalloc(C.byref(ptr), C.c_size_t(x.nbytes)) == 0
+            assert hip.hipMemcpy(ptr, x.ctypes.data_as(C.c_void_p), C.c_size_t(x.nbytes), C.c_int(1)) == 0   # host to device
+            keep.append(ptr)
+            ctx.stage_next_device(ptr.value, x.shape[0])
+
+    sigma = 12.0
+    give(0)
+    for i in range(len(chunks)):
+        ctx.commit_chunk()
+        assert ctx.chunk_size == sizes[i]
+        first = i in (0, 1, 4)                    # full searches and local ones
+        ctx.batch_epoch_async(sigma, first)
+        if i + 1 < len(chunks):
+            give(i + 1)                           # copy AND staging of chunk i+1 beside the epoch of chunk i
+        mse_g = ctx.get_mse()
+        lb = np.zeros(sizes[i], np.uint64)
+        mse_o = orc.batch_epoch(chunks[i], lb, sigma, first, nthreads=16)
+        assert ctx.chunk_size == sizes[i]
+        assert (ctx.get_last_bmu() == lb).all(), i
+        assert np.float32(mse_g) == np.float32(mse_o) or (np.isnan(mse_g) and np.isnan(mse_o)), i
+        st = ctx.get_state()
+        for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("weight", orc.weight)):
+            same = (_bits(st[k]) == _bits(ref)) | (np.isnan(st[k]) & np.isnan(ref))
+            assert same.all(), (i, k)
+        assert (st["hits"] == orc.hits).all()
+        sigma *= 0.93
+    # a chunk staged ahead and then overwritten by a plain upload: the upload wins, the prefetched chunk is staged at
+    # its commit
+    ctx.batch_epoch_async(sigma, False)           # (no reload: the search walks on from this chunk's last BMUs)
+    orc.batch_epoch(chunks[-1], lb, sigma, False, nthreads=16)
+    give(0)
+    ctx.upload_chunk(chunks[2])
+    lb = np.zeros(sizes[2], np.uint64)
+    mse_o = orc.batch_epoch(chunks[2], lb, sigma, True, nthreads=16)
+    mse_g = ctx.batch_epoch(sigma, True)
+    assert np.float32(mse_g) == np.float32(mse_o) and (ctx.get_last_bmu() == lb).all()
+    ctx.commit_chunk()
+    lb = np.zeros(sizes[0], np.uint64)
+    mse_o = orc.batch_epoch(chunks[0], lb, sigma, True, nthreads=16)
+    mse_g = ctx.batch_epoch(sigma, True)
+    assert np.float32(mse_g) == np.float32(mse_o) and (ctx.get_last_bmu() == lb).all()
+    st = ctx.get_state()
+    assert ((_bits(st["map"]) == _bits(orc.map)) | (np.isnan(st["map"]) & np.isnan(orc.map))).all()
+    ctx.close()
+    for b in keep:
+        if hasattr(b, "free"):
+            b.free()
+        else:
+            hip.hipFree(b)
+
+
 def test_commit_without_prefetch_is_an_error():
     ctx = vsom_amd.Context(4, 4, 8)
     with pytest.raises(capi.VsomError):

@@ -1,4 +1,4 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r4_mfma; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/d -o p -- python3 $R/bench.py --no-cpu --no-other-arith --steps 3 --warmup 1 > $O/d.log 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/d -o p -- python3 $R/bench.py --no-cpu --no-other-arith --no-data-variants --steps 3 --warmup 1 > $O/d.log 2>&1
 python3 $R/tools/pmc_summary.py $(find $O/d -name '*counter_collection.csv' | head -1) $(find $O/d -name '*kernel_trace.csv' | head -1) | grep -A9 "sl_gemm"
 rm -rf $O/d

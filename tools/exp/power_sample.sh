@@ -4,7 +4,7 @@
 #   bash tools/exp/power_sample.sh [strict|sigma|contracted]  > profiles/r3_power_<arith>.txt
 ARITH=${1:-strict}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-python3 $R/bench.py --steps 2500 --warmup 5 --arith $ARITH --no-other-arith --no-cpu > /tmp/power_bench.json 2>/dev/null &
+python3 $R/bench.py --steps 2500 --warmup 5 --arith $ARITH --no-other-arith --no-data-variants --no-cpu > /tmp/power_bench.json 2>/dev/null &
 BP=$!
 sleep 6
 for i in $(seq 1 16); do

@@ -1,12 +1,12 @@
 #!/bin/bash
-# PMC passes for the dominant update kernel of a bench configuration: bash tools/exp/r4_pmc_c2.sh TAG [bench args]
+# PMC passes for the dominant update kernel of a bench configuration: bash tools/pmc_kernel.sh TAG [bench args]
 set -u
 TAG=${1:-r4_c2}; shift || true
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--no-cpu --no-other-arith --steps 3 --warmup 1 $*"
+B="--no-cpu --no-other-arith --no-data-variants --steps 3 --warmup 1 $*"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/d -o p -- python3 $R/bench.py $B > $O/d.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA --kernel-trace --output-format csv -d $O/e -o p -- python3 $R/bench.py $B > $O/e.log 2>&1
 echo skip > $O/f.log

@@ -4,8 +4,8 @@
 set -u
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 bash tools/collect_profiles.sh r4_c3 --steps 20 > /dev/null 2>&1; echo c3 done
-bash tools/collect_profiles.sh r4_c3_sigma --steps 10 --arith sigma --no-other-arith > /dev/null 2>&1; echo c3 sigma done
-bash tools/collect_profiles.sh r4_c3_contracted --steps 10 --arith contracted --no-other-arith > /dev/null 2>&1; echo c3 contracted done
+bash tools/collect_profiles.sh r4_c3_sigma --steps 10 --arith sigma --no-other-arith --no-data-variants > /dev/null 2>&1; echo c3 sigma done
+bash tools/collect_profiles.sh r4_c3_contracted --steps 10 --arith contracted --no-other-arith --no-data-variants > /dev/null 2>&1; echo c3 contracted done
 bash tools/collect_profiles.sh r4_c2 --config c2 --steps 10 > /dev/null 2>&1; echo c2 done
 bash tools/collect_profiles.sh r4_c4 --config c4 --steps 10 > /dev/null 2>&1; echo c4 done
 bash tools/collect_profiles.sh r4_c5 --config c5 --steps 10 > /dev/null 2>&1; echo c5 done

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Whole trainBatchSom schedule (Som.cpp:716-754) at BASELINE config 3's size on one GPU: sigma = sigma0 exp(-decay e)
 down to 1, two chunks of 4096 MNIST-like rows per epoch, one line per epoch (sigma, ms per chunk, share of NaN in the
-map).  Late epochs are where the neighbourhood table underflows to exact zeros and the skip variants of the chain
-kernels apply (gen_nt_asm.py); VSOM_NO_SKIP=1 gives the plain kernels for comparison."""
+map).  Late epochs are where the neighbourhood table underflows to exact zeros and most of the map turns NaN (a node no
+sample of the chunk reaches has W = 0) -- the measurement behind profiles/r4_late_epoch_skip_experiment.txt."""
 import argparse
 import json
 import math
@@ -52,7 +52,7 @@ def main():
         m = ctx.get_state()["map"]
         print(json.dumps({"epoch": e, "sigma": round(sigma, 3), "ms_per_chunk_incl_upload": round(dt, 3),
                           "nan_share_of_map": round(float(np.isnan(m).mean()), 4)}), flush=True)
-    print(json.dumps({"schedule_ms": round(total, 1), "no_skip": os.environ.get("VSOM_NO_SKIP", "0")}), flush=True)
+    print(json.dumps({"schedule_ms": round(total, 1)}), flush=True)
     ctx.close()
 
 

@@ -11,7 +11,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvsom_hip.so")
+# the in-tree library; VSOM_LIB names another BUILD OF THE SAME LIBRARY (the -DVSOM_DEVELOPMENT build of tools/exp/,
+# which times variant code objects) without overwriting the shipped file
+_INTREE = os.path.join(_HERE, "libvsom_hip.so")
+LIB_PATH = os.environ.get("VSOM_LIB") or _INTREE
 
 STANDARD, MEDIAN, CLR = 0, 1, 2
 EXPONENTIAL, INVERSE_PROPORTIONAL, BATCHMAP = 0, 1, 2
@@ -26,13 +29,13 @@ SYMBOLS = [
     "vsom_last_error", "vsom_device_count", "vsom_create", "vsom_destroy", "vsom_set_stream",
     "vsom_synchronize", "vsom_set_bmu_mode", "vsom_set_update_mode", "vsom_set_column_compaction", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
     "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_host_alloc", "vsom_host_free",
-    "vsom_prefetch_chunk", "vsom_prefetch_wait", "vsom_commit_chunk", "vsom_get_last_bmu",
+    "vsom_prefetch_chunk", "vsom_prefetch_wait", "vsom_commit_chunk", "vsom_stage_next_device", "vsom_get_last_bmu",
     "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_find_bmu", "vsom_bmu_local_batch",
     "vsom_distances", "vsom_bmu_restricted_batch", "vsom_distances_row", "vsom_distances_raw", "vsom_batch_phase1_async", "vsom_batch_finish_async",
     "vsom_batch_phase2_async", "vsom_batch_epoch_async", "vsom_batch_epoch", "vsom_get_mse",
     "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk", "vsom_train_online_chunk_acc",
     "vsom_neighbourhood_weight", "vsom_device_ptr", "vsom_chunk_size", "vsom_pitch",
-    "vsom_chunk_pitch", "vsom_enable_timing", "vsom_get_timing",
+    "vsom_chunk_pitch", "vsom_small_map_chains", "vsom_enable_timing", "vsom_enable_timing_of", "vsom_get_timing",
     "vsom_group_create", "vsom_group_destroy", "vsom_group_size", "vsom_group_ctx", "vsom_group_transport",
     "vsom_group_synchronize", "vsom_group_set_state", "vsom_group_get_state", "vsom_group_set_update_mode",
     "vsom_group_set_bmu_mode", "vsom_group_upload_chunk", "vsom_group_prefetch_chunk", "vsom_group_prefetch_wait",
@@ -58,8 +61,8 @@ def build(force=False):
         for f in os.listdir(os.path.join(_HERE, "csrc")):
             if f.endswith(".o"):
                 os.remove(os.path.join(_HERE, "csrc", f))
-    subprocess.check_call(["bash", script, LIB_PATH], stdout=subprocess.DEVNULL)
-    return LIB_PATH
+    subprocess.check_call(["bash", script, _INTREE], stdout=subprocess.DEVNULL)
+    return _INTREE
 
 
 _lib = None
@@ -91,6 +94,9 @@ def lib():
         getattr(L, name).restype = C.c_uint32
     L.vsom_chunk_size.argtypes = [vp]
     L.vsom_chunk_size.restype = C.c_size_t
+    L.vsom_enable_timing_of.argtypes = [vp, C.c_uint32]
+    L.vsom_small_map_chains.argtypes = [vp, C.c_size_t]
+    L.vsom_small_map_chains.restype = C.c_int
     L.vsom_set_state.argtypes = [vp, fp, fp, fp, fp, u64p]
     L.vsom_get_state.argtypes = [vp, fp, fp, fp, fp, u64p]
     L.vsom_upload_chunk.argtypes = [vp, fp, C.c_size_t]
@@ -100,6 +106,7 @@ def lib():
     L.vsom_prefetch_chunk.argtypes = [vp, fp, C.c_size_t]
     L.vsom_prefetch_wait.argtypes = [vp]
     L.vsom_commit_chunk.argtypes = [vp]
+    L.vsom_stage_next_device.argtypes = [vp, vp, C.c_size_t]
     L.vsom_get_last_bmu.argtypes = [vp, u64p]
     L.vsom_set_last_bmu.argtypes = [vp, u64p]
     L.vsom_get_sqres.argtypes = [vp, fp]
@@ -308,6 +315,11 @@ class Context:
     def commit_chunk(self):
         check(lib().vsom_commit_chunk(self._h))
 
+    def stage_next_device(self, dev_ptr, n_rows):
+        """a next chunk that already lives in HBM: staged beside the running epoch when possible, adopted by
+        commit_chunk (the rows must stay valid until then)"""
+        check(lib().vsom_stage_next_device(self._h, C.c_void_p(int(dev_ptr) or None), int(n_rows)))
+
     def get_last_bmu(self):
         out = np.empty(self.chunk_size, np.uint64)
         check(lib().vsom_get_last_bmu(self._h, _u(out)))
@@ -412,8 +424,16 @@ class Context:
         return np.float32(mse.value)
 
     # ---- measurement ---------------------------------------------------
-    def enable_timing(self, on=True):
-        check(lib().vsom_enable_timing(self._h, int(bool(on))))
+    def enable_timing(self, on=True, groups=None):
+        """HIP-event timing of the kernel groups (TIMER_NAMES); groups = names to time only those (each timed group
+        costs two event records between otherwise back-to-back kernels)"""
+        if groups is None:
+            check(lib().vsom_enable_timing(self._h, int(bool(on))))
+        else:
+            mask = 0
+            for g in groups:
+                mask |= 1 << TIMER_NAMES.index(g)
+            check(lib().vsom_enable_timing_of(self._h, C.c_uint32(mask if on else 0)))
 
     def get_timing(self, reset=True):
         ms = (C.c_float * T_COUNT)()

@@ -12,6 +12,7 @@
 //                      (Som.cpp:777-781).
 //  stage kernels     : chunk re-layout (zero-padded rows; CLR x'/y' expansion).
 #include "vsom_device.hpp"
+#include <utility>
 
 // ------------------------------------------------------------------------------------------
 // chunk staging
@@ -61,28 +62,106 @@ __global__ void stage_pairs_kernel(const float *__restrict__ x, int J, int B, in
     yp[i] = b;
 }
 
+// the staging kernels of a chunk of B rows on `stream`: rows -> Xs (+ lastBMU := 0 in `lastbmu`), CLR pair rows, and with
+// the column compaction its record (idx / inv / meta) and the gathered rows / int8 images
+static int stage_chunk_on(vsom_ctx *c, const float *x_dev, size_t B, hipStream_t stream, u64 *lastbmu, int *idx, int *inv,
+                          unsigned *meta, bool *cc_out, bool *xi_out)
+{
+    *cc_out = false;
+    *xi_out = false;
+    if (B == 0)
+        return VSOM_OK;
+    bool cc = false;
+    if (int rc = vsom_cc_begin(c, B, &cc))      // does this chunk get the column compaction? (buffers, skip counters)
+        return rc;
+    if (cc && !idx) {                            // (buffers allocated by vsom_cc_begin just now)
+        idx = c->cc_idx;
+        inv = c->cc_inv;
+        meta = c->cc_meta;
+    }
+    hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, stream, x_dev, (int)c->J,
+                       (int)B, c->Xs, (int)c->xpitch, lastbmu, cc ? c->cc_flags : (unsigned *)nullptr,
+                       c->sl_scal ? c->sl_scal + 8192 : (unsigned *)nullptr);
+    if (c->transform == VSOM_CLR) {
+        size_t total = B * c->part_pitch;
+        hipLaunchKernelGGL(stage_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           stream, x_dev, (int)c->J, (int)B, (int)c->part_len, c->pair_i,
+                           c->pair_j, c->XP, c->YP, (int)c->part_pitch);
+    }
+    VSOM_HIP_CHECK(hipGetLastError());
+    if (cc) {                                    // live-column record of this chunk (vsom_compact.hip)
+        if (int rc = vsom_cc_stage(c, B, stream, idx, inv, meta, xi_out))
+            return rc;
+        *cc_out = true;
+    }
+    return VSOM_OK;
+}
+
 int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B)
 {
     TimerScope ts(c, VSOM_T_STAGE);
     c->cc_valid = false;
     c->xq_valid = false;
     c->xi_valid = false;
-    if (B == 0)
-        return VSOM_OK;
-    bool cc = false;
-    if (int rc = vsom_cc_begin(c, &cc))      // does this chunk get the column compaction? (buffers, skip counters)
-        return rc;
-    hipLaunchKernelGGL(stage_rows_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, c->stream, x_dev, (int)c->J,
-                       (int)B, c->Xs, (int)c->xpitch, c->lastbmu, cc ? c->cc_flags : (unsigned *)nullptr,
-                       c->sl_scal ? c->sl_scal + 8192 : (unsigned *)nullptr);
-    if (c->transform == VSOM_CLR) {
-        size_t total = B * c->part_pitch;
-        hipLaunchKernelGGL(stage_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                           c->stream, x_dev, (int)c->J, (int)B, (int)c->part_len, c->pair_i,
-                           c->pair_j, c->XP, c->YP, (int)c->part_pitch);
+    c->rows_free_valid = false;
+    if (c->ahead_valid || c->next_dev_pending) {
+        // a chunk staged ahead is overwritten by this one: the rows are staged anew when it is committed
+        VSOM_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
+        c->ahead_valid = false;
     }
-    VSOM_HIP_CHECK(hipGetLastError());
-    return cc ? vsom_cc_stage(c) : VSOM_OK;      // live-column record of this chunk (vsom_compact.hip)
+    bool cc = false, xi = false;
+    int rc = stage_chunk_on(c, x_dev, B, c->stream, c->lastbmu, c->cc_idx, c->cc_inv, c->cc_meta, &cc, &xi);
+    c->cc_valid = cc;
+    c->xi_valid = xi;
+    return rc;
+}
+
+// Can the next chunk be staged NOW, beside whatever the context's stream is running?  Needs: every buffer in place
+// (no allocation: that would synchronise), a transformation whose phase 2 does not read the staged rows (CLR reads its
+// pair rows, the small-map chain kernel the rows themselves), and an epoch enqueued on the current chunk whose
+// rows-are-free event is still the last word on the context (launch_phase2 records it).
+bool vsom_can_stage_ahead(const vsom_ctx *c, size_t B)
+{
+    if (c->transform == VSOM_CLR || !c->rows_free_valid || !c->ev_rows_free || !c->lastbmu_alt || B > c->Bcap)
+        return false;
+    if (vsom_cc_applies(c) && B > 0 && c->cc_min_rows >= 0 && (long)B >= c->cc_min_rows &&
+        (!c->cc_meta_alt || (c->Bcap + VSOM_ROW_PAD) * (size_t)c->cpitch > c->Xc_cap))
+        return false;
+    return true;
+}
+
+int launch_stage_chunk_ahead(vsom_ctx *c, const float *x_dev, size_t B)
+{
+    // after the epoch's last reader of the staged rows (xq_transpose in launch_phase2) -- NOT after its chains
+    VSOM_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_rows_free, 0));
+    bool cc = false, xi = false;
+    int rc = stage_chunk_on(c, x_dev, B, c->copy_stream, c->lastbmu_alt, c->cc_idx_alt, c->cc_inv_alt, c->cc_meta_alt, &cc, &xi);
+    if (rc)
+        return rc;
+    VSOM_HIP_CHECK(hipEventRecord(c->ev_ahead, c->copy_stream));
+    c->ahead_valid = true;
+    c->ahead_B = B;
+    c->ahead_cc = cc;
+    c->ahead_xi = xi;
+    return VSOM_OK;
+}
+
+// vsom_commit_chunk on a chunk staged ahead: the compute stream waits for the staging, the double-buffered pieces swap
+int vsom_adopt_ahead(vsom_ctx *c)
+{
+    VSOM_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
+    std::swap(c->lastbmu, c->lastbmu_alt);
+    std::swap(c->cc_idx, c->cc_idx_alt);
+    std::swap(c->cc_inv, c->cc_inv_alt);
+    std::swap(c->cc_meta, c->cc_meta_alt);
+    c->B = c->ahead_B;
+    c->chunk_loaded = true;
+    c->cc_valid = c->ahead_cc;
+    c->xi_valid = c->ahead_xi;
+    c->xq_valid = false;
+    c->rows_free_valid = false;
+    c->ahead_valid = false;
+    return VSOM_OK;
 }
 
 static DistArgs make_dist_args(const vsom_ctx *c)

@@ -15,7 +15,7 @@ int vsom_fail(int code, const std::string &msg)
     return code;
 }
 
-TimerScope::TimerScope(vsom_ctx *ctx, int w) : c(ctx), which(w), on(ctx->timing)
+TimerScope::TimerScope(vsom_ctx *ctx, int w) : c(ctx), which(w), on((ctx->timing >> w) & 1u)
 {
     if (!on)
         return;
@@ -50,6 +50,7 @@ static inline uint32_t roundup(uint32_t v, uint32_t m) { return (v + m - 1) / m 
             return vsom_fail(VSOM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_e)); \
         if (int _rc = vsom_join_aux(ctx))                              \
             return _rc;                                                \
+        (ctx)->rows_free_valid = false;   /* whatever follows may read the staged rows again */ \
     } while (0)
 // phase 2 runs beside the side stream's work and joins it at its end
 #define CHECK_CTX_NOJOIN(ctx)                                          \
@@ -120,6 +121,8 @@ int vsom_commit_end(vsom_ctx *c)
         return vsom_fail(VSOM_ERR_INVALID, "no prefetched chunk to commit");
     const int k = c->ready_slot;
     c->ready_slot = -1;
+    if (c->ahead_valid)           // staged beside the previous epoch (vsom_prefetch_chunk): nothing left to launch
+        return vsom_adopt_ahead(c);
     int rc = vsom_set_chunk_device(c, c->Xnext[k], c->Bnext);
     if (rc)
         return rc;
@@ -145,7 +148,8 @@ static int free_all(vsom_ctx *c)
     void *ptrs[] = {c->map, c->sigma, c->S, c->weight, c->hits, c->Xs, c->XP, c->YP, c->Xraw,
                     c->lastbmu, c->sqres, c->mse, c->pair_i, c->pair_j, c->partial, c->nan0,
                     c->cw, c->lut, c->lutd, c->sl_G, c->sl_nrm, c->sl_scal, c->sl_list, c->sl_tmin, c->sl_fs, c->sl_fm, c->v_dev, c->res_dev, c->onl_state, c->onl_f,
-                    c->cc_flags, c->cc_idx, c->cc_inv, c->cc_meta, c->Xc, c->Mc, c->Uc_map, c->Uc_S, c->Xq, c->zq, c->sl_xi, c->sl_l1, c->sl_q, c->sl_qscale, c->sl_qcorr};
+                    c->cc_flags, c->cc_idx, c->cc_inv, c->cc_meta, c->Xc, c->Mc, c->Uc_map, c->Uc_S, c->Xq, c->zq, c->sl_xi, c->sl_l1, c->sl_q, c->sl_qscale, c->sl_qcorr,
+                    c->lastbmu_alt, c->cc_idx_alt, c->cc_inv_alt, c->cc_meta_alt};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -186,6 +190,10 @@ static int free_all(vsom_ctx *c)
         if (c->ev_staged[i])
             (void)hipEventDestroy(c->ev_staged[i]);
     }
+    if (c->ev_rows_free)
+        (void)hipEventDestroy(c->ev_rows_free);
+    if (c->ev_ahead)
+        (void)hipEventDestroy(c->ev_ahead);
     if (c->ev_fork)
         (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join)
@@ -247,15 +255,23 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
 
     int rc = VSOM_OK;
     do {
+        // the copy stream also runs the staging kernels of a chunk staged AHEAD, beside the chains of the current one
+        // (vsom_prefetch_chunk): lowest priority, so that the dispatcher hands them the slots the chain kernel leaves
+        // free at its ragged end instead of taking turns with it (at equal priority the chains of a 128x128 map lost
+        // 0.09 ms to 0.05 ms of staging kernels: tools/exp/ab_stage.py)
+        int prio_low = 0, prio_high = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
         if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-            hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, prio_low) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_copied[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_copied[1], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_staged[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_staged[1], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->ev_staged[1], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_rows_free, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_ahead, hipEventDisableTiming) != hipSuccess) {
             rc = vsom_fail(VSOM_ERR_HIP, "hipStreamCreate failed");
             break;
         }
@@ -437,7 +453,9 @@ static int ensure_chunk_capacity(vsom_ctx *c, size_t B)
     if (B <= c->Bcap)
         return VSOM_OK;
     VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    void **ptrs[] = {(void **)&c->Xs, (void **)&c->XP, (void **)&c->YP, (void **)&c->lastbmu,
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+    c->ahead_valid = false;       // (a chunk staged ahead into the old buffers is staged anew at its commit)
+    void **ptrs[] = {(void **)&c->Xs, (void **)&c->XP, (void **)&c->YP, (void **)&c->lastbmu, (void **)&c->lastbmu_alt,
                      (void **)&c->sqres, (void **)&c->nan0, (void **)&c->partial};
     for (void **p : ptrs) {
         if (*p)
@@ -466,6 +484,8 @@ static int ensure_chunk_capacity(vsom_ctx *c, size_t B)
         VSOM_HIP_CHECK(hipMemsetAsync(c->YP, 0, (cap + VSOM_ROW_PAD) * c->part_pitch * 4, c->stream));
     }
     VSOM_HIP_CHECK(hipMalloc(&c->lastbmu, cap * 8));
+    VSOM_HIP_CHECK(hipMalloc(&c->lastbmu_alt, cap * 8));
+    VSOM_HIP_CHECK(hipMemsetAsync(c->lastbmu_alt, 0, cap * 8, c->stream));
     VSOM_HIP_CHECK(hipMalloc(&c->sqres, cap * 4));
     VSOM_HIP_CHECK(hipMalloc(&c->nan0, cap));
     VSOM_HIP_CHECK(hipMemsetAsync(c->lastbmu, 0, cap * 8, c->stream));
@@ -535,9 +555,44 @@ int vsom_host_free(void *p)
     return VSOM_OK;
 }
 
+// what follows the copy of a prefetched chunk (or a chunk that already lives in HBM): its staging kernels on the copy
+// stream, beside the epoch of the current chunk -- when that is possible now (vsom_can_stage_ahead), else at commit
+static int stage_ahead_if_possible(vsom_ctx *c, const float *x_dev, size_t B)
+{
+    c->ahead_valid = false;
+    if (!vsom_can_stage_ahead(c, B))
+        return VSOM_OK;
+    return launch_stage_chunk_ahead(c, x_dev, B);
+}
+
 int vsom_prefetch_chunk(vsom_ctx *c, const float *x_host, size_t B)
 {
-    return vsom_prefetch_rows(c, x_host, B, 0, B);
+    int rc = vsom_prefetch_rows(c, x_host, B, 0, B);
+    if (rc)
+        return rc;
+    c->next_dev_pending = false;
+    const int k = c->ready_slot;
+    if ((rc = stage_ahead_if_possible(c, c->Xnext[k], B)))
+        return rc;
+    if (c->ahead_valid) {         // the slot's raw rows have been read once the ahead staging is through
+        VSOM_HIP_CHECK(hipEventRecord(c->ev_staged[k], c->copy_stream));
+        c->staged_valid[k] = true;
+    }
+    return VSOM_OK;
+}
+
+int vsom_stage_next_device(vsom_ctx *c, const float *x_dev, size_t B)
+{
+    CHECK_CTX_NOJOIN(c);
+    if (B > 0 && !x_dev)
+        return vsom_fail(VSOM_ERR_INVALID, "x_dev is null");
+    if (B > 0x7FFFFFFFull)
+        return vsom_fail(VSOM_ERR_INVALID, "chunk too large");
+    c->ready_slot = -1;           // replaces a prefetched chunk that was never committed
+    c->next_dev = x_dev;
+    c->next_dev_B = B;
+    c->next_dev_pending = true;
+    return stage_ahead_if_possible(c, x_dev, B);
 }
 
 int vsom_prefetch_wait(vsom_ctx *c)
@@ -549,6 +604,13 @@ int vsom_prefetch_wait(vsom_ctx *c)
 
 int vsom_commit_chunk(vsom_ctx *c)
 {
+    if (c && c->next_dev_pending) {       // vsom_stage_next_device: adopt what was staged ahead, or stage it now
+        CHECK_CTX(c);
+        c->next_dev_pending = false;
+        if (c->ahead_valid)
+            return vsom_adopt_ahead(c);
+        return vsom_set_chunk_device(c, c->next_dev, c->next_dev_B);
+    }
     float *raw = nullptr;
     size_t B = 0;
     int rc = vsom_commit_begin(c, &raw, &B);
@@ -809,7 +871,15 @@ int vsom_enable_timing(vsom_ctx *c, int on)
 {
     if (!c)
         return vsom_fail(VSOM_ERR_INVALID, "null context");
-    c->timing = on != 0;
+    c->timing = on ? ~0u : 0u;
+    return VSOM_OK;
+}
+
+int vsom_enable_timing_of(vsom_ctx *c, uint32_t group_mask)
+{
+    if (!c)
+        return vsom_fail(VSOM_ERR_INVALID, "null context");
+    c->timing = group_mask;
     return VSOM_OK;
 }
 

@@ -159,9 +159,13 @@ static int cc_ensure(vsom_ctx *c)
         VSOM_HIP_CHECK(hipMemsetAsync(c->cc_flags, 0, (size_t)c->xpitch * 4, c->stream));
         VSOM_HIP_CHECK(hipMalloc(&c->cc_idx, (size_t)c->cpitch * 4));
         VSOM_HIP_CHECK(hipMalloc(&c->cc_inv, (size_t)c->xpitch * 4));
+        VSOM_HIP_CHECK(hipMalloc(&c->cc_idx_alt, (size_t)c->cpitch * 4));      // the record of a chunk staged ahead
+        VSOM_HIP_CHECK(hipMalloc(&c->cc_inv_alt, (size_t)c->xpitch * 4));
         const size_t meta_bytes = 64;
         VSOM_HIP_CHECK(hipMalloc(&c->cc_meta, meta_bytes));
         VSOM_HIP_CHECK(hipMemsetAsync(c->cc_meta, 0, meta_bytes, c->stream));
+        VSOM_HIP_CHECK(hipMalloc(&c->cc_meta_alt, meta_bytes));
+        VSOM_HIP_CHECK(hipMemsetAsync(c->cc_meta_alt, 0, meta_bytes, c->stream));
         VSOM_HIP_CHECK(hipHostMalloc(&c->cc_fb, 64));
         c->cc_fb[0] = 0u;
         c->cc_fb[1] = 0u;
@@ -183,13 +187,12 @@ static int cc_ensure(vsom_ctx *c)
 }
 
 // before the rows are staged: does this chunk get the compaction?  (then stage_rows_kernel also flags the live columns)
-int vsom_cc_begin(vsom_ctx *c, bool *on)
+int vsom_cc_begin(vsom_ctx *c, size_t B, bool *on)
 {
     *on = false;
-    c->cc_valid = false;
     // small chunks: the passes (and the model-row gather / expansion around them) cost more than a few retired
     // column quads of a short chain save; vsom_set_column_compaction moves the threshold
-    if (!vsom_cc_applies(c) || c->B == 0 || c->cc_min_rows < 0 || (long)c->B < c->cc_min_rows)
+    if (!vsom_cc_applies(c) || B == 0 || c->cc_min_rows < 0 || (long)B < c->cc_min_rows)
         return VSOM_OK;
     // feedback of earlier chunks (pinned memory, read without synchronising: stale values only delay the decision)
     volatile unsigned *fb = c->cc_fb;
@@ -211,16 +214,13 @@ int vsom_cc_begin(vsom_ctx *c, bool *on)
 }
 
 // after the rows are staged (and their live columns flagged): the live-column record, and the chunk gathered onto them
-int vsom_cc_stage(vsom_ctx *c)
+int vsom_cc_stage(vsom_ctx *c, size_t B, hipStream_t stream, int *idx, int *inv, unsigned *meta, bool *xi_out)
 {
-    hipLaunchKernelGGL(cc_scan_kernel, dim3(1), dim3(1024), 0, c->stream, c->cc_flags, (int)c->D, (int)c->cpitch, c->cc_idx,
-                       c->cc_inv, c->cc_meta, c->cc_fb);
+    hipLaunchKernelGGL(cc_scan_kernel, dim3(1), dim3(1024), 0, stream, c->cc_flags, (int)c->D, (int)c->cpitch, idx, inv, meta,
+                       c->cc_fb);
     // the chunk's rows gathered onto the live columns; with the integer shortlist's buffers in place (vsom_sl_i8.hip
     // allocates them at the first search) the same pass writes the chunk's int8 images
-    if (int rc = launch_sl_gather_quant(c))
-        return rc;
-    c->cc_valid = true;
-    return VSOM_OK;
+    return launch_sl_gather_quant(c, B, stream, idx, xi_out);
 }
 
 // the model rows gathered onto the live columns, for the contraction of the shortlist search

@@ -73,6 +73,22 @@ struct vsom_ctx {
     bool staged_valid[2] = {false, false};
     u64 *lastbmu = nullptr;
     float *sqres = nullptr;
+    // The NEXT chunk staged beside the epoch of the current one (vsom_prefetch_chunk / vsom_stage_next_device -> copy
+    // stream; vsom_commit_chunk adopts it).  Once a phase 2 has built its transposed chunk nothing of the epoch reads the
+    // staged rows (Xs, Xc, the int8 images) any more -- `ev_rows_free` -- so the staging kernels of chunk k+1 may
+    // overwrite them while the chains of chunk k run; what phase 2 still reads is double-buffered: lastBMU and the
+    // compaction's column record (the *_alt set is what the ahead staging writes, commit swaps the two).
+    u64 *lastbmu_alt = nullptr;
+    int *cc_idx_alt = nullptr, *cc_inv_alt = nullptr;
+    unsigned *cc_meta_alt = nullptr;
+    hipEvent_t ev_rows_free = nullptr, ev_ahead = nullptr;
+    bool rows_free_valid = false;   // ev_rows_free belongs to the last enqueued work on this context
+    bool ahead_valid = false;       // a chunk is staged ahead (ahead_B rows; its compaction / int8-image state below)
+    size_t ahead_B = 0;
+    bool ahead_cc = false, ahead_xi = false;
+    const float *next_dev = nullptr;   // vsom_stage_next_device: rows in HBM waiting for vsom_commit_chunk
+    size_t next_dev_B = 0;
+    bool next_dev_pending = false;
     float *mse = nullptr;           // [1]
     int *pair_i = nullptr, *pair_j = nullptr;   // CLR pair tables [P]
 
@@ -138,7 +154,7 @@ struct vsom_ctx {
     float *onl_f = nullptr;         // [4]: dist, mse
 
     // timing
-    bool timing = false;
+    uint32_t timing = 0;            // bit (1u << VSOM_T_*): that kernel group is timed with HIP events
     struct Ev { hipEvent_t a, b; int which; };
     std::vector<Ev> ev_live;
     std::vector<Ev> ev_pool;
@@ -164,6 +180,11 @@ struct TimerScope {
 
 // kernel launchers (each enqueues on ctx->stream and returns a vsom_status) -------------------
 int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B);
+// the same kernels for the NEXT chunk on the copy stream, beside the running epoch (false: not possible now --
+// the caller stages at commit time instead)
+bool vsom_can_stage_ahead(const vsom_ctx *c, size_t B);
+int launch_stage_chunk_ahead(vsom_ctx *c, const float *x_dev, size_t B);
+int vsom_adopt_ahead(vsom_ctx *c);
 // pieces of the double-buffered ingest shared with the multi-GPU group (vsom_capi.hip)
 int vsom_prefetch_rows(vsom_ctx *c, const float *x_host, size_t B, size_t r0, size_t r1);
 int vsom_commit_begin(vsom_ctx *c, float **raw, size_t *B);
@@ -182,12 +203,14 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1);
 int ensure_lut(vsom_ctx *c, double sigma);
 // column compaction (vsom_compact.hip)
 bool vsom_cc_applies(const vsom_ctx *c);
-int vsom_cc_begin(vsom_ctx *c, bool *on);
-int vsom_cc_stage(vsom_ctx *c);
+int vsom_cc_begin(vsom_ctx *c, size_t B, bool *on);
+// live-column record + gathered rows (+ int8 images) of a chunk of B rows, on `stream`, into the given record
+int vsom_cc_stage(vsom_ctx *c, size_t B, hipStream_t stream, int *idx, int *inv, unsigned *meta, bool *xi_out);
 int vsom_cc_gather_map(vsom_ctx *c);
 int vsom_cc_ensure_update_scratch(vsom_ctx *c);
 int vsom_cc_expand(vsom_ctx *c, size_t n0, size_t nloc);
-int launch_sl_gather_quant(vsom_ctx *c);                         // vsom_sl_i8.hip: rows onto the live columns (+ int8 images)
+// vsom_sl_i8.hip: rows onto the live columns (+ int8 images)
+int launch_sl_gather_quant(vsom_ctx *c, size_t B, hipStream_t stream, const int *idx, bool *xi_out);
 int vsom_xq_ensure(vsom_ctx *c);                                 // vsom_xq.hip
 bool vsom_tiny_applies(const vsom_ctx *c);                        // vsom_tiny.hip
 int launch_tiny_epoch(vsom_ctx *c, double sigma, int is_first);   // whole batch epoch, one workgroup

@@ -595,16 +595,15 @@ static int sl_i8_ensure(vsom_ctx *c, uint32_t kp8)
 
 // the compaction's gather pass (vsom_compact.hip): the staged rows onto the live columns and -- once the integer
 // shortlist's buffers exist (the first search of a context allocates them) -- their int8 images in the same pass
-int launch_sl_gather_quant(vsom_ctx *c)
+int launch_sl_gather_quant(vsom_ctx *c, size_t B, hipStream_t stream, const int *idx, bool *xi_out)
 {
     const uint32_t kp8 = (c->cpitch + 63) / 64 * 64;
     const bool xi = c->sl_xi && c->sl_kp8 == kp8 && (size_t)c->Bcap * kp8 <= c->sl_xi_cap && c->sl_scal;
-    hipLaunchKernelGGL(sl_quant_rows_kernel, dim3((unsigned)c->B), dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, c->Xc,
-                       (int)c->cpitch, (const int *)c->cc_idx, (int)c->B, xi ? c->sl_xi : (signed char *)nullptr,
-                       (size_t)c->Bcap * kp8, (int)kp8, xi ? c->sl_l1 : (float *)nullptr, (size_t)c->Bcap,
-                       xi ? c->sl_scal + 8192 : (unsigned *)nullptr);
+    hipLaunchKernelGGL(sl_quant_rows_kernel, dim3((unsigned)B), dim3(256), 0, stream, c->Xs, (int)c->xpitch, c->Xc,
+                       (int)c->cpitch, idx, (int)B, xi ? c->sl_xi : (signed char *)nullptr, (size_t)c->Bcap * kp8, (int)kp8,
+                       xi ? c->sl_l1 : (float *)nullptr, (size_t)c->Bcap, xi ? c->sl_scal + 8192 : (unsigned *)nullptr);
     VSOM_HIP_CHECK(hipGetLastError());
-    c->xi_valid = xi;
+    *xi_out = xi;
     return VSOM_OK;
 }
 

@@ -596,6 +596,8 @@ static bool vsom_use_chain(const vsom_ctx *c, size_t nloc)
     return ((nloc + 63) / 64) * ((c->D + 13) / 14) <= VSOM_CHAIN_MAX_WAVES;
 }
 
+extern "C" int vsom_small_map_chains(const vsom_ctx *c, size_t nodes) { return c && vsom_use_chain(c, nodes) ? 1 : 0; }
+
 int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
 {
     if (n1 <= n0)
@@ -712,6 +714,18 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
             // padding and sigma_finalize_kernel re-zeroes it.
             if ((rc = vsom_xq_ensure(c)))
                 return rc;
+            // nothing below reads the staged rows (Xs / Xc / int8 images) of this chunk any more: the next chunk's
+            // staging kernels may overwrite them beside the chains (vsom_prefetch_chunk / vsom_stage_next_device)
+            // -- where that pays: kernels running beside the chain kernel take slots and clock from it, and measured
+            // (tools/exp/ab_stage.py, interleaved A/B, strict, B = 4096 x 784) the step gains 2.7 % / 2.3 % on 48x48 /
+            // 64x64 maps (the chain launch leaves slots idle: 1.3 rounds of the 1024 resident workgroups), nothing
+            // at 80x80 / 96x96 and LOSES 1 % at 112x112 / 128x128 (six full rounds: 0.05 ms of staging kernels cost the
+            // chains 0.09 ms).  So the event is offered only when the chain launch is at most two rounds.
+            const size_t chain_wgs = (size_t)gx * (((c->cc_valid ? c->cpitch / 4 : (c->D + 3) / 4) + 7) / 8);
+            if (chain_wgs <= 2048) {
+                VSOM_HIP_CHECK(hipEventRecord(c->ev_rows_free, c->stream));
+                c->rows_free_valid = true;
+            }
             const bool compact = c->cc_valid;
             if (compact && (rc = vsom_cc_ensure_update_scratch(c)))
                 return rc;
