@@ -12,9 +12,10 @@ kt=$(find $O/b -name '*kernel_trace.csv' | head -1)
 python3 - "$kt" <<'PY' > $O/timeline.txt
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-# the last two steps: from the second-to-last sl_prepare / bmu launch on
+# two steps of the TIMED region (dominant-group events only): the third and fourth timed step
 starts = [i for i, r in enumerate(rows) if "sl_prepare" in r["Kernel_Name"] or "clr_node_feat" in r["Kernel_Name"]]
-i0 = starts[-2] - 6 if len(starts) >= 2 else max(0, len(rows) - 40)
+i0 = starts[4] - 6 if len(starts) >= 8 else max(0, len(rows) - 40)
+rows = rows[:starts[6] + 8] if len(starts) >= 8 else rows
 rows = rows[max(i0, 0):]
 t0 = int(rows[0]["Start_Timestamp"])
 for r in rows:

@@ -221,6 +221,8 @@ def kernel(name, mode):
     E(f"\ts_lshl_b32 {S_TMP}, {S_LDN}, 3")
     E(f"\tv_add_u32_e32 v{V_OC2}, {S_TMP}, v{V_OC}")
     E(f"\ts_lshl_b32 {S_TMP}, {S_WGX}, 10")                    # node group * 64 nodes * 16 B
+    if os.environ.get("VSOM_GEN_NT_CWL2"):                      # development, timing only (WRONG results): every workgroup
+        E(f"\ts_and_b32 {S_TMP}, {S_TMP}, 0x400")                # stages node group 0 / 1's (c, w): 8 MB, L2-resident
     E(f"\ts_add_u32 s{S_CP[0]}, s{S_CP[0]}, {S_TMP}")
     E(f"\ts_addc_u32 s{S_CP[1]}, s{S_CP[1]}, 0")
     E(f"\ts_lshl_b32 {S_CSTEP}, {S_LDN}, 4")                   # 16 pair-rows

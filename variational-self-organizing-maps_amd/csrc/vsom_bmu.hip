@@ -499,18 +499,12 @@ int launch_bmu_full(vsom_ctx *c, size_t s0, size_t s1)
             if (seq != c->sl_seq_seen) {             // the verdict of a shortlist search not looked at yet
                 c->sl_seq_seen = seq;
                 if (rows > 0 && redo * 4u > rows) {
-                    // CLR: a map on which the shortlist does not prune tends to stay that way (C5: after a batch epoch
-                    // on strongly correlated data every node is a candidate for every sample, epoch after epoch), and
-                    // a failed probe costs the contraction AND the exact search (C5: 0.65 + 1.35 ms): pause for 8
-                    // searches, and twice as long after every further failed probe (up to 128).
-                    // Standard / Median: a failed probe costs a tenth of the exact search it falls back to (C3: 0.35 of
-                    // 2.9 ms) and a wrongly skipped one eight times its own cost, and every chunk rebuilds the map from
-                    // zero (Som.cpp:843,870) -- one bad map says little about the next: no pause after a first
-                    // failure, 4 searches after a second in a row, doubling up to 32
-                    if (c->transform == VSOM_CLR)
-                        c->sl_skip = 8 << (c->sl_fail_streak < 4 ? c->sl_fail_streak : 4);
-                    else
-                        c->sl_skip = c->sl_fail_streak == 0 ? 0 : (2 << (c->sl_fail_streak < 4 ? c->sl_fail_streak : 4));
+                    // A failed probe costs a fraction of the exact search it falls back to (Standard C3: 0.35 of
+                    // 2.9 ms; CLR: a collapsed map is recognised on the device before the contraction runs, vsom_shortlist.hip)
+                    // and a wrongly skipped one several times its own cost, and every chunk rebuilds the map from zero
+                    // (Som.cpp:843,870) -- one bad map says little about the next: no pause after a first failure,
+                    // 4 searches after a second in a row, doubling up to 32
+                    c->sl_skip = c->sl_fail_streak == 0 ? 0 : (2 << (c->sl_fail_streak < 4 ? c->sl_fail_streak : 4));
                     ++c->sl_fail_streak;
                 } else {
                     c->sl_fail_streak = 0;

@@ -98,6 +98,7 @@ struct vsom_ctx {
 
     // MFMA shortlist scratch
     float *sl_G = nullptr; size_t sl_cap = 0; float *sl_nrm = nullptr; unsigned *sl_scal = nullptr;
+    float *sl_a2 = nullptr;         // CLR shortlist: per-node max A^2 (the select kernel's per-node bounds)
     int *sl_list = nullptr; size_t sl_list_cap = 0;
     float *sl_tmin = nullptr; size_t sl_tmin_cap = 0;
     unsigned *sl_fb = nullptr;      // pinned host feedback: {redo samples, candidates, rows, seq}

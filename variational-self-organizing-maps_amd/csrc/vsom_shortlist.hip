@@ -108,6 +108,19 @@ __global__ __launch_bounds__(256) void sl_norm_kernel(const float *__restrict__ 
     }
 }
 
+// CLR: a map whose nodes (nearly) coincide -- what batch training leaves when a chunk's samples lie on one line: every
+// node's parameters converge to the same regression -- makes every node a candidate of every sample; the contraction
+// would be wasted, the exact-order kernel searches such a map.  Decided on the device from the spread of the nodes'
+// sum B^2 and max A^2 (clr_node_feat_kernel: scal[0] / [3] the maxima, scal[5] / [7] the inverted minima): the
+// feature, contraction and refinement kernels of that search exit at once and every sample goes to the redo list.
+// (A heuristic about SPEED only: whichever way it decides, indices and distances come from exact-order evaluations.)
+__device__ __forceinline__ bool sl_clr_degenerate(const unsigned *__restrict__ scal)
+{
+    const float nbmax = __uint_as_float(scal[0]), a2max = __uint_as_float(scal[3]);
+    const float nbmin = __uint_as_float(~scal[5]), a2min = __uint_as_float(~scal[7]);
+    return (nbmax - nbmin) <= 1.0e-3f * nbmax && (a2max - a2min) <= 1.0e-3f * a2max;
+}
+
 #define GT 128     // block tile (samples x nodes)
 #define GK 32      // K chunk
 #define GLD 36     // LDS row stride (floats)
@@ -117,8 +130,11 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict
                                                          const float *__restrict__ nrm,
                                                          float *__restrict__ G, int ldg,
                                                          float *__restrict__ tmin, int ntm,
-                                                         const unsigned *__restrict__ kp_dev)
+                                                         const unsigned *__restrict__ kp_dev,
+                                                         const unsigned *__restrict__ clr_scal)
 {
+    if (clr_scal && sl_clr_degenerate(clr_scal))         // CLR on a collapsed map: the exact kernel searches (wave-uniform)
+        return;
     // X / M gathered onto the chunk's live columns (vsom_compact.hip): the contraction length is a device value
     if (kp_dev)
         Kp = (int)kp_dev[2];
@@ -301,9 +317,11 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
                                                         unsigned *__restrict__ stats,
                                                         const float *__restrict__ xraw, int ldxr, int J, float c_e1,
                                                         unsigned cmax, const float *__restrict__ l1x, unsigned lstride,
-                                                        float c_l1, const unsigned *__restrict__ xflag)
+                                                        float c_l1, const unsigned *__restrict__ xflag,
+                                                        const float *__restrict__ nrmn, const float *__restrict__ a2n)
 {
     __shared__ unsigned cand[SL_CMAX];
+    __shared__ float s_um[4];
     __shared__ unsigned s_cnt;
     __shared__ u64 s_best[4];
     __shared__ int s_nan0;
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
         epsmax = __uint_as_float(eb);
         l1mmax = __uint_as_float(lb);
     }
-    bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f) || !(cx <= 3.0e38f);
+    bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f) || !(cx <= 3.0e38f) || (CLR && sl_clr_degenerate(scal));
     // an all-zero map (what the epoch over an EMPTY chunk leaves, Som.cpp:840-875 -- every chunked MnistDataLoader pass
     // ends with one): every distance is the same sum over x in the same order, strict `<` keeps node 0 (Som.cpp:293-304)
     const bool zero_map = scal[SLI_NONZERO] == 0u;
@@ -384,20 +402,57 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     }
     __syncthreads();   // s_cnt = 0 visible
     if (!bad && !zero_map) {
-        float T;
+        const u64 below = (1ull << lane) - 1ull;
         if (CLR) {
-            // "CLR shortlist" below: Q bounds sum_p (A x')^2 + B^2 + y'^2 for every node
-            const float amax2 = __uint_as_float(scal[3]);
-            const float Q = 1.01f * (amax2 * cx + nmax + nx);
-            const float ea = c_g1 * Q;                       // c_g1 = ga
-            float dj = m + nx;
-            dj = dj + ea;
-            dj = dj > 0.f ? dj : 0.f;
-            const float dd = 1.02f * dj + 2.0e-5f * Q;       // covers d_jm and d_i* (derivation below)
-            const float ee = c_e1 * sqrtf(dd * Q) + c_g2 * dd;
-            T = 1.05f * (2.f * ea + 2.f * ee);
-            if (!(Q <= 3.0e38f))
-                bad = true;
+            // "CLR shortlist" below, with every bound PER NODE: the exact-order value of node i (minus the sample's
+            // constant cy) lies in [G_i - w_i, G_i + w_i], w_i = Ea_i + Ee_i from the node's own Q_i = A2max_i cx + nB_i + cy.
+            // The reference argmin i* satisfies G_i* - w_i* <= min_j (G_j + w_j): that set is the shortlist.  (A map-wide
+            // Q -- round 2 -- fails on the maps CLR training really leaves: a tenth of the nodes run away to |A| ~ 1e3..1e11
+            // on correlated data, and ONE such node made every node a candidate of every sample.)
+            auto width = [&](float gi, int i) -> float {
+                const float Q = 1.01f * (a2n[i] * cx + nrmn[i] + nx);
+                const float ea = c_g1 * Q;                   // c_g1 = ga
+                float dj = gi + nx;
+                dj = dj + ea;
+                dj = dj > 0.f ? dj : 0.f;
+                const float dd = 1.02f * dj + 2.0e-5f * Q;   // covers the true squared distance (derivation below)
+                const float ee = c_e1 * sqrtf(dd * Q) + c_g2 * dd;
+                return 1.05f * (ea + ee);
+            };
+            float um = __uint_as_float(0x7F800000u);
+            for (int i = threadIdx.x; i < N; i += 256) {
+                const float gi = g[i];
+                const float u = gi + width(gi, i);
+                um = u < um ? u : um;                        // NaN (a NaN row) never replaces
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const float o = __shfl_xor(um, off);
+                um = o < um ? o : um;
+            }
+            if (lane == 0)
+                s_um[wave] = um;
+            __syncthreads();
+            um = fminf(fminf(s_um[0], s_um[1]), fminf(s_um[2], s_um[3]));
+            if (!(um < 3.0e38f))
+                bad = true;                                  // nothing finite to compare with
+            for (int i0 = wave * 64; i0 < N && !bad; i0 += 256) {
+                const int i = i0 + lane;
+                bool c = false;
+                if (i < N) {
+                    const float gi = g[i];
+                    c = gi - width(gi, i) <= um;
+                }
+                const u64 mask = __ballot(c);
+                if (mask) {
+                    unsigned base = 0;
+                    if (lane == 0)
+                        base = atomicAdd(&s_cnt, (unsigned)__popcll(mask));
+                    base = __shfl(base, 0);
+                    const unsigned slot = base + (unsigned)__popcll(mask & below);
+                    if (c && slot < SL_CMAX)
+                        cand[slot] = (unsigned)i;
+                }
+            }
         } else {
             // T_s = 4*g1*(nMmax+nx) + 2.1*g2*(m + nx + 2*g1*(nMmax+nx)), inflated by 1.05 (header)
             float ea = c_g1 * (nmax + nx);                   // c_g1 = 2*g1 (fp32 chain) / 3.3u (integer contraction)
@@ -409,32 +464,31 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
             float dj = m + nx;
             dj = dj + ea;
             dj = dj > 0.f ? dj : 0.f;
-            T = 1.05f * (2.f * ea + c_g2 * dj);              // c_g2 = 2.1*g2
-        }
-        const float thr = m + T;
-        if (!(thr < 3.0e38f))
-            bad = true;                                      // nothing finite to compare with
-        // collect candidates (order irrelevant: the key min decides).  tmin[t] is the exact minimum of
-        // the non-NaN entries of columns [64t, 64t+64), so only tiles with tmin <= thr can hold a
-        // candidate: one coalesced 256-byte read per such tile; wavefront w takes tiles 64w + 256k + lane
-        const u64 below = (1ull << lane) - 1ull;
-        for (int t0 = wave * 64; t0 < ntm && !bad; t0 += 256) {
-            const int t = t0 + lane;
-            u64 hm = __ballot(t < ntm && tm[t] <= thr);
-            while (hm) {
-                const int tl = __ffsll((long long)hm) - 1;
-                hm &= hm - 1ull;
-                const int i = (t0 + tl) * 64 + lane;
-                const bool c = i < N && g[i] <= thr;
-                const u64 mask = __ballot(c);
-                if (mask) {
-                    unsigned base = 0;
-                    if (lane == 0)
-                        base = atomicAdd(&s_cnt, (unsigned)__popcll(mask));
-                    base = __shfl(base, 0);
-                    const unsigned slot = base + (unsigned)__popcll(mask & below);
-                    if (c && slot < SL_CMAX)
-                        cand[slot] = (unsigned)i;
+            const float T = 1.05f * (2.f * ea + c_g2 * dj);  // c_g2 = 2.1*g2
+            const float thr = m + T;
+            if (!(thr < 3.0e38f))
+                bad = true;                                  // nothing finite to compare with
+            // collect candidates (order irrelevant: the key min decides).  tmin[t] is the exact minimum of
+            // the non-NaN entries of columns [64t, 64t+64), so only tiles with tmin <= thr can hold a
+            // candidate: one coalesced 256-byte read per such tile; wavefront w takes tiles 64w + 256k + lane
+            for (int t0 = wave * 64; t0 < ntm && !bad; t0 += 256) {
+                const int t = t0 + lane;
+                u64 hm = __ballot(t < ntm && tm[t] <= thr);
+                while (hm) {
+                    const int tl = __ffsll((long long)hm) - 1;
+                    hm &= hm - 1ull;
+                    const int i = (t0 + tl) * 64 + lane;
+                    const bool c = i < N && g[i] <= thr;
+                    const u64 mask = __ballot(c);
+                    if (mask) {
+                        unsigned base = 0;
+                        if (lane == 0)
+                            base = atomicAdd(&s_cnt, (unsigned)__popcll(mask));
+                        base = __shfl(base, 0);
+                        const unsigned slot = base + (unsigned)__popcll(mask & below);
+                        if (c && slot < SL_CMAX)
+                            cand[slot] = (unsigned)i;
+                    }
                 }
             }
         }
@@ -590,11 +644,11 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
             return rc;
         hipLaunchKernelGGL(sl_gemm_kernel, grid, dim3(256), 0, c->stream, c->Xc, (int)c->cpitch, (int)s0, (int)s1,
                            c->Mc, (int)c->cpitch, (int)c->N, (int)c->cpitch, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm,
-                           (const unsigned *)c->cc_meta);
+                           (const unsigned *)c->cc_meta, (const unsigned *)nullptr);
     } else
     hipLaunchKernelGGL(sl_gemm_kernel, grid, dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, (int)s0, (int)s1,
                        c->map, (int)c->pitch, (int)c->N, (int)c->xpitch, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm,
-                       (const unsigned *)nullptr);
+                       (const unsigned *)nullptr, (const unsigned *)nullptr);
     }
     DistArgs a;
     a.xa = c->Xs;
@@ -611,7 +665,8 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     hipLaunchKernelGGL(sl_select_kernel<false>, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0,
                        (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(i8 ? 3.3 * u : 2.0 * g1),
                        (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, (const float *)nullptr, 0, 0, 0.f,
-                       (unsigned)SL_CMAX, (const float *)c->sl_l1, (unsigned)c->Bcap, i8 ? 2.0f : 0.f, (const unsigned *)xflag);
+                       (unsigned)SL_CMAX, (const float *)c->sl_l1, (unsigned)c->Bcap, i8 ? 2.0f : 0.f, (const unsigned *)xflag,
+                       (const float *)nullptr, (const float *)nullptr);
     hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(64), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
                        i8 ? (const unsigned *)xflag : (const unsigned *)nullptr, scal_next);
     VSOM_HIP_CHECK(hipGetLastError());
@@ -655,10 +710,11 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
 // phi rows.  One workgroup per sample; Kp = P32 + roundup(3J, 32), P32 = roundup(P, 32).
 __global__ __launch_bounds__(256) void clr_sample_feat_kernel(const float *__restrict__ XP, const float *__restrict__ YP, int ldp,
                                                               int P, const float *__restrict__ Xs, int ldx, int J,
-                                                              float *__restrict__ Fs, int Kp, int P32, int s0, int s1)
+                                                              float *__restrict__ Fs, int Kp, int P32, int s0, int s1,
+                                                              const unsigned *__restrict__ scal)
 {
     const int s = s0 + blockIdx.x;
-    if (s >= s1)
+    if (s >= s1 || sl_clr_degenerate(scal))
         return;
     const float *xp = XP + (size_t)s * ldp, *yp = YP + (size_t)s * ldp, *x = Xs + (size_t)s * ldx;
     float *f = Fs + (size_t)s * Kp;
@@ -677,7 +733,8 @@ __global__ __launch_bounds__(256) void clr_sample_feat_kernel(const float *__res
 // psi rows, nB, and the map-wide maxima.  One workgroup per node.
 __global__ __launch_bounds__(256) void clr_node_feat_kernel(const float *__restrict__ map, int ldm, int ppitch, int P, int J,
                                                             float *__restrict__ Fm, int Kp, int P32, int N,
-                                                            float *__restrict__ nB, unsigned *__restrict__ scal)
+                                                            float *__restrict__ nB, float *__restrict__ a2n,
+                                                            unsigned *__restrict__ scal)
 {
     const int n = blockIdx.x;
     if (n >= N)
@@ -752,11 +809,14 @@ __global__ __launch_bounds__(256) void clr_node_feat_kernel(const float *__restr
         for (int i = 1; i < 4; ++i)
             am = smax[i] > am ? smax[i] : am;
         nB[n] = tot;
+        a2n[n] = am;                                 // the node's own max A^2: the select kernel's bounds are per node
         if (sflag[0] || tot > 3.0e38f)
             atomicOr(&scal[1], 1u);                  // an inf somewhere: the bound does not apply
         else if (!sflag[1]) {                        // NaN rows are legal and excluded from every search
             atomicMax(&scal[0], __float_as_uint(tot));
             atomicMax(&scal[3], __float_as_uint(am));
+            atomicMax(&scal[5], ~__float_as_uint(tot));      // the minima, inverted (the sets are reset to 0)
+            atomicMax(&scal[7], ~__float_as_uint(am));
         }
     }
 }
@@ -801,16 +861,19 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
         VSOM_HIP_CHECK(hipHostMalloc(&c->sl_fb, 64));
         std::memset(c->sl_fb, 0, 64);
     }
+    if (!c->sl_a2)
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_a2, (size_t)c->N * sizeof(float)));
     // scal: [0] max nB bits, [1] non-finite flag, [2] redo count, [3] max A^2 bits, [4] redo samples
     unsigned *scal = c->sl_scal + 4096 * c->sl_par, *scal_next = c->sl_scal + 4096 * (c->sl_par ^ 1);
     c->sl_par ^= 1;
     hipLaunchKernelGGL(clr_node_feat_kernel, dim3((unsigned)c->N), dim3(256), 0, c->stream, c->map, (int)c->pitch,
-                       (int)c->part_pitch, (int)P, (int)J, c->sl_fm, (int)Kp, (int)P32, (int)c->N, c->sl_nrm, scal);
+                       (int)c->part_pitch, (int)P, (int)J, c->sl_fm, (int)Kp, (int)P32, (int)c->N, c->sl_nrm, c->sl_a2, scal);
     hipLaunchKernelGGL(clr_sample_feat_kernel, dim3((unsigned)nrows), dim3(256), 0, c->stream, c->XP, c->YP, (int)c->part_pitch,
-                       (int)P, c->Xs, (int)c->xpitch, (int)J, c->sl_fs, (int)Kp, (int)P32, (int)s0, (int)s1);
+                       (int)P, c->Xs, (int)c->xpitch, (int)J, c->sl_fs, (int)Kp, (int)P32, (int)s0, (int)s1, (const unsigned *)scal);
     dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
     hipLaunchKernelGGL(sl_gemm_kernel, grid, dim3(256), 0, c->stream, c->sl_fs, (int)Kp, (int)s0, (int)s1, c->sl_fm, (int)Kp,
-                       (int)c->N, (int)Kp, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, (const unsigned *)nullptr);
+                       (int)c->N, (int)Kp, c->sl_nrm, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, (const unsigned *)nullptr,
+                       (const unsigned *)scal);
     DistArgs a;
     a.xa = c->XP;
     a.xb = c->YP;
@@ -827,7 +890,7 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
     hipLaunchKernelGGL(sl_select_kernel<true>, dim3((unsigned)nrows), dim3(256), xy_bytes, c->stream, a, (int)s0, (int)s1, (int)c->N,
                        (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(1.0001 * ga), (float)(1.0001 * g2),
                        c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, c->Xs, (int)c->xpitch, (int)J, (float)(1.0001 * e1), 128u,
-                       (const float *)nullptr, 0u, 0.f, (const unsigned *)nullptr);
+                       (const float *)nullptr, 0u, 0.f, (const unsigned *)nullptr, (const float *)c->sl_nrm, (const float *)c->sl_a2);
     hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(64), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
                        (const unsigned *)nullptr, scal_next);
     VSOM_HIP_CHECK(hipGetLastError());
