@@ -34,6 +34,16 @@ CASES = [
     ("local_sigma_03_empty_window", 12, 9, 8, 0, 0, 40, 0.3),
     ("local_sigma_03_empty_window_median", 12, 9, 8, 1, 1, 40, 0.3),
     ("d794", 8, 8, 794, 0, 0, 12, 2.5),
+    # windows of at most a quarter of the map (written for round 5's look-ahead experiment, profiles/EXPERIMENTS.md, and kept
+    # as coverage of bigger maps): chunk sizes that are no multiple of 8, depths with every remainder class of Eigen's
+    # reduction (rem >= 4, < 4, < 8 in all)
+    ("la_std_exp_rem1", 40, 36, 33, 0, 0, 45, 2.0),
+    ("la_std_inv_rem5", 32, 32, 13, 0, 1, 37, 1.8),
+    ("la_median_exp_rem4", 30, 30, 20, 1, 0, 50, 2.5),
+    ("la_median_inv", 36, 28, 16, 1, 1, 41, 2.2),
+    ("la_d794", 48, 48, 794, 0, 0, 21, 3.0),
+    ("la_tiny_d3", 24, 24, 3, 0, 0, 30, 1.5),
+    ("la_d300_one_block", 40, 40, 300, 0, 1, 8, 2.0),
 ]
 
 
@@ -58,6 +68,38 @@ def test_online_chunk(name, W, H, J, tr, fn, B, sigma):
             assert beq(st[k], getattr(o, k)), (name, rep, k)
         assert beq(np.float32(mse_g), np.float32(mse_o)), (name, rep, mse_g, mse_o)
     ctx.close()
+
+
+def test_online_chunk_with_nan_rows_and_duplicates():
+    """The online chunk loop on maps that exercise the search's argmin rules: NaN rows never win, equal rows resolve to the
+    lowest index, a NaN at node 0 pins every BMU to node 0 (Som.cpp:293-304) -- and the window around node 0 then keeps
+    rewriting NaN rows."""
+    W, H, J, B = 36, 30, 24, 43
+    X = gen.blobs(B, J, 5, 1, 2, sigma=0.4)
+    init = gen.random_map(W * H, J, seed=21)
+    init[500:520] = init[100:120]            # duplicates at higher indices
+    init[7, 3] = np.nan
+    init[640:700:9] = np.nan
+    for nan0 in (False, True):
+        m = init.copy()
+        if nan0:
+            m[0, 5] = np.nan
+        o = po.OracleSom(W, H, J)
+        o.set_state(map=m)
+        ctx = vsom_amd.Context(W, H, J)
+        ctx.set_state(map=m)
+        for fn in (capi.EXPONENTIAL, capi.INVERSE_PROPORTIONAL):
+            lb = np.zeros(B, np.uint64)
+            mse_o = o.train_online_chunk(X, lb, 0.05, 2.0, fn)
+            ctx.upload_chunk(X)
+            mse_g = ctx.train_online_chunk(0.05, 2.0, fn)
+            assert beq(ctx.get_last_bmu(), lb), (nan0, fn)
+            assert nan0 == bool((lb == 0).all())
+            st = ctx.get_state()
+            for k in ("map", "S", "sigma", "weight", "hits"):
+                assert beq(st[k], getattr(o, k)), (nan0, fn, k)
+            assert beq(np.float32(mse_g), np.float32(mse_o))
+        ctx.close()
 
 
 @pytest.mark.parametrize("tr,fn,sigma", [(0, 0, 3.0), (1, 1, 2.0), (2, 0, 1.5), (0, 1, 1.0)])

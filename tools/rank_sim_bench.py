@@ -33,22 +33,30 @@ for world in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     ctx.set_update_mode({"strict": 0, "contracted": 1, "sigma": 2}[arith])
     ctx.upload_chunk(X)
     n1 = W * W // world
-    steps = int(os.environ.get("VSOM_SIM_STEPS", "5"))
+    steps = int(os.environ.get("VSOM_SIM_STEPS", "10"))
 
     def step():
         ctx.batch_phase1_async(0, s1, True)
         ctx.batch_finish_async()
         ctx.batch_phase2_async(sigma, 0, n1)
 
+    # `ms_per_step` from a pass that times the chain kernel's group only (every timed group costs two event records between
+    # kernels that otherwise run back to back: ~10 us of idle device each; all seven were 8 % of a rank's 0.9 ms step at
+    # N = 8), the per-group breakdown from a second pass with all of them
     step()
     ctx.synchronize()
-    ctx.enable_timing(True)
+    ctx.enable_timing(True, groups=["update"])
     ctx.get_timing(reset=True)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    ctx.enable_timing(True)
+    ctx.get_timing(reset=True)
+    for _ in range(steps):
+        step()
+    ctx.synchronize()
     tm = ctx.get_timing(reset=True)
     print(json.dumps({"split": split, "arith": arith, "world": world, "B_total": B, "samples_rank": s1, "nodes_rank": n1,
                       "ms_per_step": round(dt * 1e3, 3),
