@@ -35,6 +35,7 @@ def _oracle_bmu(o, X, threads=16):
 CASES = [
     ("mnist_48x48", 48, 48, 784, 384, "mnist"),
     ("d794", 40, 40, 794, 200, "mnist"),
+    ("d1024_fp64_epilogue", 36, 36, 1024, 150, "mnist"),      # > 960 contracted columns: the uint8 kind's fp64 epilogue
     ("blobs_64x64x32", 64, 64, 32, 700, "blobs"),
     ("tiny_dim5", 40, 40, 5, 300, "blobs"),
     ("ragged_33x31x77", 33, 31, 77, 150, "blobs"),

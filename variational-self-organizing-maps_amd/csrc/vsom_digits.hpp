@@ -7,6 +7,7 @@
 // grid: exact in fp32.  Rows too small for the grid (E < -100) keep E = -100; their bound is the magnitude itself.
 #pragma once
 #include "vsom_device.hpp"
+#include <type_traits>
 
 // slots of one counter set `scal` (unsigned words; layout: vsom_shortlist.hip): 32 line-sized slots per quantity
 #define SLI_NMAX(slot) (1024 + 32 * (slot))     // max |M_n|^2 over the finite rows
@@ -43,4 +44,23 @@ __device__ __forceinline__ void sl_digits3(float v, float s1, float is1, int &a,
     a = (int)t;
     b = (int)t2;
     c = (int)t3;
+}
+
+// Minimum over the 32 lanes that share `lane & ~31`, with DPP row operations on the vector pipe (five v_min_f32_dpp);
+// the result is valid in lanes 31 and 63.  Inputs must not be NaN.  (The same reduction with __shfl_xor is five
+// ds_bpermute_b32 round trips through the LDS crossbar, each waited for: 160 of them per wavefront were 40 % of the
+// integer contraction kernel's time -- 257 -> see profiles/EXPERIMENTS.md.)
+__device__ __forceinline__ float sl_min32_dpp(float v)
+{
+    auto step = [](float x, auto ctrl, auto rowmask) {
+        const int b = __float_as_int(x);
+        const int o = __builtin_amdgcn_update_dpp(b, b, decltype(ctrl)::value, decltype(rowmask)::value, 0xF, false);
+        return fminf(x, __int_as_float(o));
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});     // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});     // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});    // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});    // row_mirror: every lane of a row holds the row's minimum
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});    // row_bcast:15 into rows 1 and 3
+    return v;
 }

@@ -107,6 +107,7 @@ struct vsom_ctx {
     // integer contraction of the shortlist (vsom_sl_i8.hip): int8 images of the chunk / the model rows
     signed char *sl_xi = nullptr; size_t sl_xi_cap = 0; float *sl_l1 = nullptr;
     signed char *sl_q = nullptr; double *sl_qscale = nullptr, *sl_qcorr = nullptr;
+    void *sl_qfast = nullptr;       // int4 per node: the constants of the uint8 kind's fp32 epilogue (sl_i8_value_fast)
     uint32_t sl_kp8 = 0;
     bool xi_valid = false;          // sl_xi / sl_l1 describe the staged chunk
     int sl_par = 0;                 // which of the two scal sets the next search uses

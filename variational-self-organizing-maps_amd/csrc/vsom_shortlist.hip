@@ -240,12 +240,8 @@ __global__ __launch_bounds__(256, 2) void sl_gemm_kernel(const float *__restrict
             const float m0 = (col0 < N && g0 == g0) ? g0 : inf;
             const float m1 = (col1 < N && g1 == g1) ? g1 : inf;
             float mn = m1 < m0 ? m1 : m0;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) {   // the 32 lanes that share this row
-                float o = __shfl_xor(mn, off);
-                mn = o < mn ? o : mn;
-            }
-            if (lr == 0 && row < s1)
+            mn = sl_min32_dpp(mn);                     // the 32 lanes that share this row; valid in lanes 31 / 63
+            if (lr == 31 && row < s1)
                 tmin[(size_t)(row - s0) * ntm + blockIdx.x * 2 + wn] = mn;
         }
     }
@@ -455,11 +451,11 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
             }
         } else {
             // T_s = 4*g1*(nMmax+nx) + 2.1*g2*(m + nx + 2*g1*(nMmax+nx)), inflated by 1.05 (header)
-            float ea = c_g1 * (nmax + nx);                   // c_g1 = 2*g1 (fp32 chain) / 3.3u (integer contraction)
+            float ea = c_g1 * (nmax + nx);                   // c_g1 = 2*g1 (fp32 chain) / 5.5u (integer contraction)
             if (c_l1 > 0.f) {
                 const bool gen = xflag[0] != 0u;
                 const float l1e = l1x[(gen ? 2 * (size_t)lstride : 0) + s], es = gen ? l1x[3 * (size_t)lstride + s] : 0.f;
-                ea = ea + 1.001f * c_l1 * (l1e * epsmax + es * l1mmax);
+                ea = ea + 1.001f * c_l1 * (l1e * epsmax + es * l1mmax) + 0.01f * epsmax;   // (+ the fp32 epilogue's second rounding)
             }
             float dj = m + nx;
             dj = dj + ea;
@@ -629,6 +625,8 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     const bool i8 = c->xpitch <= 4096;
     unsigned *xflag = c->sl_scal + 8192;
     dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
+    const double u = 5.9604644775390625e-08;   // 2^-24
+    const double g2 = ((double)c->D / 8.0 + 10.0) * u;
     if (i8) {
         int rc = launch_sl_i8(c, s0, s1, ldg, ntm, scal, xflag);
         if (rc)
@@ -658,12 +656,12 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     a.mb = c->map;
     a.ldm = (int)c->pitch;
     a.L = (int)c->part_len;
-    const double u = 5.9604644775390625e-08;   // 2^-24
     const double K = (double)c->xpitch;
-    const double g1 = ((double)GK + K / GK + 3.0) * u, g2 = ((double)c->D / 8.0 + 10.0) * u;
-    // integer contraction: |G - (|M|^2 - 2<x,M>)| <= 2 |x|_1 eps_max + 3.1u (nMmax + |x|^2)  (vsom_sl_i8.hip)
+    const double g1 = ((double)GK + K / GK + 3.0) * u;
+    // integer contraction: |G - (|M|^2 - 2<x,M>)| <= 2 (e_s L1Mmax + l1eff_s eps_max) + 5.1u (nMmax + |x|^2) + 2^-7 eps_max
+    // (vsom_sl_i8.hip; 3.1u with the fp64 epilogue, 5.1u with the two-rounding fp32 one of the uint8 kind)
     hipLaunchKernelGGL(sl_select_kernel<false>, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0,
-                       (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(i8 ? 3.3 * u : 2.0 * g1),
+                       (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(i8 ? 5.5 * u : 2.0 * g1),
                        (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, (const float *)nullptr, 0, 0, 0.f,
                        (unsigned)SL_CMAX, (const float *)c->sl_l1, (unsigned)c->Bcap, i8 ? 2.0f : 0.f, (const unsigned *)xflag,
                        (const float *)nullptr, (const float *)nullptr);

@@ -20,14 +20,19 @@
 //   |<x,M> - approx| <= |<rho, M>| + |<x^, r>| + dropped
 //                    <= e_s |M_n|_1 + (|x_s|_1 + K e_s) eps_n + t_s s_n 64 (2^-21 + 2^-28) a_s
 //                    <= e_s L1Mmax + l1eff_s eps_max,      l1eff_s := |x_s|_1 + K e_s + 1.01 t_s a_s   (s_n <= 2^15 eps_n)
-//   |G - (|M_n|^2 - 2 <x, M_n>)| <= 2 (e_s L1Mmax + l1eff_s eps_max) + 3.1 u (nMmax + |x|^2)
+//   |G - (|M_n|^2 - 2 <x, M_n>)| <= 2 (e_s L1Mmax + l1eff_s eps_max) + 3.1 u (nMmax + |x|^2)     [fp64 epilogue; the fp32
+//                                   epilogue of the uint8 kind, sl_i8_value_fast: 5.1 u (...) + 2^-7 eps_max]
 // (uint8 kind: e_s = 0, l1eff_s = |x_s|_1 -- round 4's bound) which sl_select_kernel uses in place of the fp32 chain's
 // 2 g1 (nMmax + |x|^2), g1 = (32 + K/32 + 3) u.
 // Samples holding NaN / inf / overflowing values are redone exactly through the |x|^2 test of the select kernel.
 #include "vsom_digits.hpp"
+#include <cstdlib>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+#ifdef VSOM_DEVELOPMENT
+__device__ int vsom_sl_dbg = 0;      // timing experiments (WRONG results): 1 = one K chunk only, 2 = no epilogue, 4 = values only (no stores)
+#endif
 
 // ---- samples: both int8 images, the per-sample bound terms, the chunk's kind -----------------------------------------
 // One workgroup per row.  src = the staged rows; idx = the compaction's live-column list (then dst = the row gathered onto
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
                                                             const int *__restrict__ idx, int kp, const unsigned *__restrict__ kp_dev,
                                                             int kp8, signed char *__restrict__ q, float *__restrict__ nrm,
                                                             double *__restrict__ qscale, double *__restrict__ qcorr,
-                                                            unsigned *__restrict__ scal)
+                                                            int4 *__restrict__ qfast, unsigned *__restrict__ scal)
 {
     const int n = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N)
@@ -212,7 +217,10 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
     if (lane == 0) {
         nrm[n] = nf;
         qscale[n] = (double)s1 * 0x1.0p-14;              // s 2^-14: multiplies 16384 A0 + 128 A1 + A2
-        qcorr[n] = 128.0 * (double)((long long)r1 * 16384 + (long long)r2 * 128 + (long long)r3);   // the (x - 128) offset put back
+        const long long rr = (long long)r1 * 16384 + (long long)r2 * 128 + (long long)r3;
+        qcorr[n] = 128.0 * (double)rr;                   // the (x - 128) offset put back
+        // sl_i8_value_fast: cr = 128 rr = 16384 (rr >> 7) + ((rr & 127) << 7)
+        qfast[n] = make_int4((int)__float_as_uint(2.f * s1), (int)__float_as_uint(s1 * 0x1.0p-13f), (int)(rr >> 7), (int)((rr & 127) << 7));
         const int slot = n & 31;
         if (nf == nf) {
             if (nf > 3.0e38f)
@@ -238,6 +246,23 @@ __device__ __forceinline__ float sl_i8_value(int a0, int a1, int a2, double cr, 
     return (float)(nm - 2.0 * (sc * t));
 }
 
+// The same value for the uint8 kind WITHOUT fp64 (the epilogue was half of the contraction kernel's time: 67 M elements x
+// 3 int -> fp64 conversions, 5 fp64 operations and a conversion back, at a half to a sixteenth of the fp32 rate).
+// T = 16384 a0 + 128 a1 + a2 + cr is an integer below 2^47; with u = 128 a1 + a2 (int32, exact) it is split as
+// T = 16384 A + Bq,  A = a0 + (u >> 14) + (cr >> 14),  Bq = (u & 16383) + (cr & 16383)  -- |A| < 2^24 for K <= 960 contracted
+// columns, 0 <= Bq < 2^15: both exact as fp32 -- and the scale 2 sc = s 2^-13 is a power of two, so
+//   g = fma(-s 2^-13, Bq, fma(-2 s, A, |M|^2))
+// has TWO roundings where the fp64 form has one: |g - exact| <= 2u |G| + 2^-7 eps_n, which the select kernel's bound
+// carries as c_g1 = 5.5u (instead of 3.3u) and a 0.01 eps_max term.  f = {bits of 2 s, bits of s 2^-13, cr >> 14, cr & 16383}.
+__device__ __forceinline__ float sl_i8_value_fast(int a0, int a1, int a2, int4 f, float nm)
+{
+    const int u = (a1 << 7) + a2;
+    const int A = a0 + (u >> 14) + f.z;                  // arithmetic shift: floor
+    const int Bq = (u & 16383) + f.w;
+    const float g1 = fmaf(-__int_as_float(f.x), (float)A, nm);
+    return fmaf(-__int_as_float(f.y), (float)Bq, g1);
+}
+
 // workgroup tile (64 MI) samples x 64 nodes, wavefront tile (32 MI) x 32 (MI MFMA tiles of 32 x 32), K streamed through
 // LDS in chunks of 64 bytes with the next chunk's global loads in flight.  For problems too small to fill the chip with
 // the ring kernel's 256 x 128 tiles.
@@ -250,7 +275,7 @@ __device__ __forceinline__ void sl_gemm_i8_body(const signed char *__restrict__ 
                                                 const float *__restrict__ nrm, const double *__restrict__ qscale,
                                                 const double *__restrict__ qcorr, const float *__restrict__ xscale,
                                                 float *__restrict__ G, int ldg, float *__restrict__ tmin, int ntm,
-                                                signed char *As, signed char *Bs, float *smin)
+                                                signed char *As, signed char *Bs, float *smin, const int4 *__restrict__ qfast)
 {
     const int k64 = (kp + IK - 1) / IK * IK;             // <= kp8; columns past kp hold q = 0
     constexpr int IT_S = 64 * MI;
@@ -326,29 +351,53 @@ __device__ __forceinline__ void sl_gemm_i8_body(const signed char *__restrict__ 
                         acc[pl + l][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pl][i], b[l], acc[pl + l][i], 0, 0, 0);
         }
     }
+    // epilogue in three phases (constants, values, stores: see sl_gemm_i8_ring_body)
     const float inf = __uint_as_float(0x7F800000u);
     const int col = nbase + wn * 32 + lr;
     const bool cok = col < N;
-    const double nm = cok ? (double)nrm[col] : 0.0, sc = cok ? qscale[col] : 0.0, cr = cok && XD == 1 ? qcorr[col] : 0.0;
+    const int cc = cok ? col : N - 1;
+    const bool fast = XD == 1 && qfast != nullptr;       // workgroup-uniform
+    const float nmf = nrm[cc];
+    const double nm = (double)nmf, sc = qscale[cc], cr = XD == 1 ? qcorr[cc] : 0.0;
+    const int4 ff = fast ? qfast[cc] : make_int4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        float rsf[16];
+        if (XD != 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = sbase + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                rsf[r] = xscale[row < s1 ? row : s1 - 1];
+            }
+        }
+        if (fast) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[0][i][r] = __float_as_int(sl_i8_value_fast(acc[0][i][r], acc[1][i][r], acc[2][i][r], ff, nmf));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[0][i][r] = __float_as_int(sl_i8_value(acc[0][i][r], acc[1][i][r], acc[2][i][r], cr,
+                                                          XD == 1 ? sc : sc * (double)rsf[r], nm));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float g = __int_as_float(acc[0][i][r]);
+            // exact minimum of the finite entries of this row over the workgroup's 64 nodes: NaN -> +inf
+            float mn = (cok && g == g) ? g : inf;
+            mn = sl_min32_dpp(mn);                       // the 32 lanes that share this row; valid in lanes 31 / 63
+            if (lr == 31)
+                smin[wn * IT_S + lrow] = mn;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int lrow = wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int row = sbase + lrow;
-            const double rs = XD == 1 ? 1.0 : (double)xscale[row < s1 ? row : s1 - 1];
-            const float g = sl_i8_value(acc[0][i][r], acc[1][i][r], acc[2][i][r], cr, sc * rs, nm);
+            const int row = sbase + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (row < s1 && cok)
-                G[(size_t)(row - s0) * ldg + col] = g;
-            // exact minimum of the finite entries of this row over the workgroup's 64 nodes: NaN -> +inf
-            float mn = (cok && g == g) ? g : inf;
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) {     // the 32 lanes that share this row
-                const float o = __shfl_xor(mn, off);
-                mn = o < mn ? o : mn;
-            }
-            if (lr == 0)
-                smin[wn * IT_S + lrow] = mn;
+                G[(size_t)(row - s0) * ldg + col] = __int_as_float(acc[0][i][r]);
         }
     }
     __syncthreads();
@@ -370,7 +419,7 @@ __global__ __launch_bounds__(256, XD == 1 ? 3 : 2) void sl_gemm_i8_kernel(const 
                                                             const float *__restrict__ nrm, const double *__restrict__ qscale,
                                                             const double *__restrict__ qcorr, const float *__restrict__ xscale,
                                                             float *__restrict__ G, int ldg, float *__restrict__ tmin, int ntm,
-                                                            const unsigned *__restrict__ xflag)
+                                                            const unsigned *__restrict__ xflag, const int4 *__restrict__ qfast)
 {
     if ((xflag[0] != 0u) != (XD == 3))   // wavefront-uniform (a scalar load)
         return;
@@ -379,7 +428,7 @@ __global__ __launch_bounds__(256, XD == 1 ? 3 : 2) void sl_gemm_i8_kernel(const 
     __shared__ __attribute__((aligned(16))) signed char As[XD * 64 * MI * ILD];
     __shared__ __attribute__((aligned(16))) signed char Bs[3 * IT_N * ILD];
     __shared__ float smin[2 * 64 * MI];
-    sl_gemm_i8_body<MI, XD>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, As, Bs, smin);
+    sl_gemm_i8_body<MI, XD>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, As, Bs, smin, qfast);
 }
 
 // ---- the same contraction with big tiles and a ring of LDS stages filled by LDS-DMA ---------------------------------------
@@ -395,25 +444,26 @@ __global__ __launch_bounds__(256, XD == 1 ? 3 : 2) void sl_gemm_i8_kernel(const 
 #define RT_S 256
 #define RT_N 128
 #define RING_BYTES 147456      // max(3 x 40960, 2 x 73728)
-template <int XD>
+template <int XD, int WM, int NS, bool FAST>
 __device__ __forceinline__ void sl_gemm_i8_ring_body(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
                                                      const signed char *__restrict__ q, int N, int kp, int kp8,
                                                      const float *__restrict__ nrm, const double *__restrict__ qscale,
                                                      const double *__restrict__ qcorr, const float *__restrict__ xscale,
                                                      float *__restrict__ G, int ldg, float *__restrict__ tmin, int ntm,
-                                                     signed char *ring)
+                                                     signed char *ring, const int4 *__restrict__ qfast)
 {
-    constexpr int NS = XD == 1 ? 3 : 2;                  // ring depth
-    constexpr int AU = 16 * XD;                          // 1 KB units of the sample planes per stage (16 rows each)
+    // WM = wavefront rows of the tile (64 samples each; 2 wavefront columns of 64 nodes), NS = ring depth
+    constexpr int AUP = 4 * WM;                          // 1 KB units (16 rows each) of ONE sample plane per stage
+    constexpr int AU = AUP * XD;                         // ... of all sample planes
     constexpr int UNITS = AU + 24;                       // + 3 model planes x 8 units
-    constexpr int UPW = UNITS / 8;                       // per wavefront: 5 / 9
-    constexpr int STAGE = UNITS * 1024, QOFF = AU * 1024;
-    static_assert(UNITS % 8 == 0 && NS * STAGE <= RING_BYTES, "ring layout");
+    constexpr int UPW = UNITS / (2 * WM);                // per wavefront: 5 / 9 (WM = 4), 8 (WM = 2, one sample plane)
+    constexpr int STAGE = UNITS * 1024, QOFF = AU * 1024, RTS = 64 * WM;
+    static_assert(UNITS % (2 * WM) == 0 && NS * STAGE <= RING_BYTES, "ring layout");
     const int nchunks = (kp + IK - 1) / IK;             // columns past kp hold q = 0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
-    const int sbase = s0 + blockIdx.y * RT_S, nbase = blockIdx.x * RT_N;
+    const int sbase = s0 + blockIdx.y * RTS, nbase = blockIdx.x * RT_N;
     const size_t plane = (size_t)N * kp8;
     const signed char *xbase = XD == 1 ? xi : xi + xplane;
 
@@ -426,7 +476,7 @@ __device__ __forceinline__ void sl_gemm_i8_ring_body(const signed char *__restri
         const int id = wave * UPW + i;
         const int rin = lane >> 2, slot = lane & 3;
         if (id < AU) {
-            const int pl = id >> 4, row = (id & 15) * 16 + rin;
+            const int pl = id / AUP, row = (id % AUP) * 16 + rin;
             int sr = sbase + row;
             sr = sr < s1 ? sr : s1 - 1;                  // rows past the chunk: re-read the last one (never stored)
             soff[i] = (unsigned)(pl * xplane + (size_t)sr * kp8 + ((slot ^ ((row >> 2) & 3)) << 4));
@@ -465,7 +515,12 @@ __device__ __forceinline__ void sl_gemm_i8_ring_body(const signed char *__restri
     for (int c = 0; c < NS - 1; ++c)
         if (c < nchunks)
             issue(c);
-    for (int c = 0; c < nchunks; ++c) {
+#ifdef VSOM_DEVELOPMENT
+    const int dbg = vsom_sl_dbg;
+#else
+    constexpr int dbg = 0;
+#endif
+    for (int c = 0; c < ((dbg & 1) ? 1 : nchunks); ++c) {
         // my pieces of chunk c have landed (the NS - 2 chunks behind it may still be in flight)
         if (NS == 3 && c + 1 < nchunks)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(UPW) : "memory");
@@ -484,7 +539,7 @@ __device__ __forceinline__ void sl_gemm_i8_ring_body(const signed char *__restri
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int r = wm * 64 + i * 32 + lr;
-                    a[pl][i] = *reinterpret_cast<const v4i *>(st + pl * 16384 + r * 64 + ((P ^ ((r >> 2) & 3)) << 4));
+                    a[pl][i] = *reinterpret_cast<const v4i *>(st + pl * (AUP * 1024) + r * 64 + ((P ^ ((r >> 2) & 3)) << 4));
                 }
 #pragma unroll
             for (int l = 0; l < 3; ++l)
@@ -504,40 +559,78 @@ __device__ __forceinline__ void sl_gemm_i8_ring_body(const signed char *__restri
                             acc[pl + l][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pl][i], b[l][j], acc[pl + l][i][j], 0, 0, 0);
         }
     }
-    // epilogue; a wavefront's 64 columns are exactly one 64-node tile of `tmin`
+    if (dbg & 2)
+        return;
+    // epilogue; a wavefront's 64 columns are exactly one 64-node tile of `tmin`.  Three phases, so that no load is pending
+    // while values are formed and stored: with the constants loaded under `if (col < N)` and a conditional store behind
+    // every value, hipcc put `s_waitcnt vmcnt(0)` in front of EVERY value -- 64 times the latency of the previous store per
+    // wavefront, half of the kernel's time (round 5: 257 -> see profiles/EXPERIMENTS.md).
+    // phase 0: the per-column constants (columns past N: those of the last column, never stored)
     const float inf = __uint_as_float(0x7F800000u);
-    double nm[2], sc[2], cr[2];
     int col[2];
+    double nm[2], sc[2], cr[2];
+    int4 ff[2];
+    float nmf[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         col[j] = nbase + wn * 64 + j * 32 + lr;
-        const bool ok = col[j] < N;
-        nm[j] = ok ? (double)nrm[col[j]] : 0.0;
-        sc[j] = ok ? qscale[col[j]] : 0.0;
-        cr[j] = ok && XD == 1 ? qcorr[col[j]] : 0.0;
+        const int cc = col[j] < N ? col[j] : N - 1;
+        nmf[j] = nrm[cc];
+        if (FAST) {
+            ff[j] = qfast[cc];
+        } else {
+            nm[j] = (double)nmf[j];
+            sc[j] = qscale[cc];
+            cr[j] = XD == 1 ? qcorr[cc] : 0.0;
+        }
     }
+    // phase 1: the values (into the first accumulator set) and the row minima over this wavefront's 64 nodes (into the
+    // second, whose sums have been consumed by then); general kind: the 16 row scales of each half tile loaded together
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float rsf[16];
+        if (XD != 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = sbase + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                rsf[r] = xscale[row < s1 ? row : s1 - 1];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float mn = inf;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float g;
+                if (FAST)
+                    g = sl_i8_value_fast(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], ff[j], nmf[j]);
+                else
+                    g = sl_i8_value(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], cr[j],
+                                    XD == 1 ? sc[j] : sc[j] * (double)rsf[r], nm[j]);
+                acc[0][i][j][r] = __float_as_int(g);
+                const float m = (col[j] < N && g == g) ? g : inf;       // exact minimum of the finite entries: NaN -> +inf
+                mn = m < mn ? m : mn;
+            }
+            acc[1][i][0][r] = __float_as_int(sl_min32_dpp(mn));   // the 32 lanes that share this row; valid in lanes 31 / 63
+        }
+    }
+    if (dbg & 4)
+        return;
+    // phase 2: stores only
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = sbase + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const double rs = XD == 1 ? 1.0 : (double)xscale[row < s1 ? row : s1 - 1];
-            float mn = inf;
+            if (row < s1) {
+                float *grow = G + (size_t)(row - s0) * ldg;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float g = sl_i8_value(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], cr[j], sc[j] * rs, nm[j]);
-                if (row < s1 && col[j] < N)
-                    G[(size_t)(row - s0) * ldg + col[j]] = g;
-                const float m = (col[j] < N && g == g) ? g : inf;       // exact minimum of the finite entries: NaN -> +inf
-                mn = m < mn ? m : mn;
+                for (int j = 0; j < 2; ++j)
+                    if (col[j] < N)
+                        grow[col[j]] = __int_as_float(acc[0][i][j][r]);
+                if (lr == 31)
+                    tmin[(size_t)(row - s0) * ntm + blockIdx.x * 2 + wn] = __int_as_float(acc[1][i][0][r]);
             }
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) {     // the 32 lanes that share this row
-                const float o = __shfl_xor(mn, off);
-                mn = o < mn ? o : mn;
-            }
-            if (lr == 0 && row < s1)
-                tmin[(size_t)(row - s0) * ntm + blockIdx.x * 2 + wn] = mn;
         }
     }
 }
@@ -548,15 +641,18 @@ __global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed ch
                                                                  const float *__restrict__ nrm, const double *__restrict__ qscale,
                                                                  const double *__restrict__ qcorr, const float *__restrict__ xscale,
                                                                  float *__restrict__ G, int ldg, float *__restrict__ tmin, int ntm,
-                                                                 const unsigned *__restrict__ xflag)
+                                                                 const unsigned *__restrict__ xflag,
+                                                                 const int4 *__restrict__ qfast)
 {
     if (kp_dev)
         kp = (int)kp_dev[2];
     extern __shared__ __attribute__((aligned(1024))) signed char ring[];
     if (xflag[0] != 0u)          // wavefront-uniform (a scalar load)
-        sl_gemm_i8_ring_body<3>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring);
+        sl_gemm_i8_ring_body<3, 4, 2, false>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
+    else if (qfast)
+        sl_gemm_i8_ring_body<1, 4, 3, true>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
     else
-        sl_gemm_i8_ring_body<1>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring);
+        sl_gemm_i8_ring_body<1, 4, 3, false>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
 }
 
 // ---- host --------------------------------------------------------------------------------------------------------------
@@ -569,11 +665,13 @@ static int sl_i8_ensure(vsom_ctx *c, uint32_t kp8)
             VSOM_HIP_CHECK(hipFree(c->sl_q));
             VSOM_HIP_CHECK(hipFree(c->sl_qscale));
             VSOM_HIP_CHECK(hipFree(c->sl_qcorr));
+            VSOM_HIP_CHECK(hipFree(c->sl_qfast));
         }
         c->sl_q = nullptr;
         VSOM_HIP_CHECK(hipMalloc(&c->sl_q, (size_t)3 * c->N * kp8));
         VSOM_HIP_CHECK(hipMalloc(&c->sl_qscale, (size_t)c->N * sizeof(double)));
         VSOM_HIP_CHECK(hipMalloc(&c->sl_qcorr, (size_t)c->N * sizeof(double)));
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_qfast, (size_t)c->N * sizeof(int4)));
         c->sl_kp8 = kp8;
         c->xi_valid = false;
         c->sl_xi_cap = 0;
@@ -617,6 +715,17 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
     const uint32_t kp8 = (kmax + 63) / 64 * 64;
     if (int rc = sl_i8_ensure(c, kp8))
         return rc;
+#ifdef VSOM_DEVELOPMENT
+    {
+        static int last = -1;
+        const char *e = std::getenv("VSOM_SL_DBG");
+        const int v = e ? std::atoi(e) : 0;
+        if (v != last) {
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(vsom_sl_dbg), &v, sizeof(int));
+            last = v;
+        }
+    }
+#endif
     const size_t xplane = (size_t)c->Bcap * kp8;
     if (!c->xi_valid) {      // once per staged chunk (the compaction's gather pass does it when the buffers exist)
         hipLaunchKernelGGL(sl_quant_rows_kernel, dim3((unsigned)c->B), dim3(256), 0, c->stream, compact ? c->Xc : c->Xs, (int)kmax,
@@ -628,7 +737,9 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
     const unsigned *kp_dev = compact ? (const unsigned *)c->cc_meta : nullptr;
     hipLaunchKernelGGL(sl_prepare_i8_kernel, dim3((unsigned)((c->N + 3) / 4)), dim3(256), 0, c->stream, c->map, (int)c->pitch,
                        (int)c->part_pitch, (int)c->N, compact ? (const int *)c->cc_idx : (const int *)nullptr, (int)kmax, kp_dev,
-                       (int)kp8, c->sl_q, c->sl_nrm, c->sl_qscale, c->sl_qcorr, scal);
+                       (int)kp8, c->sl_q, c->sl_nrm, c->sl_qscale, c->sl_qcorr, (int4 *)c->sl_qfast, scal);
+    // the fp32 two-fma epilogue of the uint8 kind needs |A| < 2^24: K <= 960 contracted columns (sl_i8_value_fast)
+    const int4 *qfast = kp8 <= 960 ? (const int4 *)c->sl_qfast : (const int4 *)nullptr;
     // big maps and chunks: 256 x 128 tiles through the LDS-DMA ring; otherwise (few tiles: they would not fill the
     // chip) 128 x 64 tiles staged through registers
     const size_t big_tiles = ((size_t)c->N + RT_N - 1) / RT_N * ((s1 - s0 + RT_S - 1) / RT_S);
@@ -644,16 +755,16 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
         dim3 grid((unsigned)(ntm / 2), (unsigned)((s1 - s0 + RT_S - 1) / RT_S));   // ntm = 2 ceil(N / 128) 64-node tiles
         hipLaunchKernelGGL(sl_gemm_i8_ring_kernel, grid, dim3(512), RING_BYTES, c->stream, c->sl_xi, xplane, (int)s0, (int)s1,
                            c->sl_q, (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, xscale, c->sl_G,
-                           (int)ldg, c->sl_tmin, (int)ntm, (const unsigned *)xflag);
+                           (int)ldg, c->sl_tmin, (int)ntm, (const unsigned *)xflag, qfast);
     } else {
         constexpr int MI = 2;
         dim3 grid((unsigned)ntm, (unsigned)((s1 - s0 + 64 * MI - 1) / (64 * MI)));   // ntm 64-node tiles (the last may lie past N: minima +inf)
         hipLaunchKernelGGL((sl_gemm_i8_kernel<MI, 1>), grid, dim3(256), 0, c->stream, c->sl_xi, xplane, (int)s0, (int)s1, c->sl_q,
                            (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, xscale, c->sl_G, (int)ldg,
-                           c->sl_tmin, (int)ntm, (const unsigned *)xflag);
+                           c->sl_tmin, (int)ntm, (const unsigned *)xflag, qfast);
         hipLaunchKernelGGL((sl_gemm_i8_kernel<MI, 3>), grid, dim3(256), 0, c->stream, c->sl_xi, xplane, (int)s0, (int)s1, c->sl_q,
                            (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, xscale, c->sl_G, (int)ldg,
-                           c->sl_tmin, (int)ntm, (const unsigned *)xflag);
+                           c->sl_tmin, (int)ntm, (const unsigned *)xflag, qfast);
     }
     VSOM_HIP_CHECK(hipGetLastError());
     return VSOM_OK;
