@@ -39,6 +39,10 @@ CASES = [
     ("blobs_64x64x32", 64, 64, 32, 700, "blobs"),
     ("tiny_dim5", 40, 40, 5, 300, "blobs"),
     ("ragged_33x31x77", 33, 31, 77, 150, "blobs"),
+    # rows of at most 64 values: the G-less contraction (tile minima only) and its one-wavefront-per-sample refinement
+    ("gless_u8_d48_n1295", 37, 35, 48, 333, "mnist"),
+    ("gless_d64", 40, 40, 64, 500, "blobs"),
+    ("gless_d20_n1023", 33, 31, 20, 150, "blobs"),
 ]
 
 
@@ -428,4 +432,43 @@ def test_general_kind_integer_contraction():
     ctx.bmu_batch()
     st = ctx.shortlist_stats()
     assert st["redo_samples"] == 0 and st["candidates"] < 64 * B, st
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["blobs", "u8"])
+def test_c4_size_short_rows_search_equals_exact_kernel(kind):
+    """BASELINE config 4's search (64x64 map, 32-dim, B = 16384): in the automatic mode rows of at most 64 values go
+    through the G-less integer contraction; every index and distance equals the exact-order kernel's, on the random and on
+    the trained (smooth) map, and a subset is checked against the oracle."""
+    W = H = 64
+    J, B = 32, 16384
+    if kind == "u8":
+        X = gen.mnist_like(B, 5, J)
+        init = (gen.random_map(W * H, J, 42) * np.float32(100) + np.float32(100)).astype(np.float32)
+    else:
+        X = gen.blobs(B, J, 8, 1, 2, sigma=0.5)
+        init = gen.random_map(W * H, J, 42)
+    ctx = vsom_amd.Context(W, H, J, po.MEDIAN)
+    ctx.set_state(map=init)
+    ctx.upload_chunk(X)
+    for rnd in range(2):
+        i_a, d_a = _run(ctx, capi.BMU_AUTO)
+        st = ctx.shortlist_stats()
+        i_e, d_e = _run(ctx, capi.BMU_EXACT)
+        assert beq(i_a, i_e) and beq(d_a, d_e), (kind, rnd)
+        assert st["samples"] == B, st                    # the shortlist path ran
+        # (one Median epoch at sigma = 16 leaves a nearly constant map: on uint8 data most nodes then tie within the
+        # bound and the samples go to the exact kernel -- correct, just not fast)
+        if rnd == 0 or kind == "blobs":
+            assert st["redo_samples"] == 0 and st["candidates"] < 256 * B, (rnd, st)
+        if rnd == 0:
+            ctx.set_bmu_mode(capi.BMU_AUTO)
+            ctx.batch_epoch(16.0, True)
+            ctx.upload_chunk(X)
+    mp = ctx.get_state(sigma=False, S=False, weight=False, hits=False)["map"]
+    o = po.OracleSom(W, H, J, po.MEDIAN)
+    o.set_state(map=mp)
+    rs = np.random.RandomState(1)
+    for s_ in rs.randint(0, B, size=32):
+        assert o.find_bmu(X[s_]) == int(i_a[s_])
     ctx.close()

@@ -12,6 +12,7 @@
 //                      (Som.cpp:777-781).
 //  stage kernels     : chunk re-layout (zero-padded rows; CLR x'/y' expansion).
 #include "vsom_device.hpp"
+#include <algorithm>
 #include <utility>
 
 // ------------------------------------------------------------------------------------------
@@ -29,8 +30,8 @@ __global__ __launch_bounds__(256) void stage_rows_kernel(const float *__restrict
     const int r0 = blockIdx.x * 16, r1 = r0 + 16 < B ? r0 + 16 : B;
     if (threadIdx.x < 16 && r0 + (int)threadIdx.x < B)
         lastbmu[r0 + threadIdx.x] = 0;
-    if (xflag && blockIdx.x == 0 && threadIdx.x == 0)
-        *xflag = 0u;
+    if (xflag && blockIdx.x == 0 && threadIdx.x < 33)
+        xflag[32 * threadIdx.x] = 0u;                    // the word and its 32 write slots (sl_kind_mark, vsom_sl_i8.hip)
     for (int d = threadIdx.x; d < xpitch; d += 256) {
         bool live = false;
         for (int r = r0; r < r1; ++r) {
@@ -197,23 +198,14 @@ static DistArgs make_dist_args(const vsom_ctx *c)
 // TI = 2 -- a 32-sample x 64-node tile, 64 accumulators -- which leaves registers for the next K-chunk's loads
 // in flight while the current one is consumed and lets three workgroups share a CU.
 template <bool CLR, int TI>
-__global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, int s1, int N,
-                                                          u64 *__restrict__ partial, int pstride,
-                                                          unsigned char *__restrict__ nan0,
-                                                          const int *__restrict__ slist,
-                                                          const unsigned *__restrict__ scount,
-                                                          const u64 *__restrict__ hits, u64 min_hits)
+__device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1, int N,
+                                              u64 *__restrict__ partial, int pstride,
+                                              unsigned char *__restrict__ nan0,
+                                              const int *__restrict__ slist,
+                                              const u64 *__restrict__ hits, u64 min_hits, int by)
 {
     constexpr int TS = 16 * TI;                 // samples per tile
     constexpr int NX = TS * 8 / 256;            // float4 of a sample operand per thread and K-chunk (1 or 2)
-    // optional indirection: process only the samples listed by the shortlist path
-    // (vsom_shortlist.hip); s0/s1 then index the list and workgroups beyond its length exit
-    if (scount) {
-        const int cnt = (int)*scount;
-        s1 = s0 + cnt < s1 ? s0 + cnt : s1;
-        if (s0 + (int)blockIdx.y * TS >= s1)
-            return;
-    }
     __shared__ __attribute__((aligned(16))) float sx[TILE * LDT];   // TS rows used (also the key scratch: 64 x 16 u64 max)
     __shared__ __attribute__((aligned(16))) float sm[TILE * LDT];
     __shared__ __attribute__((aligned(16))) float sy[CLR ? TS * LDT : 4];
@@ -221,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
 
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int nbase = blockIdx.x * TILE;
-    const int sbase = s0 + blockIdx.y * TS;
+    const int sbase = s0 + by * TS;
     const int L = a.L, L8 = L & ~7;
     const int nchunks = (L + VSOM_TK - 1) / VSOM_TK;
 
@@ -405,6 +397,33 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
     }
 }
 
+// LIST = false: grid.y = sample tiles.  LIST = true: only the samples the shortlist path lists (slist / scount,
+// vsom_shortlist.hip; s0 / s1 then index the list) with a SMALL grid.y, every workgroup walking on through the list's
+// tiles in steps of grid.y -- the list is usually empty, and a grid sized for the whole chunk costs 7 us of workgroups
+// that start only to leave (16384 of them at C3 / C4).  (Two instantiations: the loop keeps the per-thread offsets
+// alive across the body, 19 spilled registers that the plain search should not pay.)
+template <bool CLR, int TI, bool LIST>
+__global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, int s1, int N,
+                                                          u64 *__restrict__ partial, int pstride,
+                                                          unsigned char *__restrict__ nan0,
+                                                          const int *__restrict__ slist,
+                                                          const unsigned *__restrict__ scount,
+                                                          const u64 *__restrict__ hits, u64 min_hits)
+{
+    constexpr int TS = 16 * TI;
+    if (!LIST) {
+        bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, nullptr, hits, min_hits, (int)blockIdx.y);
+        return;
+    }
+    const int cnt = (int)*scount;
+    s1 = s0 + cnt < s1 ? s0 + cnt : s1;
+    for (int by = blockIdx.y; s0 + by * TS < s1; by += gridDim.y) {
+        if (by != (int)blockIdx.y)
+            __syncthreads();                    // the key scratch of the previous tile has been read
+        bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, slist, hits, min_hits, by);
+    }
+}
+
 __global__ void bmu_reduce_kernel(const u64 *__restrict__ partial, int pstride, int ntiles,
                                   const unsigned char *__restrict__ nan0, int s0, int s1,
                                   u64 *__restrict__ lastbmu, float *__restrict__ sqres,
@@ -450,13 +469,26 @@ int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *s
         c->partial_cap = need;
     }
     DistArgs a = make_dist_args(c);
-    dim3 grid((unsigned)ntn, (unsigned)nts);
-    if (c->transform == VSOM_CLR)
-        hipLaunchKernelGGL((bmu_tile_kernel<true, 2>), grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
-                           (int)c->N, c->partial, (int)c->Bcap, c->nan0, slist, scount, hits, min_hits);
-    else
-        hipLaunchKernelGGL((bmu_tile_kernel<false, 4>), grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1,
-                           (int)c->N, c->partial, (int)c->Bcap, c->nan0, slist, scount, hits, min_hits);
+    // (a redo list is usually empty or short: ~512 workgroups -- the two per CU the kernel's registers allow -- each
+    // walking on through the list's tiles)
+    const bool list = slist != nullptr && scount != nullptr;
+    const int gy = list ? std::min(nts, std::max(1, 512 / ntn)) : nts;
+    dim3 grid((unsigned)ntn, (unsigned)gy);
+#define VSOM_TILE_LAUNCH(K)                                                                                             \
+    hipLaunchKernelGGL(K, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N, c->partial, (int)c->Bcap, c->nan0, \
+                       slist, scount, hits, min_hits)
+    if (c->transform == VSOM_CLR) {
+        if (list)
+            VSOM_TILE_LAUNCH((bmu_tile_kernel<true, 2, true>));
+        else
+            VSOM_TILE_LAUNCH((bmu_tile_kernel<true, 2, false>));
+    } else {
+        if (list)
+            VSOM_TILE_LAUNCH((bmu_tile_kernel<false, 4, true>));
+        else
+            VSOM_TILE_LAUNCH((bmu_tile_kernel<false, 4, false>));
+    }
+#undef VSOM_TILE_LAUNCH
     hipLaunchKernelGGL(bmu_reduce_kernel, dim3((unsigned)((s1 - s0 + 255) / 256)), dim3(256), 0,
                        c->stream, c->partial, (int)c->Bcap, ntn, c->nan0, (int)s0, (int)s1, c->lastbmu,
                        c->sqres, slist, scount);
@@ -488,7 +520,12 @@ int launch_bmu_full(vsom_ctx *c, size_t s0, size_t s1)
     // (CLR: one contraction of length P + 3J over derived features, vsom_shortlist.hip "CLR shortlist")
     const bool can = true;
     bool want = c->bmu_mode == VSOM_BMU_SHORTLIST;
-    if (c->bmu_mode == VSOM_BMU_AUTO && c->N >= 1024 && (s1 - s0) >= 64 && c->D > 64) {
+    // Rows of at most 64 values (Standard / Median): the contraction keeps tile minima only, nothing of size B x N is
+    // written (sl_k64_kernel, vsom_sl_i8.hip) -- it beats the exact kernel once that has ~0.1 ms of work
+    // (C4, 16384 x 4096 x 32: exact 0.21 ms)
+    const bool short_rows = c->transform != VSOM_CLR && c->D <= 64 && c->D >= 16 &&
+                            (double)(s1 - s0) * (double)c->N * (double)c->D >= 1.0e9;
+    if (c->bmu_mode == VSOM_BMU_AUTO && c->N >= 1024 && (s1 - s0) >= 64 && (c->D > 64 || short_rows)) {
         want = true;
         // feedback of the previous shortlist call (pinned host words written by the device, read
         // without synchronising: possibly one call stale): when more than a quarter of the samples

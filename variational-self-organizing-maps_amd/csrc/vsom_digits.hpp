@@ -4,7 +4,9 @@
 // A row with largest finite magnitude mx gets the scale s = 2^E, E = exponent(mx) - 5, so that |v| / s < 64, and
 // every value is written as   v = s (d1 + d2/128 + d3/16384) + r   with integer digits d_l in [-64, 64] and
 // |r| <= s 2^-15.  The residuals between the steps are differences of a value and its rounding to a coarser power-of-two
-// grid: exact in fp32.  Rows too small for the grid (E < -100) keep E = -100; their bound is the magnitude itself.
+// grid: exact in fp32.  Rows too small for the grid (E < -50) keep E = -50; their bound is the magnitude itself.  (With
+// both scales >= 2^-50 the product t_s s_n 2^-13 of a sample's and a model row's scale is a normal fp32 number: the fp32
+// epilogues multiply them, sl_k64_kernel.)
 #pragma once
 #include "vsom_device.hpp"
 #include <type_traits>
@@ -15,17 +17,18 @@
 #define SLI_L1MAX(slot) (3072 + 32 * (slot))    // max |M_n|_1 over the contracted columns
 #define SLI_NONZERO 6                           // some model value is not +-0 (NaN counts)
 
+#define SL_EFLOOR (-50)
 // scale 2^E, its inverse and the residual bound eps of a row whose largest finite magnitude is mx
 __device__ __forceinline__ void sl_row_scale(float mx, float &s1, float &is1, float &eps)
 {
     int e = mx > 0.f ? (int)((__float_as_uint(mx) >> 23) & 0xFF) - 127 : -100;
     e = mx > 0.f && ((__float_as_uint(mx) >> 23) & 0xFF) == 0 ? -126 : e;      // denormal maximum
     int E = e - 5;                                       // mx < 2^(e+1)  ->  mx / 2^E < 64
-    E = E < -100 ? -100 : E;
+    E = E < SL_EFLOOR ? SL_EFLOOR : E;
     s1 = __uint_as_float((unsigned)(E + 127) << 23);
     is1 = __uint_as_float((unsigned)(127 - E) << 23);
     // eps >= s 2^-15 in every case (callers bound s by eps 2^15): a row below the grid is bounded by its magnitude
-    eps = e - 5 < -100 ? fmaxf(mx, 0x1.0p-115f) : s1 * 0x1.0p-15f;
+    eps = e - 5 < SL_EFLOOR ? fmaxf(mx, 0x1.0p-65f) : s1 * 0x1.0p-15f;
 }
 
 // the three digits of v on the grid of scale s1 (non-finite values count as 0: such a row is excluded / redone)

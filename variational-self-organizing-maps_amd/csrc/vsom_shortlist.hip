@@ -544,6 +544,137 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     }
 }
 
+// The refinement of the G-less integer contraction (sl_k64_kernel, vsom_sl_i8.hip: at most 64 contracted columns).
+// One WAVEFRONT per sample: tmin[sample][t] is the minimum of the approximations over tile t = 16 nodes
+// (32 (t >> 1) + 4 (t & 1) + {0..3, 8..11, 16..19, 24..27}); every node of every tile with tmin <= row minimum + T_s
+// (the bound of sl_select_kernel, same terms) is evaluated in the reference's order, 8 lanes per node, node 0 always.
+// More than `tmax` such tiles, or a sample / map the bound does not cover: the redo list.
+__global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1, int N, int D,
+                                                      const float *__restrict__ tmin, int ntl,
+                                                      const unsigned *__restrict__ scal, float c_g1, float c_g2,
+                                                      u64 *__restrict__ lastbmu, float *__restrict__ sqres,
+                                                      unsigned *__restrict__ redo_count, int *__restrict__ redo_list,
+                                                      unsigned *__restrict__ stats, unsigned tmax,
+                                                      const float *__restrict__ l1x, unsigned lstride, float c_l1,
+                                                      const unsigned *__restrict__ xflag, const float *__restrict__ nrm0)
+{
+    // candidate statistics: one global atomic per workgroup (the last of its four wavefronts to arrive sends the sum)
+    __shared__ unsigned s_tot, s_arr;
+    if (threadIdx.x == 0) {
+        s_tot = 0u;
+        s_arr = 0u;
+    }
+    __syncthreads();      // the only barrier: every wavefront passes it before any leaves
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = s0 + blockIdx.x * 4 + wave;
+    auto leave = [&](unsigned cands) {
+        if (lane == 0) {
+            atomicAdd(&s_tot, cands);
+            __threadfence_block();
+            if (atomicAdd(&s_arr, 1u) == 3u) {
+                const unsigned tot = atomicAdd(&s_tot, 0u);
+                if (tot)
+                    atomicAdd(&stats[12 + 32 * (blockIdx.x & 31)], tot);
+            }
+        }
+    };
+    if (s >= s1) {        // wavefront-uniform
+        leave(0u);
+        return;
+    }
+    const float *xr = a.xa + (size_t)s * a.ldx;
+    const float *tm = tmin + (size_t)(s - s0) * ntl;
+    // |x|^2 from the quantisation pass (plane 4 of l1x), the map-wide maxima from sl_k64_kernel (scal[8..10])
+    const float nx = l1x[4 * (size_t)lstride + s];
+    const float nmax = __uint_as_float(scal[8]), epsmax = __uint_as_float(scal[9]), l1mmax = __uint_as_float(scal[10]);
+    bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f);
+    const bool zero_map = scal[SLI_NONZERO] == 0u;       // sl_select_kernel: every node ties, node 0 wins
+    float m = __uint_as_float(0x7F800000u);
+    for (int i = lane; i < ntl; i += 64) {
+        const float v = tm[i];
+        m = v < m ? v : m;
+    }
+    m = sl_min32_dpp(m);                                 // (entries are never NaN: sl_k64_kernel's fminf)
+    m = fminf(__shfl(m, 31), __shfl(m, 63));
+    // T_s as in sl_select_kernel (integer contraction, fp32 epilogue)
+    float ea = c_g1 * (nmax + nx);
+    {
+        const bool gen = xflag[0] != 0u;
+        const float l1e = l1x[(gen ? 2 * (size_t)lstride : 0) + s], es = gen ? l1x[3 * (size_t)lstride + s] : 0.f;
+        ea = ea + 1.001f * c_l1 * (l1e * epsmax + es * l1mmax) + 0.01f * epsmax;
+        if (gen)     // sl_k64_kernel converts u = 128 a1 + a2 (< 2^27) to fp32: off by at most 4, times t_s s_n 2^-13
+            ea = ea + 16.1f * l1x[(size_t)lstride + s] * epsmax;
+    }
+    float dj = m + nx;
+    dj = dj + ea;
+    dj = dj > 0.f ? dj : 0.f;
+    const float T = 1.05f * (2.f * ea + c_g2 * dj);
+    const float thr = m + T;
+    if (!(thr < 3.0e38f))
+        bad = true;
+    const int grp = lane >> 3, k = lane & 7;
+    // Node 0 seeds the reference's search (Som.cpp:293-299): a NaN there pins the BMU to 0.  With a finite sample and no
+    // inf in the map (both checked above) its distance is NaN exactly when its row holds a NaN, i.e. when |M_0|^2 is NaN;
+    // otherwise node 0 is a node like any other and the argmin's tile is always among the candidates (tmin = m <= thr).
+    const float n0 = nrm0[0];
+    const bool nan0 = n0 != n0;
+    u64 best = ~0ull;
+    if (zero_map || nan0) {
+        float d0 = vsom_group_dist_lat<false>(xr, xr, a.ma, a.ma, a.L, k);
+        d0 = __shfl(d0, 0);
+        best = vsom_key(d0, 0u);
+    }
+    unsigned ntiles = 0;
+    if (!bad && !zero_map && !nan0) {
+        for (int t0 = 0; t0 < ntl; t0 += 64) {
+            const int t = t0 + lane;
+            u64 hm = __ballot(t < ntl && tm[t] <= thr);
+            ntiles += (unsigned)__popcll(hm);
+            if (ntiles > tmax) {
+                bad = true;
+                break;
+            }
+            while (hm) {
+                const int tl = t0 + __ffsll((long long)hm) - 1;
+                hm &= hm - 1ull;
+                const int nbase = 32 * (tl >> 1) + 4 * (tl & 1);
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+                    const int j = pass * 8 + grp;
+                    const int node = nbase + (j & 3) + 8 * (j >> 2);
+                    const bool ok = node < N;
+                    const float d = vsom_group_dist_lat<false>(xr, xr, a.ma + (size_t)(ok ? node : 0) * a.ldm, a.ma, a.L, k);
+                    const u64 key = ok ? vsom_key(d, (unsigned)node) : ~0ull;
+                    best = key < best ? key : best;
+                }
+            }
+        }
+    }
+    if (bad) {   // wavefront-uniform
+        if (lane == 0) {
+            const unsigned slot = atomicAdd(redo_count, 1u);
+            redo_list[slot] = s;
+            atomicAdd(&stats[0], 1u);
+        }
+        leave(0u);
+        return;
+    }
+    for (int off = 32; off >= 8; off >>= 1) {
+        const u64 o = __shfl_xor(best, off);
+        best = o < best ? o : best;
+    }
+    leave(16u * ntiles);
+    if (lane == 0) {
+        if (nan0) {
+            lastbmu[s] = 0;
+            sqres[s] = __uint_as_float(0x7FC00000u);
+        } else {
+            lastbmu[s] = best & 0xFFFFFFFFull;
+            sqres[s] = __uint_as_float((uint32_t)(best >> 32));
+        }
+    }
+}
+
 // copies {redo samples, candidates} of this call into the host-visible feedback words
 // ... and clears the counters of the OTHER scal set for the next search (the two sets alternate, so no launch is
 // needed to reset them: nobody touches the other set during this search)
@@ -558,22 +689,24 @@ __global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsi
         scal_next[SLI_EMAX(threadIdx.x)] = 0u;
         scal_next[SLI_L1MAX(threadIdx.x)] = 0u;
     }
+    unsigned cand = threadIdx.x < 32 ? scal[16 + 32 * threadIdx.x] : 0u;      // (one wavefront: 32 loads in flight, not a chain)
+    for (int off = 16; off > 0; off >>= 1)
+        cand += (unsigned)__shfl_xor((int)cand, off);
     if (threadIdx.x != 0)
         return;
-    unsigned cand = 0;
-    for (int sl = 0; sl < 32; ++sl)
-        cand += scal[16 + 32 * sl];
     host_fb[0] = scal[4];
     host_fb[1] = cand;
     host_fb[2] = nrows;
     host_fb[4] = xflag ? xflag[0] : 0u;       // integer contraction asked for on a chunk that is not uint8 data
-    __threadfence_system();
+    // (no fence before the sequence word: the host reads these words without synchronising, as a hint for the pause
+    // policy only -- a torn read costs at most one misjudged search -- and a system-scope fence here waited 2-3 us
+    // for the writes to cross the bus)
     host_fb[3] = host_fb[3] + 1u;
 }
 
 // host side ------------------------------------------------------------------------------------
 int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount);
-int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag);   // vsom_sl_i8.hip
+int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag, bool gless);   // vsom_sl_i8.hip
 
 static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1);
 
@@ -584,8 +717,14 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     if (c->transform == VSOM_CLR)
         return launch_bmu_full_shortlist_clr(c, s0, s1);
     const size_t nrows = s1 - s0;
+    // the contraction in exact integer arithmetic on the int8 matrix pipe (vsom_sl_i8.hip): one digit per sample value
+    // for chunks of small non-negative integers (MNIST pixels), three for any other data -- which of the two is a
+    // device-side fact of the staged chunk (`xflag`) that the kernels read; nothing is decided here
+    const bool i8 = c->xpitch <= 4096;
+    // at most 64 contracted columns: tile minima only, no B x N matrix (sl_k64_kernel + sl_pick_kernel)
+    const bool gless = i8 && ((c->cc_valid ? c->cpitch : c->xpitch) + 63) / 64 == 1;
     const size_t ldg = ((size_t)c->N + 127) / 128 * 128;
-    const size_t need = nrows * ldg;
+    const size_t need = gless ? 0 : nrows * ldg;
     if (need > c->sl_cap) {
         if (c->sl_G)
             VSOM_HIP_CHECK(hipFree(c->sl_G));
@@ -593,7 +732,7 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
         VSOM_HIP_CHECK(hipMalloc(&c->sl_G, need * sizeof(float)));
         c->sl_cap = need;
     }
-    const size_t ntm = (((size_t)c->N + GT - 1) / GT) * 2;
+    const size_t ntm = gless ? (((size_t)c->N + 31) / 32) * 2 : (((size_t)c->N + GT - 1) / GT) * 2;
     if (nrows * ntm > c->sl_tmin_cap) {
         if (c->sl_tmin)
             VSOM_HIP_CHECK(hipFree(c->sl_tmin));
@@ -619,16 +758,12 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     // scal: [0] max nrm bits, [1] non-finite flag, [2] redo count, [4] redo samples, [5] candidates
     unsigned *scal = c->sl_scal + 4096 * c->sl_par, *scal_next = c->sl_scal + 4096 * (c->sl_par ^ 1);
     c->sl_par ^= 1;
-    // the contraction in exact integer arithmetic on the int8 matrix pipe (vsom_sl_i8.hip): one digit per sample value
-    // for chunks of small non-negative integers (MNIST pixels), three for any other data -- which of the two is a
-    // device-side fact of the staged chunk (`xflag`) that the kernels read; nothing is decided here
-    const bool i8 = c->xpitch <= 4096;
     unsigned *xflag = c->sl_scal + 8192;
     dim3 grid((unsigned)((c->N + GT - 1) / GT), (unsigned)((nrows + GT - 1) / GT));
     const double u = 5.9604644775390625e-08;   // 2^-24
     const double g2 = ((double)c->D / 8.0 + 10.0) * u;
     if (i8) {
-        int rc = launch_sl_i8(c, s0, s1, ldg, ntm, scal, xflag);
+        int rc = launch_sl_i8(c, s0, s1, ldg, ntm, scal, xflag, gless);
         if (rc)
             return rc;
     } else {
@@ -660,6 +795,12 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     const double g1 = ((double)GK + K / GK + 3.0) * u;
     // integer contraction: |G - (|M|^2 - 2<x,M>)| <= 2 (e_s L1Mmax + l1eff_s eps_max) + 5.1u (nMmax + |x|^2) + 2^-7 eps_max
     // (vsom_sl_i8.hip; 3.1u with the fp64 epilogue, 5.1u with the two-rounding fp32 one of the uint8 kind)
+    if (gless)
+        hipLaunchKernelGGL(sl_pick_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N,
+                           (int)c->D, c->sl_tmin, (int)ntm, scal, (float)(5.5 * u), (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2,
+                           c->sl_list, scal + 4, 64u, (const float *)c->sl_l1, (unsigned)c->Bcap, 2.0f, (const unsigned *)xflag,
+                           (const float *)c->sl_nrm);
+    else
     hipLaunchKernelGGL(sl_select_kernel<false>, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0,
                        (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(i8 ? 5.5 * u : 2.0 * g1),
                        (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, (const float *)nullptr, 0, 0, 0.f,

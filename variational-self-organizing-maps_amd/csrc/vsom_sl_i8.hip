@@ -34,6 +34,30 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 __device__ int vsom_sl_dbg = 0;      // timing experiments (WRONG results): 1 = one K chunk only, 2 = no epilogue, 4 = values only (no stores)
 #endif
 
+// The chunk's kind word xflag[0] (0: every value an integer in [0, 255]) is written through 32 line-sized slots
+// xflag[32 (1 + k)]: the thousands of wavefronts of a quantisation pass that start together all find the word clear, and
+// that many writes to ONE address queue up at the memory side (4096 atomics 30 us, 4096 plain stores 80 us of a 5 us
+// kernel).  The next search's prepare kernel folds the slots into word 0 and clears them (sl_kind_fold);
+// stage_rows_kernel clears word 0 and the slots for a new chunk.
+__device__ __forceinline__ void sl_kind_mark(unsigned *xflag, unsigned who)
+{
+    unsigned *slot = xflag + 32 * (1 + (who & 31u));
+    if (__atomic_load_n(slot, __ATOMIC_RELAXED) == 0u)
+        __atomic_store_n(slot, 1u, __ATOMIC_RELAXED);
+}
+// first wavefront of ONE workgroup of a kernel that runs after the quantisation and before the word's first reader
+__device__ __forceinline__ void sl_kind_fold(unsigned *xflag)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned v = lane < 32 ? xflag[32 * (1 + lane)] : 0u;
+    if (__ballot(v != 0u)) {
+        if (lane < 32 && v != 0u)
+            xflag[32 * (1 + lane)] = 0u;
+        if (lane == 0)
+            xflag[0] = 1u;
+    }
+}
+
 // ---- samples: both int8 images, the per-sample bound terms, the chunk's kind -----------------------------------------
 // One workgroup per row.  src = the staged rows; idx = the compaction's live-column list (then dst = the row gathered onto
 // them, vsom_compact.hip) or null (identity: the padded row itself).  Planes of xi: [0] x - 128 (uint8 kind), [1..3] the
@@ -92,8 +116,8 @@ __global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restr
         mx = o > mx ? o : mx;
     }
     // (one atomic per chunk, not per wavefront: 16384 same-address atomics take 0.13 ms; a stale read only repeats it)
-    if (__ballot(bad) && lane == 0 && __atomic_load_n(xflag, __ATOMIC_RELAXED) == 0u)
-        atomicOr(xflag, 1u);
+    if (__ballot(bad) && lane == 0)
+        sl_kind_mark(xflag, blockIdx.x);
     if (lane == 0) {
         ssum[wave] = sum;
         smax[wave] = mx;
@@ -137,6 +161,86 @@ __global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restr
     }
 }
 
+// The same for rows of at most 64 columns (kp8 == 64): 16 lanes per row, four columns each, no LDS, no barrier (a
+// workgroup per row spends its time in the two barriers: 50 us for C4's 16384 rows of 32 values against 5 here).
+__global__ __launch_bounds__(256) void sl_quant_rows64_kernel(const float *__restrict__ src, int lds_, float *__restrict__ dst,
+                                                              int ldd, const int *__restrict__ idx, int nrows,
+                                                              signed char *__restrict__ xi, size_t xplane,
+                                                              float *__restrict__ lx, size_t lstride, unsigned *__restrict__ xflag)
+{
+    const int row = blockIdx.x * 16 + ((int)threadIdx.x >> 4), k4 = ((int)threadIdx.x & 15) * 4;
+    if (row >= nrows)
+        return;   // whole 16-lane groups leave; the exchanges below stay inside a group
+    const float *s = src + (size_t)row * lds_;
+    float vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = k4 + u;
+        const int c = k < ldd ? (idx ? idx[k] : k) : -1;
+        vv[u] = c >= 0 ? s[c] : 0.f;
+    }
+    if (dst && k4 < ldd)
+        *reinterpret_cast<float4 *>(dst + (size_t)row * ldd + k4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (!xi)
+        return;
+    float sum = 0.f, mx = 0.f, l1f = 0.f;
+    bool bad = false;
+    char4 q;
+    signed char *qq = reinterpret_cast<signed char *>(&q);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float f = vv[u];
+        const bool ok = f >= 0.f && f <= 255.f && f == rintf(f);
+        bad |= !ok;
+        const int iv = ok ? (int)f : 0;
+        sum += (float)iv;
+        qq[u] = (signed char)(iv - 128);
+        const float af = fabsf(f);
+        const bool fin = af <= 3.0e38f;
+        mx = (fin && af > mx) ? af : mx;
+        l1f += fin ? af : 0.f;
+    }
+    *reinterpret_cast<char4 *>(xi + (size_t)row * 64 + k4) = q;
+    float nx2 = (vv[0] * vv[0] + vv[1] * vv[1]) + (vv[2] * vv[2] + vv[3] * vv[3]);
+    for (int off = 8; off > 0; off >>= 1) {
+        nx2 += __shfl_xor(nx2, off);
+        sum += __shfl_xor(sum, off);
+        l1f += __shfl_xor(l1f, off);
+        const float o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0)
+        sl_kind_mark(xflag, blockIdx.x);
+    float t1, it1, es;
+    sl_row_scale(mx, t1, it1, es);
+    char4 o1, o2, o3;
+    signed char *p1 = reinterpret_cast<signed char *>(&o1), *p2 = reinterpret_cast<signed char *>(&o2),
+                *p3 = reinterpret_cast<signed char *>(&o3);
+    int asum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int a, b, c3;
+        sl_digits3(vv[u], t1, it1, a, b, c3);
+        p1[u] = (signed char)a;
+        p2[u] = (signed char)b;
+        p3[u] = (signed char)c3;
+        asum += (b < 0 ? -b : b) + (c3 < 0 ? -c3 : c3);
+    }
+    signed char *o = xi + xplane + (size_t)row * 64 + k4;
+    *reinterpret_cast<char4 *>(o) = o1;
+    *reinterpret_cast<char4 *>(o + xplane) = o2;
+    *reinterpret_cast<char4 *>(o + 2 * xplane) = o3;
+    for (int off = 8; off > 0; off >>= 1)
+        asum += __shfl_xor(asum, off);
+    if ((threadIdx.x & 15) == 0) {
+        lx[row] = sum;
+        lx[lstride + row] = t1;
+        lx[2 * lstride + row] = (l1f * 1.001f + 64.f * es + 1.01f * t1 * (float)asum) * 1.001f;
+        lx[3 * lstride + row] = es;
+        lx[4 * lstride + row] = nx2;                     // |x|^2 (any order: it only enters bounds), NaN / inf if x has one
+    }
+}
+
 // ---- model rows: |M|^2 (fp64 sum), live columns gathered, three 7-bit digits, row sums -------------------------------
 // one WAVEFRONT per node (4 per workgroup), no LDS, no barriers.  idx = live-column list of the compaction (null:
 // identity), kp = contraction length (device value kp_dev[2] when compacted).  q planes: [3][N][kp8].
@@ -144,9 +248,12 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
                                                             const int *__restrict__ idx, int kp, const unsigned *__restrict__ kp_dev,
                                                             int kp8, signed char *__restrict__ q, float *__restrict__ nrm,
                                                             double *__restrict__ qscale, double *__restrict__ qcorr,
-                                                            int4 *__restrict__ qfast, unsigned *__restrict__ scal)
+                                                            int4 *__restrict__ qfast, unsigned *__restrict__ scal,
+                                                            unsigned *__restrict__ xflag)
 {
     const int n = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+        sl_kind_fold(xflag);
     if (n >= N)
         return;
     if (kp_dev)
@@ -230,6 +337,106 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
         }
         atomicMax(&scal[SLI_EMAX(slot)], __float_as_uint(eps));
         atomicMax(&scal[SLI_L1MAX(slot)], __float_as_uint(l1 * 1.001f));     // fp32 sum of <= 4096 magnitudes, rounded up
+    }
+}
+
+// The same for rows of at most 64 columns (kp8 == 64, Dp <= 64): 16 lanes per node, one atomic set per wavefront
+__global__ __launch_bounds__(256) void sl_prepare64_kernel(const float *__restrict__ map, int ldm, int Dp, int N,
+                                                           const int *__restrict__ idx, int kp, const unsigned *__restrict__ kp_dev,
+                                                           signed char *__restrict__ q, float *__restrict__ nrm,
+                                                           double *__restrict__ qscale, double *__restrict__ qcorr,
+                                                           int4 *__restrict__ qfast, unsigned *__restrict__ scal,
+                                                           unsigned *__restrict__ xflag)
+{
+    const int n0 = blockIdx.x * 16 + ((int)threadIdx.x >> 4), k4 = ((int)threadIdx.x & 15) * 4;
+    if (blockIdx.x == 0 && threadIdx.x < 64)
+        sl_kind_fold(xflag);
+    const bool ok = n0 < N;
+    const int n = ok ? n0 : N - 1;                       // (no early exit: the wavefront's maxima are exchanged below)
+    if (kp_dev)
+        kp = (int)kp_dev[2];
+    const float *src = map + (size_t)n * ldm;
+    double ss = 0.0;
+    bool nz = false;
+    if (k4 < Dp) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + k4);
+        ss = (double)v.x * (double)v.x + (double)v.y * (double)v.y;
+        ss += (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+        nz = !(v.x == 0.f) || !(v.y == 0.f) || !(v.z == 0.f) || !(v.w == 0.f);
+    }
+    float vv[4], mx = 0.f, l1 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = k4 + u;
+        const int c = k < kp ? (idx ? idx[k] : k) : -1;
+        vv[u] = c >= 0 && c < Dp ? src[c] : 0.f;
+        const float v = fabsf(vv[u]);
+        const bool fin = v <= 3.0e38f;
+        mx = (fin && v > mx) ? v : mx;
+        l1 += fin ? v : 0.f;
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+        ss += __shfl_xor(ss, off);
+        const float o = __shfl_xor(mx, off);
+        mx = o > mx ? o : mx;
+        l1 += __shfl_xor(l1, off);
+    }
+    const float nf = (float)ss;
+    float s1, is1, eps;
+    sl_row_scale(mx, s1, is1, eps);
+    int r1 = 0, r2 = 0, r3 = 0;
+    char4 o1, o2, o3;
+    signed char *p1 = reinterpret_cast<signed char *>(&o1), *p2 = reinterpret_cast<signed char *>(&o2),
+                *p3 = reinterpret_cast<signed char *>(&o3);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int a, b, c3;
+        sl_digits3(vv[u], s1, is1, a, b, c3);            // columns past kp: 0 -> digits 0
+        p1[u] = (signed char)a;
+        p2[u] = (signed char)b;
+        p3[u] = (signed char)c3;
+        r1 += a;
+        r2 += b;
+        r3 += c3;
+    }
+    const size_t plane = (size_t)N * 64;
+    if (ok) {
+        signed char *q1 = q + (size_t)n * 64 + k4;
+        *reinterpret_cast<char4 *>(q1) = o1;
+        *reinterpret_cast<char4 *>(q1 + plane) = o2;
+        *reinterpret_cast<char4 *>(q1 + 2 * plane) = o3;
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+        r1 += __shfl_xor(r1, off);
+        r2 += __shfl_xor(r2, off);
+        r3 += __shfl_xor(r3, off);
+    }
+    if (ok && (threadIdx.x & 15) == 0) {
+        nrm[n] = nf;
+        qscale[n] = (double)s1 * 0x1.0p-14;
+        const long long rr = (long long)r1 * 16384 + (long long)r2 * 128 + (long long)r3;
+        qcorr[n] = 128.0 * (double)rr;
+        qfast[n] = make_int4((int)__float_as_uint(2.f * s1), (int)__float_as_uint(s1 * 0x1.0p-13f), (int)(rr >> 7), (int)((rr & 127) << 7));
+    }
+    // the wavefront's four nodes: one atomic per quantity (rows past N repeat node N - 1)
+    unsigned nb = (nf == nf && nf <= 3.0e38f) ? __float_as_uint(nf) : 0u, eb = __float_as_uint(eps), lb = __float_as_uint(l1 * 1.001f);
+    const bool isinf = nf == nf && nf > 3.0e38f;
+    for (int off = 16; off <= 32; off <<= 1) {
+        const unsigned a1 = (unsigned)__shfl_xor((int)nb, off), a2 = (unsigned)__shfl_xor((int)eb, off), a3 = (unsigned)__shfl_xor((int)lb, off);
+        nb = a1 > nb ? a1 : nb;
+        eb = a2 > eb ? a2 : eb;
+        lb = a3 > lb ? a3 : lb;
+    }
+    const bool anynz = __ballot(nz) != 0ull, anyinf = __ballot(isinf) != 0ull;
+    if ((threadIdx.x & 63) == 0) {
+        const int slot = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) & 31;
+        if (anynz && scal[SLI_NONZERO] == 0u)
+            atomicOr(&scal[SLI_NONZERO], 1u);
+        if (anyinf)
+            atomicOr(&scal[1], 1u);
+        atomicMax(&scal[SLI_NMAX(slot)], nb);
+        atomicMax(&scal[SLI_EMAX(slot)], eb);
+        atomicMax(&scal[SLI_L1MAX(slot)], lb);
     }
 }
 
@@ -655,6 +862,134 @@ __global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed ch
         sl_gemm_i8_ring_body<1, 4, 3, false>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
 }
 
+// ---- at most 64 contracted columns: no G at all ----------------------------------------------------------------------------
+// With K <= 64 a (sample, node) value costs two MFMAs per digit product and NO K loop: writing the B x N matrix G and
+// reading it back in the refinement would be all of the time (C4, 16384 x 4096: 268 MB each way against 0.6 MB of
+// operands).  Here the operands go from global memory straight into the MFMA registers (rows of the int8 planes are 64
+// bytes: the 16-byte fragment of lane (row lr, k half lh) is one load), the tile is evaluated TRANSPOSED -- nodes along
+// the accumulator registers, samples along the lanes -- so that the minimum over a lane's 16 registers is the minimum of
+// one sample over 16 nodes without any cross-lane step, and only those minima are written: tmin[sample][tile], tile
+// t = 2 (node block of 32) + (lane >> 5) = the nodes 32 (t >> 1) + 4 (t & 1) + {0..3, 8..11, 16..19, 24..27}.  The
+// refinement (sl_pick_kernel, vsom_shortlist.hip) evaluates every node of every tile whose minimum is within the bound of the
+// row minimum in the reference's order.  Both kinds evaluate the value in fp32: the uint8 kind as sl_i8_value_fast, the
+// general kind as |M|^2 - t_s (2 s_n w) with w = (16384 a0 + 128 a1 + a2) / 16384 -- the scales are powers of two >= 2^-50
+// each (vsom_digits.hpp), so the products with them are exact.
+#define K64_NB 16         // node blocks of 32 per workgroup (its 256 threads stage the constants of these 512 nodes)
+template <int XD>
+__device__ __forceinline__ void sl_k64_body(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
+                                            const signed char *__restrict__ q, int N, const float *__restrict__ xscale,
+                                            float *__restrict__ tmin, int ntl, const float *s_nrm, const int4 *s_f)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nbase = blockIdx.x * (K64_NB * 32);
+    const int srow = s0 + blockIdx.y * 128 + wave * 32 + lr;
+    const bool sok = srow < s1;
+    const size_t sr = (size_t)(sok ? srow : s1 - 1);
+    const size_t plane = (size_t)N * 64;
+    const signed char *xbase = (XD == 1 ? xi : xi + xplane) + sr * 64 + 16 * lh;
+    v4i a[XD][2];
+#pragma unroll
+    for (int pl = 0; pl < XD; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            a[pl][ks] = *reinterpret_cast<const v4i *>(xbase + pl * xplane + ks * 32);
+    const float ts = XD == 3 ? xscale[sr] : 1.f;
+    float *out = tmin + (size_t)(srow - s0) * ntl + (nbase >> 4) + lh;
+    const int nbn = (N - nbase + 31) / 32 < K64_NB ? (N - nbase + 31) / 32 : K64_NB;      // node blocks of this workgroup
+    v4i b[3][2], bn[3][2];
+    auto bload = [&](int nb, v4i (&dst)[3][2]) {         // the model fragments of block nb (clamped: always valid rows)
+        int n = nbase + nb * 32 + lr;
+        n = n < N ? n : N - 1;
+        const signed char *qb = q + (size_t)n * 64 + 16 * lh;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                dst[l][ks] = *reinterpret_cast<const v4i *>(qb + l * plane + ks * 32);
+    };
+    bload(0, b);
+    for (int nb = 0; nb < nbn; ++nb) {
+        bload(nb + 1 < nbn ? nb + 1 : nb, bn);           // the next block's fragments stay in flight behind this block's work
+        v16i acc[3];
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[l][r] = 0;
+#pragma unroll
+        for (int pl = 0; pl < XD; ++pl)
+#pragma unroll
+            for (int l = 0; l + pl < 3; ++l)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)      // first operand = rows of the result = nodes
+                    acc[pl + l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][ks], a[pl][ks], acc[pl + l], 0, 0, 0);
+        float mn = __uint_as_float(0x7F800000u);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int nl = nb * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+            const float nm = s_nrm[nl];                  // nodes past N: +inf (f = 0): never a minimum
+            float g;
+            if (XD == 1) {
+                g = sl_i8_value_fast(acc[0][r], acc[1][r], acc[2][r], s_f[nl], nm);
+            } else {
+                // T = 16384 a0 + u, u = 128 a1 + a2 (|u| < 2^27: its conversion is off by at most 4, which the
+                // refinement's bound carries as 16 t_s eps_n); w = T / 16384 and the scales are powers of two:
+                // g = |M|^2 - t_s (2 s_n w), three roundings (conversion, w, g)
+                const int u = (acc[1][r] << 7) + acc[2][r];
+                const float w = fmaf((float)u, 0x1.0p-14f, (float)acc[0][r]);
+                g = fmaf(-ts, __int_as_float(s_f[nl].x) * w, nm);
+            }
+            mn = fminf(mn, g);                           // a NaN (a NaN row of the map) never replaces the minimum
+        }
+        if (sok)
+            out[2 * nb] = mn;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                b[l][ks] = bn[l][ks];
+    }
+}
+
+// scal: the counter set of this search; its words 8..10 receive the maxima of |M|^2, eps and |M|_1 over the 32 slots the
+// prepare kernel filled (the refinement reads three words instead of reducing 96 per sample).
+__global__ __launch_bounds__(256, 3) void sl_k64_kernel(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
+                                                        const signed char *__restrict__ q, int N,
+                                                        const float *__restrict__ nrm, const int4 *__restrict__ qfast,
+                                                        const float *__restrict__ xscale, float *__restrict__ tmin, int ntl,
+                                                        const unsigned *__restrict__ xflag, unsigned *__restrict__ scal)
+{
+    __shared__ float s_nrm[K64_NB * 32];
+    __shared__ int4 s_f[K64_NB * 32];
+    for (int i = threadIdx.x; i < K64_NB * 32; i += 256) {
+        const int n = blockIdx.x * (K64_NB * 32) + i;
+        s_nrm[i] = n < N ? nrm[n] : __uint_as_float(0x7F800000u);
+        s_f[i] = n < N ? qfast[n] : make_int4(0, 0, 0, 0);
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        unsigned nb = scal[SLI_NMAX(lane & 31)], eb = scal[SLI_EMAX(lane & 31)], lb = scal[SLI_L1MAX(lane & 31)];
+        for (int off = 16; off > 0; off >>= 1) {
+            const unsigned o1 = (unsigned)__shfl_xor((int)nb, off), o2 = (unsigned)__shfl_xor((int)eb, off),
+                           o3 = (unsigned)__shfl_xor((int)lb, off);
+            nb = o1 > nb ? o1 : nb;
+            eb = o2 > eb ? o2 : eb;
+            lb = o3 > lb ? o3 : lb;
+        }
+        if (lane == 0) {
+            scal[8] = nb;
+            scal[9] = eb;
+            scal[10] = lb;
+        }
+    }
+    __syncthreads();
+    if (xflag[0] != 0u)                                  // workgroup-uniform (a scalar load)
+        sl_k64_body<3>(xi, xplane, s0, s1, q, N, xscale, tmin, ntl, s_nrm, s_f);
+    else
+        sl_k64_body<1>(xi, xplane, s0, s1, q, N, xscale, tmin, ntl, s_nrm, s_f);
+}
+
 // ---- host --------------------------------------------------------------------------------------------------------------
 // buffers of the int8 images: model planes for N rows, sample planes for Bcap rows of kp8 bytes
 static int sl_i8_ensure(vsom_ctx *c, uint32_t kp8)
@@ -684,7 +1019,7 @@ static int sl_i8_ensure(vsom_ctx *c, uint32_t kp8)
         }
         c->sl_xi = nullptr;
         VSOM_HIP_CHECK(hipMalloc(&c->sl_xi, (size_t)4 * c->Bcap * kp8));             // [0] x - 128, [1..3] digits
-        VSOM_HIP_CHECK(hipMalloc(&c->sl_l1, (size_t)4 * c->Bcap * sizeof(float)));   // |x|_1, t_s, l1eff_s, e_s
+        VSOM_HIP_CHECK(hipMalloc(&c->sl_l1, (size_t)5 * c->Bcap * sizeof(float)));   // |x|_1, t_s, l1eff_s, e_s, |x|^2 (rows of <= 64 values)
         c->sl_xi_cap = (size_t)c->Bcap * kp8;
         c->xi_valid = false;
     }
@@ -697,6 +1032,11 @@ int launch_sl_gather_quant(vsom_ctx *c, size_t B, hipStream_t stream, const int 
 {
     const uint32_t kp8 = (c->cpitch + 63) / 64 * 64;
     const bool xi = c->sl_xi && c->sl_kp8 == kp8 && (size_t)c->Bcap * kp8 <= c->sl_xi_cap && c->sl_scal;
+    if (kp8 == 64)
+        hipLaunchKernelGGL(sl_quant_rows64_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, stream, c->Xs, (int)c->xpitch, c->Xc,
+                           (int)c->cpitch, idx, (int)B, xi ? c->sl_xi : (signed char *)nullptr, (size_t)c->Bcap * kp8,
+                           xi ? c->sl_l1 : (float *)nullptr, (size_t)c->Bcap, xi ? c->sl_scal + 8192 : (unsigned *)nullptr);
+    else
     hipLaunchKernelGGL(sl_quant_rows_kernel, dim3((unsigned)B), dim3(256), 0, stream, c->Xs, (int)c->xpitch, c->Xc,
                        (int)c->cpitch, idx, (int)B, xi ? c->sl_xi : (signed char *)nullptr, (size_t)c->Bcap * kp8, (int)kp8,
                        xi ? c->sl_l1 : (float *)nullptr, (size_t)c->Bcap, xi ? c->sl_scal + 8192 : (unsigned *)nullptr);
@@ -708,7 +1048,7 @@ int launch_sl_gather_quant(vsom_ctx *c, size_t B, hipStream_t stream, const int 
 // prepares the int8 images and computes G / tmin for samples [s0, s1) (ldg, ntm as the fp32 path lays them out: 64-node
 // tile minima); scal = the counter set THIS search's select / feedback kernels read (the two sets alternate,
 // vsom_shortlist.hip), already reset
-int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag)
+int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag, bool gless)
 {
     const bool compact = c->cc_valid;
     const uint32_t kmax = compact ? c->cpitch : c->xpitch;
@@ -728,6 +1068,11 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
 #endif
     const size_t xplane = (size_t)c->Bcap * kp8;
     if (!c->xi_valid) {      // once per staged chunk (the compaction's gather pass does it when the buffers exist)
+        if (kp8 == 64)
+            hipLaunchKernelGGL(sl_quant_rows64_kernel, dim3((unsigned)((c->B + 15) / 16)), dim3(256), 0, c->stream,
+                               compact ? c->Xc : c->Xs, (int)kmax, (float *)nullptr, (int)kmax, (const int *)nullptr, (int)c->B,
+                               c->sl_xi, xplane, c->sl_l1, (size_t)c->Bcap, xflag);
+        else
         hipLaunchKernelGGL(sl_quant_rows_kernel, dim3((unsigned)c->B), dim3(256), 0, c->stream, compact ? c->Xc : c->Xs, (int)kmax,
                            (float *)nullptr, (int)kmax, (const int *)nullptr, (int)c->B, c->sl_xi, xplane, (int)kp8, c->sl_l1,
                            (size_t)c->Bcap, xflag);
@@ -735,11 +1080,25 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
     }
     const float *xscale = c->sl_l1 + c->Bcap;
     const unsigned *kp_dev = compact ? (const unsigned *)c->cc_meta : nullptr;
+    if (kp8 == 64 && c->part_pitch <= 64)
+        hipLaunchKernelGGL(sl_prepare64_kernel, dim3((unsigned)((c->N + 15) / 16)), dim3(256), 0, c->stream, c->map, (int)c->pitch,
+                           (int)c->part_pitch, (int)c->N, compact ? (const int *)c->cc_idx : (const int *)nullptr, (int)kmax, kp_dev,
+                           c->sl_q, c->sl_nrm, c->sl_qscale, c->sl_qcorr, (int4 *)c->sl_qfast, scal, xflag);
+    else
     hipLaunchKernelGGL(sl_prepare_i8_kernel, dim3((unsigned)((c->N + 3) / 4)), dim3(256), 0, c->stream, c->map, (int)c->pitch,
                        (int)c->part_pitch, (int)c->N, compact ? (const int *)c->cc_idx : (const int *)nullptr, (int)kmax, kp_dev,
-                       (int)kp8, c->sl_q, c->sl_nrm, c->sl_qscale, c->sl_qcorr, (int4 *)c->sl_qfast, scal);
+                       (int)kp8, c->sl_q, c->sl_nrm, c->sl_qscale, c->sl_qcorr, (int4 *)c->sl_qfast, scal, xflag);
     // the fp32 two-fma epilogue of the uint8 kind needs |A| < 2^24: K <= 960 contracted columns (sl_i8_value_fast)
     const int4 *qfast = kp8 <= 960 ? (const int4 *)c->sl_qfast : (const int4 *)nullptr;
+    if (gless) {             // K <= 64: tile minima only (ntm = 16-node tiles), the refinement is sl_pick_kernel
+        if (kp8 != 64)
+            return VSOM_ERR_INVALID;
+        dim3 grid((unsigned)((c->N + K64_NB * 32 - 1) / (K64_NB * 32)), (unsigned)((s1 - s0 + 127) / 128));
+        hipLaunchKernelGGL(sl_k64_kernel, grid, dim3(256), 0, c->stream, c->sl_xi, xplane, (int)s0, (int)s1, c->sl_q, (int)c->N,
+                           c->sl_nrm, (const int4 *)c->sl_qfast, xscale, c->sl_tmin, (int)ntm, (const unsigned *)xflag, scal);
+        VSOM_HIP_CHECK(hipGetLastError());
+        return VSOM_OK;
+    }
     // big maps and chunks: 256 x 128 tiles through the LDS-DMA ring; otherwise (few tiles: they would not fill the
     // chip) 128 x 64 tiles staged through registers
     const size_t big_tiles = ((size_t)c->N + RT_N - 1) / RT_N * ((s1 - s0 + RT_S - 1) / RT_S);
