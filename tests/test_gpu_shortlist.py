@@ -460,7 +460,7 @@ def test_c4_size_short_rows_search_equals_exact_kernel(kind):
         # (one Median epoch at sigma = 16 leaves a nearly constant map: on uint8 data most nodes then tie within the
         # bound and the samples go to the exact kernel -- correct, just not fast)
         if rnd == 0 or kind == "blobs":
-            assert st["redo_samples"] == 0 and st["candidates"] < 256 * B, (rnd, st)
+            assert st["redo_samples"] * 100 <= B and st["candidates"] < 256 * B, (rnd, st)
         if rnd == 0:
             ctx.set_bmu_mode(capi.BMU_AUTO)
             ctx.batch_epoch(16.0, True)

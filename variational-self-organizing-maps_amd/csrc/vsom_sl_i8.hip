@@ -871,11 +871,17 @@ __global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed ch
 // one sample over 16 nodes without any cross-lane step, and only those minima are written: tmin[sample][tile], tile
 // t = 2 (node block of 32) + (lane >> 5) = the nodes 32 (t >> 1) + 4 (t & 1) + {0..3, 8..11, 16..19, 24..27}.  The
 // refinement (sl_pick_kernel, vsom_shortlist.hip) evaluates every node of every tile whose minimum is within the bound of the
-// row minimum in the reference's order.  Both kinds evaluate the value in fp32: the uint8 kind as sl_i8_value_fast, the
-// general kind as |M|^2 - t_s (2 s_n w) with w = (16384 a0 + 128 a1 + a2) / 16384 -- the scales are powers of two >= 2^-50
-// each (vsom_digits.hpp), so the products with them are exact.
+// row minimum in the reference's order.
+// Both kinds evaluate the value in fp32: the uint8 kind as sl_i8_value_fast, the general kind as |M|^2 - t_s (2 s_n w) with
+// w = (16384 a0 + 128 a1 + a2) / 16384 -- the scales are powers of two >= 2^-50 each (vsom_digits.hpp), so the products
+// with them are exact; the conversion of u = 128 a1 + a2 (< 2^27) is off by at most 4, which the refinement's bound
+// carries as 16 t_s eps_n.  The kernel is bound by the vector instructions of its epilogue (7 per value), not by the
+// matrix pipe: accumulators start from the MFMA's zero operand instead of 48 moves, and the model fragments alternate
+// between two register sets instead of being copied.  (Two digits per value instead of three -- half the MFMAs, 6
+// instructions per value, bound terms x 128 -- measured at C4: kernel 30 instead of 34 us, but 4.7 instead of 1.0
+// candidate tiles per sample on the trained map: refinement 45 instead of 22 us.  Dropped.)
 #define K64_NB 16         // node blocks of 32 per workgroup (its 256 threads stage the constants of these 512 nodes)
-template <int XD>
+template <int XD>         // sample planes: 1 (uint8 image) or 3 (digits)
 __device__ __forceinline__ void sl_k64_body(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
                                             const signed char *__restrict__ q, int N, const float *__restrict__ xscale,
                                             float *__restrict__ tmin, int ntl, const float *s_nrm, const int4 *s_f)
@@ -897,8 +903,9 @@ __device__ __forceinline__ void sl_k64_body(const signed char *__restrict__ xi, 
     const float ts = XD == 3 ? xscale[sr] : 1.f;
     float *out = tmin + (size_t)(srow - s0) * ntl + (nbase >> 4) + lh;
     const int nbn = (N - nbase + 31) / 32 < K64_NB ? (N - nbase + 31) / 32 : K64_NB;      // node blocks of this workgroup
-    v4i b[3][2], bn[3][2];
+    v4i b0[3][2], b1[3][2];
     auto bload = [&](int nb, v4i (&dst)[3][2]) {         // the model fragments of block nb (clamped: always valid rows)
+        nb = nb < nbn ? nb : nbn - 1;
         int n = nbase + nb * 32 + lr;
         n = n < N ? n : N - 1;
         const signed char *qb = q + (size_t)n * 64 + 16 * lh;
@@ -908,21 +915,21 @@ __device__ __forceinline__ void sl_k64_body(const signed char *__restrict__ xi, 
             for (int ks = 0; ks < 2; ++ks)
                 dst[l][ks] = *reinterpret_cast<const v4i *>(qb + l * plane + ks * 32);
     };
-    bload(0, b);
-    for (int nb = 0; nb < nbn; ++nb) {
-        bload(nb + 1 < nbn ? nb + 1 : nb, bn);           // the next block's fragments stay in flight behind this block's work
+    auto tile = [&](int nb, const v4i (&b)[3][2]) {
+        const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // first operand = rows of the result = nodes.  acc[w]: products (sample plane pl) x (model plane l), pl + l = w
         v16i acc[3];
 #pragma unroll
-        for (int l = 0; l < 3; ++l)
+        for (int l = 0; l < 3; ++l) {                    // sample plane 0 opens every accumulator set
+            acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][0], a[0][0], zero, 0, 0, 0);
+            acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][1], a[0][1], acc[l], 0, 0, 0);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[l][r] = 0;
-#pragma unroll
-        for (int pl = 0; pl < XD; ++pl)
+        for (int pl = 1; pl < XD; ++pl)
 #pragma unroll
             for (int l = 0; l + pl < 3; ++l)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)      // first operand = rows of the result = nodes
+                for (int ks = 0; ks < 2; ++ks)
                     acc[pl + l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][ks], a[pl][ks], acc[pl + l], 0, 0, 0);
         float mn = __uint_as_float(0x7F800000u);
 #pragma unroll
@@ -933,9 +940,6 @@ __device__ __forceinline__ void sl_k64_body(const signed char *__restrict__ xi, 
             if (XD == 1) {
                 g = sl_i8_value_fast(acc[0][r], acc[1][r], acc[2][r], s_f[nl], nm);
             } else {
-                // T = 16384 a0 + u, u = 128 a1 + a2 (|u| < 2^27: its conversion is off by at most 4, which the
-                // refinement's bound carries as 16 t_s eps_n); w = T / 16384 and the scales are powers of two:
-                // g = |M|^2 - t_s (2 s_n w), three roundings (conversion, w, g)
                 const int u = (acc[1][r] << 7) + acc[2][r];
                 const float w = fmaf((float)u, 0x1.0p-14f, (float)acc[0][r]);
                 g = fmaf(-ts, __int_as_float(s_f[nl].x) * w, nm);
@@ -944,11 +948,15 @@ __device__ __forceinline__ void sl_k64_body(const signed char *__restrict__ xi, 
         }
         if (sok)
             out[2 * nb] = mn;
-#pragma unroll
-        for (int l = 0; l < 3; ++l)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                b[l][ks] = bn[l][ks];
+    };
+    bload(0, b0);
+    for (int nb = 0; nb < nbn; nb += 2) {                // the next block's fragments stay in flight behind this block's work
+        bload(nb + 1, b1);
+        tile(nb, b0);
+        if (nb + 1 < nbn) {
+            bload(nb + 2, b0);
+            tile(nb + 1, b1);
+        }
     }
 }
 
