@@ -280,6 +280,10 @@ def kernel(name, mode):
     E(f"\t.p2align 6\n.L_loop_{name}:")
     E(f"\ts_waitcnt vmcnt(0)")                                # block b+1 landed in the staging registers
     lwrite()                                                    # -> the slot block b-1 was read from
+    # a dead quad (784 dims: the last workgroup of every node group has four) only stages: its chain steps were 2 % of
+    # the launch's issue slots
+    E(f"\ts_cmp_lg_u32 {S_DEAD}, 0")
+    E(f"\ts_cbranch_scc1 .L_dead_{name}")
     for g in range(CT // 4):
         E(f"\ts_waitcnt lgkmcnt(0)")                          # x and (c, w) of this group (and my LDS writes)
         if g == 0:
@@ -305,8 +309,24 @@ def kernel(name, mode):
     E(f"\ts_sub_u32 {S_CNT}, {S_CNT}, 1")
     E(f"\ts_cmp_lg_u32 {S_CNT}, 0")
     E(f"\ts_cbranch_scc1 .L_loop_{name}")
+    E(f"\ts_branch .L_last_{name}")
+    # ---- the same block for a dead quad: staging, the barrier, nothing else ------------------------
+    E(f".L_dead_{name}:")
+    E(f"\ts_cmp_lt_u32 {S_CNT}, 2")                           # block b+2 -> registers (if there is one)
+    E(f"\ts_cbranch_scc1 .L_dnl_{name}")
+    gload()
+    E(f".L_dnl_{name}:")
+    E(f"\tv_xor_b32_e32 v{V_CW}, {SLOT_XOR}, v{V_CW}")
+    E(f"\ts_waitcnt lgkmcnt(0)")
+    E(f"\ts_barrier")
+    E(f"\ts_sub_u32 {S_CNT}, {S_CNT}, 1")
+    E(f"\ts_cmp_lg_u32 {S_CNT}, 0")
+    E(f"\ts_cbranch_scc1 .L_loop_{name}")
+    E(f"\ts_branch .L_end_{name}")
     # ---- last block: 1..32 samples, no staging ----------------------------------------------------
     E(f".L_last_{name}:")
+    E(f"\ts_cmp_lg_u32 {S_DEAD}, 0")                           # (a dead quad of a chunk of at most 32 samples)
+    E(f"\ts_cbranch_scc1 .L_end_{name}")
     for g in range(CT // 4):
         E(f"\ts_cmp_le_u32 {S_TAIL}, {4 * g}")
         E(f"\ts_cbranch_scc1 .L_store_{name}")
