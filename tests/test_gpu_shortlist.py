@@ -1,6 +1,8 @@
 """GPU: the MFMA shortlist BMU search must return exactly what the exact-order search returns
 (indices bit-exact, distances bit-identical) -- against the oracle at sizes it finishes in
 seconds, and against the exact-order GPU kernel at BASELINE's full size."""
+import os
+
 import numpy as np
 import pytest
 
@@ -471,4 +473,62 @@ def test_c4_size_short_rows_search_equals_exact_kernel(kind):
     rs = np.random.RandomState(1)
     for s_ in rs.randint(0, B, size=32):
         assert o.find_bmu(X[s_]) == int(i_a[s_])
+    ctx.close()
+
+
+def _sl_sweep_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        W, H = int(rs.randint(6, 72)), int(rs.randint(6, 72))
+        J = int(rs.choice([rs.randint(2, 65), rs.randint(2, 65), rs.randint(65, 140)]))      # mostly the G-less form (<= 64)
+        B = int(rs.choice([rs.randint(1, 130), rs.randint(130, 700)]))
+        kind = str(rs.choice(["u8", "u8_sparse", "float", "float_sparse", "tiny", "huge", "mixed_scales"]))
+        mapk = str(rs.choice(["random", "trained", "duplicates", "offset"]))
+        out.append((f"sl{i}_{W}x{H}x{J}_B{B}_{kind}_{mapk}", W, H, J, B, kind, mapk, int(rs.randint(1, 1 << 30))))
+    return out
+
+
+SL_SWEEP = _sl_sweep_cases(int(os.environ.get("VSOM_SL_SWEEP_N", "24")), int(os.environ.get("VSOM_SWEEP_SEED", "20240611")))
+
+
+@pytest.mark.parametrize("name,W,H,J,B,kind,mapk,seed", SL_SWEEP, ids=[c[0] for c in SL_SWEEP])
+def test_random_shortlist_search_equals_exact_kernel(name, W, H, J, B, kind, mapk, seed):
+    """Random shapes, data kinds (uint8 pixels, floats, magnitudes from 1e-20 to 1e15, rows of mixed scale, exact zeros) and
+    maps (random, after one epoch, with duplicate rows, far from the data): the forced shortlist search -- the G-less
+    form for rows of at most 64 values, the G form above -- returns the exact-order kernel's indices and distances bit for
+    bit (the exact kernel is checked against the oracle by every other test).  VSOM_SL_SWEEP_N widens the sweep."""
+    rs = np.random.RandomState(seed)
+    if kind.startswith("u8"):
+        X = rs.randint(0, 256, size=(B, J)).astype(np.float32)
+    else:
+        X = rs.randn(B, J).astype(np.float32)
+    if kind.endswith("sparse"):
+        X[rs.rand(B, J) < 0.7] = 0.0
+    if kind == "tiny":
+        X *= np.float32(1e-20)
+    elif kind == "huge":
+        X *= np.float32(1e15)
+    elif kind == "mixed_scales":
+        X *= np.exp(rs.uniform(-30, 30, size=(B, 1))).astype(np.float32)
+    scale = np.float32(np.abs(X).max() if np.abs(X).max() > 0 else 1.0)
+    init = (gen.random_map(W * H, J, seed % 1000) * scale).astype(np.float32)
+    if mapk == "duplicates":
+        k = max(1, (W * H) // 5)
+        init[-k:] = init[:k]
+        init[0] = init[W * H // 2]
+    elif mapk == "offset":
+        init = (init + np.float32(3) * scale).astype(np.float32)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_state(map=init)
+    ctx.upload_chunk(X)
+    if mapk == "trained":
+        ctx.set_bmu_mode(capi.BMU_EXACT)
+        ctx.batch_epoch(max(W, H) / 5.0, True)
+        ctx.upload_chunk(X)
+    i_s, d_s = _run(ctx, capi.BMU_SHORTLIST)
+    i_e, d_e = _run(ctx, capi.BMU_EXACT)
+    bad = np.nonzero(i_s != i_e)[0]
+    assert bad.size == 0, (name, bad[:8], i_s[bad[:8]], i_e[bad[:8]])
+    assert beq(d_s, d_e), name
     ctx.close()
