@@ -455,7 +455,8 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
             if (c_l1 > 0.f) {
                 const bool gen = xflag[0] != 0u;
                 const float l1e = l1x[(gen ? 2 * (size_t)lstride : 0) + s], es = gen ? l1x[3 * (size_t)lstride + s] : 0.f;
-                ea = ea + 1.001f * c_l1 * (l1e * epsmax + es * l1mmax) + 0.01f * epsmax;   // (+ the fp32 epilogue's second rounding)
+                // (+ the fp32 epilogues' second rounding: 2^-7 eps_n for the uint8 kind, 2^-8 t_s eps_n for the general one)
+                ea = ea + 1.001f * c_l1 * (l1e * epsmax + es * l1mmax) + 0.01f * epsmax * (gen ? fmaxf(1.f, l1x[(size_t)lstride + s]) : 1.f);
             }
             float dj = m + nx;
             dj = dj + ea;

@@ -470,6 +470,18 @@ __device__ __forceinline__ float sl_i8_value_fast(int a0, int a1, int a2, int4 f
     return fmaf(-__int_as_float(f.y), (float)Bq, g1);
 }
 
+// The general kind without fp64: no offset, and the scale t_s s_n 2^-14 is a product of two powers of two >= 2^-50 each
+// (vsom_digits.hpp) -- exact in fp32.  Same split of T as above (|u| = |128 a1 + a2| < 2^31 and |A| < 2^23 for K <= 960), two
+// roundings; the second one's extra term u |t s 2^-13 Bq| <= 2^-8 t_s eps_n is carried by the select kernel's bound.
+__device__ __forceinline__ float sl_i8_value_fast3(int a0, int a1, int a2, int4 f, float ts, float nm)
+{
+    const int u = (a1 << 7) + a2;
+    const int A = a0 + (u >> 14);
+    const int Bq = u & 16383;
+    const float g1 = fmaf(-(ts * __int_as_float(f.x)), (float)A, nm);
+    return fmaf(-(ts * __int_as_float(f.y)), (float)Bq, g1);
+}
+
 // workgroup tile (64 MI) samples x 64 nodes, wavefront tile (32 MI) x 32 (MI MFMA tiles of 32 x 32), K streamed through
 // LDS in chunks of 64 bytes with the next chunk's global loads in flight.  For problems too small to fill the chip with
 // the ring kernel's 256 x 128 tiles.
@@ -563,7 +575,7 @@ __device__ __forceinline__ void sl_gemm_i8_body(const signed char *__restrict__ 
     const int col = nbase + wn * 32 + lr;
     const bool cok = col < N;
     const int cc = cok ? col : N - 1;
-    const bool fast = XD == 1 && qfast != nullptr;       // workgroup-uniform
+    const bool fast = qfast != nullptr;                  // workgroup-uniform (K <= 960 contracted columns)
     const float nmf = nrm[cc];
     const double nm = (double)nmf, sc = qscale[cc], cr = XD == 1 ? qcorr[cc] : 0.0;
     const int4 ff = fast ? qfast[cc] : make_int4(0, 0, 0, 0);
@@ -580,7 +592,8 @@ __device__ __forceinline__ void sl_gemm_i8_body(const signed char *__restrict__ 
         if (fast) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                acc[0][i][r] = __float_as_int(sl_i8_value_fast(acc[0][i][r], acc[1][i][r], acc[2][i][r], ff, nmf));
+                acc[0][i][r] = __float_as_int(XD == 1 ? sl_i8_value_fast(acc[0][i][r], acc[1][i][r], acc[2][i][r], ff, nmf)
+                                                      : sl_i8_value_fast3(acc[0][i][r], acc[1][i][r], acc[2][i][r], ff, rsf[r], nmf));
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -810,7 +823,8 @@ __device__ __forceinline__ void sl_gemm_i8_ring_body(const signed char *__restri
             for (int j = 0; j < 2; ++j) {
                 float g;
                 if (FAST)
-                    g = sl_i8_value_fast(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], ff[j], nmf[j]);
+                    g = XD == 1 ? sl_i8_value_fast(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], ff[j], nmf[j])
+                                : sl_i8_value_fast3(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], ff[j], rsf[r], nmf[j]);
                 else
                     g = sl_i8_value(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], cr[j],
                                     XD == 1 ? sc[j] : sc[j] * (double)rsf[r], nm[j]);
@@ -854,9 +868,12 @@ __global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed ch
     if (kp_dev)
         kp = (int)kp_dev[2];
     extern __shared__ __attribute__((aligned(1024))) signed char ring[];
-    if (xflag[0] != 0u)          // wavefront-uniform (a scalar load)
-        sl_gemm_i8_ring_body<3, 4, 2, false>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
-    else if (qfast)
+    if (xflag[0] != 0u) {        // wavefront-uniform (a scalar load)
+        if (qfast)
+            sl_gemm_i8_ring_body<3, 4, 2, true>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
+        else
+            sl_gemm_i8_ring_body<3, 4, 2, false>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
+    } else if (qfast)
         sl_gemm_i8_ring_body<1, 4, 3, true>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
     else
         sl_gemm_i8_ring_body<1, 4, 3, false>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
