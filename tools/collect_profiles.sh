@@ -12,14 +12,14 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O/summary
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O/a -o r -- python3 $R/bench.py --warmup 3 --no-cpu $BARGS > $O/summary/bench_under_rocprof.json 2> $O/a.err
+timeout -k 10 420 rocprofv3 --kernel-trace --stats -d $O/a -o r -- python3 $R/bench.py --warmup 3 --no-cpu $BARGS > $O/summary/bench_under_rocprof.json 2> $O/a.err
 python3 $R/tools/rocpd_summary.py $O/a/r_results.db > $O/summary/kernel_stats.txt 2>&1
 echo "kernel stats done"
-rocprofv3 --pmc FETCH_SIZE TCC_HIT --kernel-trace --output-format csv -d $O/b -o p -- python3 $R/bench.py --no-cpu --no-other-arith --no-data-variants $BARGS --steps 3 --warmup 1 > $O/b.log 2>&1
+timeout -k 10 420 rocprofv3 --pmc FETCH_SIZE TCC_HIT --kernel-trace --output-format csv -d $O/b -o p -- python3 $R/bench.py --no-cpu --no-other-arith --no-data-variants $BARGS --steps 3 --warmup 1 > $O/b.log 2>&1
 echo "pmc pass 1 done"
-rocprofv3 --pmc WRITE_SIZE TCC_MISS TCC_REQ --kernel-trace --output-format csv -d $O/c -o p -- python3 $R/bench.py --no-cpu --no-other-arith --no-data-variants $BARGS --steps 3 --warmup 1 > $O/c.log 2>&1
+timeout -k 10 420 rocprofv3 --pmc WRITE_SIZE TCC_MISS TCC_REQ --kernel-trace --output-format csv -d $O/c -o p -- python3 $R/bench.py --no-cpu --no-other-arith --no-data-variants $BARGS --steps 3 --warmup 1 > $O/c.log 2>&1
 echo "pmc pass 2 done"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/d -o p -- python3 $R/bench.py --no-cpu --no-other-arith --no-data-variants $BARGS --steps 3 --warmup 1 > $O/d.log 2>&1
+timeout -k 10 420 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/d -o p -- python3 $R/bench.py --no-cpu --no-other-arith --no-data-variants $BARGS --steps 3 --warmup 1 > $O/d.log 2>&1
 echo "pmc pass 3 done"
 for p in b c d; do
   cc=$(find $O/$p -name '*counter_collection.csv' | head -1)
