@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
                                                         const float *__restrict__ xraw, int ldxr, int J, float c_e1,
                                                         unsigned cmax, const float *__restrict__ l1x, unsigned lstride,
                                                         float c_l1, const unsigned *__restrict__ xflag,
-                                                        const float *__restrict__ nrmn, const float *__restrict__ a2n)
+                                                        const float *__restrict__ nrmn, const float *__restrict__ a2n,
+                                                        const float *__restrict__ nrm0)
 {
     __shared__ unsigned cand[SL_CMAX];
     __shared__ float s_um[4];
@@ -357,6 +358,8 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
             cx = cx + __shfl_xor(cx, off);
             nx = nx + __shfl_xor(nx, off);
         }
+    } else if (c_l1 > 0.f) {
+        nx = l1x[4 * (size_t)lstride + s];               // integer contraction: |x|^2 from the quantisation pass
     } else {
         for (int d = lane; d < D; d += 64) {
             float v = xr[d];
@@ -370,18 +373,10 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     // in 32 line-sized slots each; the approximation error is c_l1 (e_s L1Mmax + l1eff_s eps_max) + c_g1 (nMmax + |x|^2),
     // with (e_s, l1eff_s) = (0, |x|_1) for a chunk of the uint8 kind (`xflag` clear) and the digit-grid terms otherwise
     float nmax = __uint_as_float(scal[0]), epsmax = 0.f, l1mmax = 0.f;
-    if (c_l1 > 0.f) {
-        unsigned nb = scal[SLI_NMAX(lane & 31)], eb = scal[SLI_EMAX(lane & 31)], lb = scal[SLI_L1MAX(lane & 31)];
-        for (int off = 16; off > 0; off >>= 1) {
-            const unsigned o1 = (unsigned)__shfl_xor((int)nb, off), o2 = (unsigned)__shfl_xor((int)eb, off),
-                           o3 = (unsigned)__shfl_xor((int)lb, off);
-            nb = o1 > nb ? o1 : nb;
-            eb = o2 > eb ? o2 : eb;
-            lb = o3 > lb ? o3 : lb;
-        }
-        nmax = __uint_as_float(nb);                      // non-negative floats: the bit patterns order like the values
-        epsmax = __uint_as_float(eb);
-        l1mmax = __uint_as_float(lb);
+    if (c_l1 > 0.f) {                                    // folded by the contraction kernel (sl_fold_maxima, vsom_sl_i8.hip)
+        nmax = __uint_as_float(scal[8]);                 // non-negative floats: the bit patterns order like the values
+        epsmax = __uint_as_float(scal[9]);
+        l1mmax = __uint_as_float(scal[10]);
     }
     bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f) || !(cx <= 3.0e38f) || (CLR && sl_clr_degenerate(scal));
     // an all-zero map (what the epoch over an EMPTY chunk leaves, Som.cpp:840-875 -- every chunked MnistDataLoader pass
@@ -506,7 +501,15 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     // node 0 always included (wavefront 0)
     const int grp = lane >> 3, k = lane & 7;
     u64 best = ~0ull;
-    if (wave == 0) {
+    // Node 0 seeds the reference's search (Som.cpp:293-299): a NaN there pins the BMU to 0.  Standard / Median: with a
+    // finite sample and no inf in the map (both checked above) its distance is NaN exactly when its row holds a NaN, i.e.
+    // when |M_0|^2 is NaN; otherwise it is a node like any other, and the argmin always is among the candidates (its G is
+    // the row minimum or within the bound of it) -- so its 784-element evaluation, which used to double wavefront 0's
+    // critical path, is skipped.
+    const bool need0 = CLR || nrm0 == nullptr || zero_map || nrm0[0] != nrm0[0];
+    if (threadIdx.x == 0)
+        s_nan0 = 0;
+    if (wave == 0 && need0) {
         float d0 = CLR ? sl_clr_dist<8>(s_xy, s_xy + a.ldx, a.ma, a.mb, a.L, k) : vsom_group_dist<false>(xr, xr, a.ma, a.ma, a.L, k);
         d0 = __shfl(d0, 0);
         best = vsom_key(d0, 0u);
@@ -806,7 +809,7 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
                        (int)s1, (int)c->N, (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(i8 ? 5.5 * u : 2.0 * g1),
                        (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, (const float *)nullptr, 0, 0, 0.f,
                        (unsigned)SL_CMAX, (const float *)c->sl_l1, (unsigned)c->Bcap, i8 ? 2.0f : 0.f, (const unsigned *)xflag,
-                       (const float *)nullptr, (const float *)nullptr);
+                       (const float *)nullptr, (const float *)nullptr, (const float *)c->sl_nrm);
     hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(64), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
                        i8 ? (const unsigned *)xflag : (const unsigned *)nullptr, scal_next);
     VSOM_HIP_CHECK(hipGetLastError());
@@ -1030,7 +1033,8 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
     hipLaunchKernelGGL(sl_select_kernel<true>, dim3((unsigned)nrows), dim3(256), xy_bytes, c->stream, a, (int)s0, (int)s1, (int)c->N,
                        (int)c->D, c->sl_G, (int)ldg, c->sl_tmin, (int)ntm, scal, (float)(1.0001 * ga), (float)(1.0001 * g2),
                        c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, c->Xs, (int)c->xpitch, (int)J, (float)(1.0001 * e1), 128u,
-                       (const float *)nullptr, 0u, 0.f, (const unsigned *)nullptr, (const float *)c->sl_nrm, (const float *)c->sl_a2);
+                       (const float *)nullptr, 0u, 0.f, (const unsigned *)nullptr, (const float *)c->sl_nrm, (const float *)c->sl_a2,
+                       (const float *)nullptr);
     hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(64), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
                        (const unsigned *)nullptr, scal_next);
     VSOM_HIP_CHECK(hipGetLastError());

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restr
                                                             signed char *__restrict__ xi, size_t xplane, int kp8,
                                                             float *__restrict__ lx, size_t lstride, unsigned *__restrict__ xflag)
 {
-    __shared__ float ssum[4], smax[4], sl1[4];
+    __shared__ float ssum[4], smax[4], sl1[4], snx[4];
     __shared__ int sa[4];
     const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (row >= nrows)
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restr
         return c >= 0 ? s[c] : 0.f;
     };
     const int kend = xi ? kp8 : ldd;
-    float sum = 0.f, mx = 0.f, l1f = 0.f;
+    float sum = 0.f, mx = 0.f, l1f = 0.f, nx2 = 0.f;
     bool bad = false;
     for (int k4 = threadIdx.x * 4; k4 < kend; k4 += 1024) {
         const float vv[4] = {value(k4), value(k4 + 1), value(k4 + 2), value(k4 + 3)};
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restr
                 const bool fin = af <= 3.0e38f;
                 mx = (fin && af > mx) ? af : mx;
                 l1f += fin ? af : 0.f;
+                nx2 += f * f;
             }
             *reinterpret_cast<char4 *>(xi + (size_t)row * kp8 + k4) = q;
         }
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restr
     for (int off = 32; off > 0; off >>= 1) {
         sum += __shfl_xor(sum, off);
         l1f += __shfl_xor(l1f, off);
+        nx2 += __shfl_xor(nx2, off);
         const float o = __shfl_xor(mx, off);
         mx = o > mx ? o : mx;
     }
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restr
         ssum[wave] = sum;
         smax[wave] = mx;
         sl1[wave] = l1f;
+        snx[wave] = nx2;
     }
     __syncthreads();
     mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restr
         const float at = (float)(sa[0] + sa[1] + sa[2] + sa[3]);             // exact: < 2^24
         lx[2 * lstride + row] = (l1 + (float)kp8 * es + 1.01f * t1 * at) * 1.001f;
         lx[3 * lstride + row] = es;
+        lx[4 * lstride + row] = (snx[0] + snx[1]) + (snx[2] + snx[3]);      // |x|^2 (any order: it only enters bounds)
     }
 }
 
@@ -527,6 +531,27 @@ __global__ __launch_bounds__(256) void sl_prepare64_kernel(const float *__restri
     }
 }
 
+// The maxima of |M|^2, eps and |M|_1 over the 32 slots the prepare kernel filled -> words 8..10 of the counter set: the
+// first wavefront of ONE workgroup of the contraction kernel does it, the refinement kernels (one workgroup or wavefront
+// per sample) then read three words instead of reducing 96 each.
+__device__ __forceinline__ void sl_fold_maxima(unsigned *__restrict__ scal)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned nb = scal[SLI_NMAX(lane & 31)], eb = scal[SLI_EMAX(lane & 31)], lb = scal[SLI_L1MAX(lane & 31)];
+    for (int off = 16; off > 0; off >>= 1) {
+        const unsigned o1 = (unsigned)__shfl_xor((int)nb, off), o2 = (unsigned)__shfl_xor((int)eb, off),
+                       o3 = (unsigned)__shfl_xor((int)lb, off);
+        nb = o1 > nb ? o1 : nb;
+        eb = o2 > eb ? o2 : eb;
+        lb = o3 > lb ? o3 : lb;
+    }
+    if (lane == 0) {
+        scal[8] = nb;
+        scal[9] = eb;
+        scal[10] = lb;
+    }
+}
+
 // ---- G = |M|^2 - 2 <x^, M^>, tile minima ----------------------------------------------------------------------------
 // XD = sample planes (1: uint8 kind, 3: general kind), chosen at run time from the chunk's flag: the kernels below hold
 // both bodies.  Accumulator set w collects the digit products of weight 128^-w: (sample plane pl) x (model plane l),
@@ -726,10 +751,13 @@ __global__ __launch_bounds__(256, XD == 1 ? 3 : 2) void sl_gemm_i8_kernel(const 
                                                             const float *__restrict__ nrm, const double *__restrict__ qscale,
                                                             const double *__restrict__ qcorr, const float *__restrict__ xscale,
                                                             float *__restrict__ G, int ldg, float *__restrict__ tmin, int ntm,
-                                                            const unsigned *__restrict__ xflag, const int4 *__restrict__ qfast)
+                                                            const unsigned *__restrict__ xflag, const int4 *__restrict__ qfast,
+                                                            unsigned *__restrict__ scal)
 {
     if ((xflag[0] != 0u) != (XD == 3))   // wavefront-uniform (a scalar load)
         return;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64)
+        sl_fold_maxima(scal);
     if (kp_dev)
         kp = (int)kp_dev[2];
     __shared__ __attribute__((aligned(16))) signed char As[XD * 64 * MI * ILD];
@@ -950,10 +978,12 @@ __global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed ch
                                                                  const double *__restrict__ qcorr, const float *__restrict__ xscale,
                                                                  float *__restrict__ G, int ldg, float *__restrict__ tmin, int ntm,
                                                                  const unsigned *__restrict__ xflag,
-                                                                 const int4 *__restrict__ qfast)
+                                                                 const int4 *__restrict__ qfast, unsigned *__restrict__ scal)
 {
     if (kp_dev)
         kp = (int)kp_dev[2];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64)
+        sl_fold_maxima(scal);
     extern __shared__ __attribute__((aligned(1024))) signed char ring[];
     if (xflag[0] != 0u) {        // wavefront-uniform (a scalar load)
         if (qfast)
@@ -1064,8 +1094,7 @@ __device__ __forceinline__ void sl_k64_body(const signed char *__restrict__ xi, 
     }
 }
 
-// scal: the counter set of this search; its words 8..10 receive the maxima of |M|^2, eps and |M|_1 over the 32 slots the
-// prepare kernel filled (the refinement reads three words instead of reducing 96 per sample).
+// scal: the counter set of this search (sl_fold_maxima)
 __global__ __launch_bounds__(256, 3) void sl_k64_kernel(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
                                                         const signed char *__restrict__ q, int N,
                                                         const float *__restrict__ nrm, const int4 *__restrict__ qfast,
@@ -1079,22 +1108,8 @@ __global__ __launch_bounds__(256, 3) void sl_k64_kernel(const signed char *__res
         s_nrm[i] = n < N ? nrm[n] : __uint_as_float(0x7F800000u);
         s_f[i] = n < N ? qfast[n] : make_int4(0, 0, 0, 0);
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        unsigned nb = scal[SLI_NMAX(lane & 31)], eb = scal[SLI_EMAX(lane & 31)], lb = scal[SLI_L1MAX(lane & 31)];
-        for (int off = 16; off > 0; off >>= 1) {
-            const unsigned o1 = (unsigned)__shfl_xor((int)nb, off), o2 = (unsigned)__shfl_xor((int)eb, off),
-                           o3 = (unsigned)__shfl_xor((int)lb, off);
-            nb = o1 > nb ? o1 : nb;
-            eb = o2 > eb ? o2 : eb;
-            lb = o3 > lb ? o3 : lb;
-        }
-        if (lane == 0) {
-            scal[8] = nb;
-            scal[9] = eb;
-            scal[10] = lb;
-        }
-    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64)
+        sl_fold_maxima(scal);
     __syncthreads();
     if (xflag[0] != 0u)                                  // workgroup-uniform (a scalar load)
         sl_k64_body<3>(xi, xplane, s0, s1, q, N, xscale, tmin, ntl, s_nrm, s_f);
@@ -1226,16 +1241,16 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
         dim3 grid((unsigned)(ntm / 2), (unsigned)((s1 - s0 + RT_S - 1) / RT_S));   // ntm = 2 ceil(N / 128) 64-node tiles
         hipLaunchKernelGGL(sl_gemm_i8_ring_kernel, grid, dim3(512), RING_BYTES, c->stream, c->sl_xi, xplane, (int)s0, (int)s1,
                            c->sl_q, (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, xscale, c->sl_G,
-                           (int)ldg, c->sl_tmin, (int)ntm, (const unsigned *)xflag, qfast);
+                           (int)ldg, c->sl_tmin, (int)ntm, (const unsigned *)xflag, qfast, scal);
     } else {
         constexpr int MI = 2;
         dim3 grid((unsigned)ntm, (unsigned)((s1 - s0 + 64 * MI - 1) / (64 * MI)));   // ntm 64-node tiles (the last may lie past N: minima +inf)
         hipLaunchKernelGGL((sl_gemm_i8_kernel<MI, 1>), grid, dim3(256), 0, c->stream, c->sl_xi, xplane, (int)s0, (int)s1, c->sl_q,
                            (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, xscale, c->sl_G, (int)ldg,
-                           c->sl_tmin, (int)ntm, (const unsigned *)xflag, qfast);
+                           c->sl_tmin, (int)ntm, (const unsigned *)xflag, qfast, scal);
         hipLaunchKernelGGL((sl_gemm_i8_kernel<MI, 3>), grid, dim3(256), 0, c->stream, c->sl_xi, xplane, (int)s0, (int)s1, c->sl_q,
                            (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, c->sl_qscale, c->sl_qcorr, xscale, c->sl_G, (int)ldg,
-                           c->sl_tmin, (int)ntm, (const unsigned *)xflag, qfast);
+                           c->sl_tmin, (int)ntm, (const unsigned *)xflag, qfast, scal);
     }
     VSOM_HIP_CHECK(hipGetLastError());
     return VSOM_OK;
