@@ -33,11 +33,18 @@ __global__ __launch_bounds__(256) void stage_rows_kernel(const float *__restrict
     if (xflag && blockIdx.x == 0 && threadIdx.x < 33)
         xflag[32 * threadIdx.x] = 0u;                    // the word and its 32 write slots (sl_kind_mark, vsom_sl_i8.hip)
     for (int d = threadIdx.x; d < xpitch; d += 256) {
+        // the 16 loads of a column first, then the stores (a rolled row loop waits for every load before its store:
+        // 64 round trips per thread, 27 us for C3's chunk with one workgroup per CU)
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            v[i] = (d < J && r0 + i < r1) ? x[(size_t)(r0 + i) * J + d] : 0.f;
         bool live = false;
-        for (int r = r0; r < r1; ++r) {
-            const float v = d < J ? x[(size_t)r * J + d] : 0.f;
-            xs[(size_t)r * xpitch + d] = v;
-            live |= !(v == 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (r0 + i < r1)
+                xs[(size_t)(r0 + i) * xpitch + d] = v[i];
+            live |= !(v[i] == 0.f);
         }
         if (flags && live && flags[d] == 0u)
             flags[d] = 1u;

@@ -84,8 +84,12 @@ __global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restr
     const int kend = xi ? kp8 : ldd;
     float sum = 0.f, mx = 0.f, l1f = 0.f, nx2 = 0.f;
     bool bad = false;
+    float keep[4] = {0.f, 0.f, 0.f, 0.f};                // rows of <= 1024 values: the thread's four, kept for the digits
     for (int k4 = threadIdx.x * 4; k4 < kend; k4 += 1024) {
         const float vv[4] = {value(k4), value(k4 + 1), value(k4 + 2), value(k4 + 3)};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            keep[u] = vv[u];
         if (dst && k4 < ldd)
             *reinterpret_cast<float4 *>(dst + (size_t)row * ldd + k4) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         if (xi) {
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(256) void sl_quant_rows_kernel(const float *__restr
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             int a, b, c3;
-            sl_digits3(value(k4 + u), t1, it1, a, b, c3);
+            sl_digits3(kp8 <= 1024 ? keep[u] : value(k4 + u), t1, it1, a, b, c3);
             p1[u] = (signed char)a;
             p2[u] = (signed char)b;
             p3[u] = (signed char)c3;
