@@ -12,6 +12,7 @@
 //                      (Som.cpp:777-781).
 //  stage kernels     : chunk re-layout (zero-padded rows; CLR x'/y' expansion).
 #include "vsom_device.hpp"
+#include "vsom_digits.hpp"
 #include <algorithm>
 #include <utility>
 
@@ -415,9 +416,11 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
                                                           unsigned char *__restrict__ nan0,
                                                           const int *__restrict__ slist,
                                                           const unsigned *__restrict__ scount,
-                                                          const u64 *__restrict__ hits, u64 min_hits)
+                                                          const u64 *__restrict__ hits, u64 min_hits, SlFeedback fb)
 {
     constexpr int TS = 16 * TI;
+    if (LIST && fb.scal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64)
+        sl_feedback_write(fb);               // (vsom_digits.hpp: the search's statistics for the host)
     if (!LIST) {
         bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, nullptr, hits, min_hits, (int)blockIdx.y);
         return;
@@ -460,8 +463,11 @@ __global__ void bmu_reduce_kernel(const u64 *__restrict__ partial, int pstride, 
 }
 
 int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount,
-                                 const u64 *hits, u64 min_hits)
+                                 const u64 *hits, u64 min_hits, const SlFeedback *fbp = nullptr)
 {
+    SlFeedback fb = {nullptr, nullptr, 0u, nullptr, nullptr};
+    if (fbp)
+        fb = *fbp;
     if (s1 <= s0)
         return VSOM_OK;
     const int ntn = (int)((c->N + TILE - 1) / TILE);
@@ -477,13 +483,13 @@ int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *s
     }
     DistArgs a = make_dist_args(c);
     // (a redo list is usually empty or short: ~512 workgroups -- the two per CU the kernel's registers allow -- each
-    // walking on through the list's tiles)
+    // walking on through the list's tiles; 768 for CLR measured slower: a second, half-empty round)
     const bool list = slist != nullptr && scount != nullptr;
     const int gy = list ? std::min(nts, std::max(1, 512 / ntn)) : nts;
     dim3 grid((unsigned)ntn, (unsigned)gy);
 #define VSOM_TILE_LAUNCH(K)                                                                                             \
     hipLaunchKernelGGL(K, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N, c->partial, (int)c->Bcap, c->nan0, \
-                       slist, scount, hits, min_hits)
+                       slist, scount, hits, min_hits, fb)
     if (c->transform == VSOM_CLR) {
         if (list)
             VSOM_TILE_LAUNCH((bmu_tile_kernel<true, 2, true>));
@@ -503,9 +509,9 @@ int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *s
     return VSOM_OK;
 }
 
-int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount)
+int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount, const SlFeedback *fb)
 {
-    return launch_bmu_full_exact_masked(c, s0, s1, slist, scount, nullptr, 0);
+    return launch_bmu_full_exact_masked(c, s0, s1, slist, scount, nullptr, 0, fb);
 }
 
 int launch_bmu_restricted(vsom_ctx *c, u64 min_hits)
@@ -562,7 +568,7 @@ int launch_bmu_full(vsom_ctx *c, size_t s0, size_t s1)
     }
     if (can && want)
         return launch_bmu_full_shortlist(c, s0, s1);
-    return launch_bmu_full_exact_list(c, s0, s1, nullptr, nullptr);
+    return launch_bmu_full_exact_list(c, s0, s1, nullptr, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -67,3 +67,40 @@ __device__ __forceinline__ float sl_min32_dpp(float v)
     v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});    // row_bcast:15 into rows 1 and 3
     return v;
 }
+
+// Feedback of a shortlist search: {redo samples, candidates} of this call into the host-visible words (a hint for the
+// pause policy, read without synchronising), and the counters of the OTHER counter set cleared for the next search (the
+// two sets alternate: nobody touches the other one during this search).  Done by the first wavefront of the redo pass's
+// exact kernel (bmu_tile_kernel, vsom_bmu.hip) -- it runs after the refinement kernel anyway; as a launch of its own
+// this was 6 us per search.
+struct SlFeedback {
+    const unsigned *scal;        // this search's counter set (null: no feedback)
+    unsigned *host_fb;
+    unsigned nrows;
+    const unsigned *xflag;       // the chunk's kind word or null
+    unsigned *scal_next;
+};
+__device__ __forceinline__ void sl_feedback_write(const SlFeedback &f)
+{
+    const unsigned t = threadIdx.x;          // < 64
+    if (t < 8)
+        f.scal_next[t] = 0u;
+    if (t < 32) {
+        f.scal_next[16 + 32 * t] = 0u;       // candidate-count slots
+        f.scal_next[SLI_NMAX(t)] = 0u;       // max |M|^2 / eps / |M|_1 slots of the integer contraction (vsom_sl_i8.hip)
+        f.scal_next[SLI_EMAX(t)] = 0u;
+        f.scal_next[SLI_L1MAX(t)] = 0u;
+    }
+    unsigned cand = t < 32 ? f.scal[16 + 32 * t] : 0u;
+    for (int off = 16; off > 0; off >>= 1)
+        cand += (unsigned)__shfl_xor((int)cand, off);
+    if (t != 0)
+        return;
+    f.host_fb[0] = f.scal[4];
+    f.host_fb[1] = cand;
+    f.host_fb[2] = f.nrows;
+    f.host_fb[4] = f.xflag ? f.xflag[0] : 0u;
+    // (no fence before the sequence word: a torn read costs at most one misjudged search, and a system-scope fence here
+    // waited 2-3 us for the writes to cross the bus)
+    f.host_fb[3] = f.host_fb[3] + 1u;
+}

@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
     __syncthreads();
     if (threadIdx.x == 0) {
         // statistics only, but 4096 same-address atomics per chunk queue up at the memory side: the
-        // count goes to one of 32 line-sized slots (scal[16 + 32 s]); sl_feedback_kernel adds them up
+        // count goes to one of 32 line-sized slots (scal[16 + 32 s]); sl_feedback_write adds them up
         atomicAdd(&stats[12 + 32 * (blockIdx.x & 31)], cnt);
         u64 b = s_best[0];
         for (int i = 1; i < 4; ++i)
@@ -679,37 +679,8 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
     }
 }
 
-// copies {redo samples, candidates} of this call into the host-visible feedback words
-// ... and clears the counters of the OTHER scal set for the next search (the two sets alternate, so no launch is
-// needed to reset them: nobody touches the other set during this search)
-__global__ void sl_feedback_kernel(const unsigned *scal, unsigned *host_fb, unsigned nrows, const unsigned *xflag,
-                                   unsigned *scal_next)
-{
-    if (threadIdx.x < 8)
-        scal_next[threadIdx.x] = 0u;
-    if (threadIdx.x < 32) {
-        scal_next[16 + 32 * threadIdx.x] = 0u;     // candidate-count slots
-        scal_next[SLI_NMAX(threadIdx.x)] = 0u;     // max |M|^2 / eps / |M|_1 slots of the integer contraction (vsom_sl_i8.hip)
-        scal_next[SLI_EMAX(threadIdx.x)] = 0u;
-        scal_next[SLI_L1MAX(threadIdx.x)] = 0u;
-    }
-    unsigned cand = threadIdx.x < 32 ? scal[16 + 32 * threadIdx.x] : 0u;      // (one wavefront: 32 loads in flight, not a chain)
-    for (int off = 16; off > 0; off >>= 1)
-        cand += (unsigned)__shfl_xor((int)cand, off);
-    if (threadIdx.x != 0)
-        return;
-    host_fb[0] = scal[4];
-    host_fb[1] = cand;
-    host_fb[2] = nrows;
-    host_fb[4] = xflag ? xflag[0] : 0u;       // integer contraction asked for on a chunk that is not uint8 data
-    // (no fence before the sequence word: the host reads these words without synchronising, as a hint for the pause
-    // policy only -- a torn read costs at most one misjudged search -- and a system-scope fence here waited 2-3 us
-    // for the writes to cross the bus)
-    host_fb[3] = host_fb[3] + 1u;
-}
-
 // host side ------------------------------------------------------------------------------------
-int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount);
+int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount, const SlFeedback *fb);
 int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag, bool gless);   // vsom_sl_i8.hip
 
 static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1);
@@ -810,11 +781,10 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
                        (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, (const float *)nullptr, 0, 0, 0.f,
                        (unsigned)SL_CMAX, (const float *)c->sl_l1, (unsigned)c->Bcap, i8 ? 2.0f : 0.f, (const unsigned *)xflag,
                        (const float *)nullptr, (const float *)nullptr, (const float *)c->sl_nrm);
-    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(64), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
-                       i8 ? (const unsigned *)xflag : (const unsigned *)nullptr, scal_next);
     VSOM_HIP_CHECK(hipGetLastError());
-    // exact-order redo of the listed samples (device-side count; blocks beyond it exit at once)
-    return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2);
+    // exact-order redo of the listed samples (device-side count; its workgroups walk the list) + the feedback words
+    const SlFeedback fb = {scal, c->sl_fb, (unsigned)nrows, i8 ? (const unsigned *)xflag : (const unsigned *)nullptr, scal_next};
+    return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2, &fb);
 }
 
 // ==============================================================================================
@@ -969,7 +939,7 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
     // the select kernel keeps the sample's x' / y' rows in LDS (2 * part_pitch floats beside 8.3 KB of
     // static storage): beyond 48 KB (J > 110) the exact-order kernel searches instead
     if ((size_t)2 * c->part_pitch * sizeof(float) > 48 * 1024)
-        return launch_bmu_full_exact_list(c, s0, s1, nullptr, nullptr);
+        return launch_bmu_full_exact_list(c, s0, s1, nullptr, nullptr, nullptr);
     const size_t nrows = s1 - s0;
     const uint32_t P = c->part_len, J = c->J;
     const uint32_t P32 = (P + 31) / 32 * 32, Kp = P32 + (3 * J + 31) / 32 * 32;
@@ -1035,8 +1005,7 @@ static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1)
                        c->lastbmu, c->sqres, scal + 2, c->sl_list, scal + 4, c->Xs, (int)c->xpitch, (int)J, (float)(1.0001 * e1), 128u,
                        (const float *)nullptr, 0u, 0.f, (const unsigned *)nullptr, (const float *)c->sl_nrm, (const float *)c->sl_a2,
                        (const float *)nullptr);
-    hipLaunchKernelGGL(sl_feedback_kernel, dim3(1), dim3(64), 0, c->stream, scal, c->sl_fb, (unsigned)nrows,
-                       (const unsigned *)nullptr, scal_next);
     VSOM_HIP_CHECK(hipGetLastError());
-    return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2);
+    const SlFeedback fb = {scal, c->sl_fb, (unsigned)nrows, (const unsigned *)nullptr, scal_next};
+    return launch_bmu_full_exact_list(c, s0, s1, c->sl_list, scal + 2, &fb);
 }
