@@ -1014,92 +1014,99 @@ __global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed ch
 // w = (16384 a0 + 128 a1 + a2) / 16384 -- the scales are powers of two >= 2^-50 each (vsom_digits.hpp), so the products
 // with them are exact; the conversion of u = 128 a1 + a2 (< 2^27) is off by at most 4, which the refinement's bound
 // carries as 16 t_s eps_n.  The kernel is bound by the vector instructions of its epilogue (7 per value), not by the
-// matrix pipe: accumulators start from the MFMA's zero operand instead of 48 moves, and the model fragments alternate
-// between two register sets instead of being copied.  (Two digits per value instead of three -- half the MFMAs, 6
+// matrix pipe: accumulators start from the MFMA's zero operand instead of 48 moves.  (Two digits per value instead of three -- half the MFMAs, 6
 // instructions per value, bound terms x 128 -- measured at C4: kernel 30 instead of 34 us, but 4.7 instead of 1.0
 // candidate tiles per sample on the trained map: refinement 45 instead of 22 us.  Dropped.)
 #define K64_NB 16         // node blocks of 32 per workgroup (its 256 threads stage the constants of these 512 nodes)
+#define K64_SB 2          // sample blocks of 32 per wavefront: every model fragment feeds two MFMAs (see below)
 template <int XD>         // sample planes: 1 (uint8 image) or 3 (digits)
 __device__ __forceinline__ void sl_k64_body(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
                                             const signed char *__restrict__ q, int N, const float *__restrict__ xscale,
                                             float *__restrict__ tmin, int ntl, const float *s_nrm, const int4 *s_f)
 {
+    // What the first version (one sample block per wavefront) waited for was the texture-address unit, not the matrix
+    // pipe: a 16-byte load of 64 lanes occupies it for 16 cycles, six model fragments per node block = 96 cycles per
+    // wavefront against 384 cycles of MFMAs on ITS SIMD -- but one unit serves the CU's four SIMDs.  With two sample
+    // blocks per wavefront the same fragments feed twice the MFMAs.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int nbase = blockIdx.x * (K64_NB * 32);
-    const int srow = s0 + blockIdx.y * 128 + wave * 32 + lr;
-    const bool sok = srow < s1;
-    const size_t sr = (size_t)(sok ? srow : s1 - 1);
     const size_t plane = (size_t)N * 64;
-    const signed char *xbase = (XD == 1 ? xi : xi + xplane) + sr * 64 + 16 * lh;
-    v4i a[XD][2];
+    v4i a[K64_SB][XD][2];
+    float ts[K64_SB];
+    bool sok[K64_SB];
+    float *out[K64_SB];
 #pragma unroll
-    for (int pl = 0; pl < XD; ++pl)
+    for (int sb = 0; sb < K64_SB; ++sb) {
+        const int srow = s0 + (blockIdx.y * 4 + wave) * (32 * K64_SB) + sb * 32 + lr;
+        sok[sb] = srow < s1;
+        const size_t sr = (size_t)(sok[sb] ? srow : s1 - 1);
+        const signed char *xbase = (XD == 1 ? xi : xi + xplane) + sr * 64 + 16 * lh;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            a[pl][ks] = *reinterpret_cast<const v4i *>(xbase + pl * xplane + ks * 32);
-    const float ts = XD == 3 ? xscale[sr] : 1.f;
-    float *out = tmin + (size_t)(srow - s0) * ntl + (nbase >> 4) + lh;
+        for (int pl = 0; pl < XD; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                a[sb][pl][ks] = *reinterpret_cast<const v4i *>(xbase + pl * xplane + ks * 32);
+        ts[sb] = XD == 3 ? xscale[sr] : 1.f;
+        out[sb] = tmin + (size_t)(srow - s0) * ntl + (nbase >> 4) + lh;
+    }
     const int nbn = (N - nbase + 31) / 32 < K64_NB ? (N - nbase + 31) / 32 : K64_NB;      // node blocks of this workgroup
-    v4i b0[3][2], b1[3][2];
-    auto bload = [&](int nb, v4i (&dst)[3][2]) {         // the model fragments of block nb (clamped: always valid rows)
-        nb = nb < nbn ? nb : nbn - 1;
+    for (int nb = 0; nb < nbn; ++nb) {
         int n = nbase + nb * 32 + lr;
         n = n < N ? n : N - 1;
         const signed char *qb = q + (size_t)n * 64 + 16 * lh;
+        v4i b[3][2];
 #pragma unroll
         for (int l = 0; l < 3; ++l)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                dst[l][ks] = *reinterpret_cast<const v4i *>(qb + l * plane + ks * 32);
-    };
-    auto tile = [&](int nb, const v4i (&b)[3][2]) {
-        const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        // first operand = rows of the result = nodes.  acc[w]: products (sample plane pl) x (model plane l), pl + l = w
-        v16i acc[3];
-#pragma unroll
-        for (int l = 0; l < 3; ++l) {                    // sample plane 0 opens every accumulator set
-            acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][0], a[0][0], zero, 0, 0, 0);
-            acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][1], a[0][1], acc[l], 0, 0, 0);
-        }
-#pragma unroll
-        for (int pl = 1; pl < XD; ++pl)
-#pragma unroll
-            for (int l = 0; l + pl < 3; ++l)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    acc[pl + l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][ks], a[pl][ks], acc[pl + l], 0, 0, 0);
-        float mn = __uint_as_float(0x7F800000u);
+                b[l][ks] = *reinterpret_cast<const v4i *>(qb + l * plane + ks * 32);
+        // the per-node constants of this block (16 per lane), shared by the sample blocks
+        float nm[16], fx[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int nl = nb * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
-            const float nm = s_nrm[nl];                  // nodes past N: +inf (f = 0): never a minimum
-            float g;
-            if (XD == 1) {
-                g = sl_i8_value_fast(acc[0][r], acc[1][r], acc[2][r], s_f[nl], nm);
-            } else {
-                const int u = (acc[1][r] << 7) + acc[2][r];
-                const float w = fmaf((float)u, 0x1.0p-14f, (float)acc[0][r]);
-                g = fmaf(-ts, __int_as_float(s_f[nl].x) * w, nm);
-            }
-            mn = fminf(mn, g);                           // a NaN (a NaN row of the map) never replaces the minimum
+            nm[r] = s_nrm[nl];                           // nodes past N: +inf (f = 0): never a minimum
+            fx[r] = __int_as_float(s_f[nl].x);
         }
-        if (sok)
-            out[2 * nb] = mn;
-    };
-    bload(0, b0);
-    for (int nb = 0; nb < nbn; nb += 2) {                // the next block's fragments stay in flight behind this block's work
-        bload(nb + 1, b1);
-        tile(nb, b0);
-        if (nb + 1 < nbn) {
-            bload(nb + 2, b0);
-            tile(nb + 1, b1);
+#pragma unroll
+        for (int sb = 0; sb < K64_SB; ++sb) {
+            const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // first operand = rows of the result = nodes.  acc[w]: products (sample plane pl) x (model plane l), pl + l = w
+            v16i acc[3];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {                // sample plane 0 opens every accumulator set
+                acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][0], a[sb][0][0], zero, 0, 0, 0);
+                acc[l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][1], a[sb][0][1], acc[l], 0, 0, 0);
+            }
+#pragma unroll
+            for (int pl = 1; pl < XD; ++pl)
+#pragma unroll
+                for (int l = 0; l + pl < 3; ++l)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        acc[pl + l] = __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][ks], a[sb][pl][ks], acc[pl + l], 0, 0, 0);
+            float mn = __uint_as_float(0x7F800000u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float g;
+                if (XD == 1) {
+                    g = sl_i8_value_fast(acc[0][r], acc[1][r], acc[2][r], s_f[nb * 32 + 4 * lh + (r & 3) + 8 * (r >> 2)], nm[r]);
+                } else {
+                    const int u = (acc[1][r] << 7) + acc[2][r];
+                    const float w = fmaf((float)u, 0x1.0p-14f, (float)acc[0][r]);
+                    g = fmaf(-ts[sb], fx[r] * w, nm[r]);
+                }
+                mn = fminf(mn, g);                       // a NaN (a NaN row of the map) never replaces the minimum
+            }
+            if (sok[sb])
+                out[sb][2 * nb] = mn;
         }
     }
 }
 
 // scal: the counter set of this search (sl_fold_maxima)
-__global__ __launch_bounds__(256, 3) void sl_k64_kernel(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
+__global__ __launch_bounds__(256, 2) void sl_k64_kernel(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
                                                         const signed char *__restrict__ q, int N,
                                                         const float *__restrict__ nrm, const int4 *__restrict__ qfast,
                                                         const float *__restrict__ xscale, float *__restrict__ tmin, int ntl,
@@ -1224,7 +1231,7 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
     if (gless) {             // K <= 64: tile minima only (ntm = 16-node tiles), the refinement is sl_pick_kernel
         if (kp8 != 64)
             return VSOM_ERR_INVALID;
-        dim3 grid((unsigned)((c->N + K64_NB * 32 - 1) / (K64_NB * 32)), (unsigned)((s1 - s0 + 127) / 128));
+        dim3 grid((unsigned)((c->N + K64_NB * 32 - 1) / (K64_NB * 32)), (unsigned)((s1 - s0 + 128 * K64_SB - 1) / (128 * K64_SB)));
         hipLaunchKernelGGL(sl_k64_kernel, grid, dim3(256), 0, c->stream, c->sl_xi, xplane, (int)s0, (int)s1, c->sl_q, (int)c->N,
                            c->sl_nrm, (const int4 *)c->sl_qfast, xscale, c->sl_tmin, (int)ntm, (const unsigned *)xflag, scal);
         VSOM_HIP_CHECK(hipGetLastError());
