@@ -532,3 +532,41 @@ def test_random_shortlist_search_equals_exact_kernel(name, W, H, J, B, kind, map
     assert bad.size == 0, (name, bad[:8], i_s[bad[:8]], i_e[bad[:8]])
     assert beq(d_s, d_e), name
     ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["float", "u8"])
+def test_short_rows_search_with_retired_columns(kind):
+    """Rows of exactly 64 values in a chunk large enough for the column compaction (>= 1024 rows) with all-zero columns:
+    the G-less contraction then runs on the gathered live columns (the 16-lanes-per-row quantisation kernels with the
+    live-column list).  Forced shortlist search and a whole epoch against the oracle."""
+    W = H = 40
+    J, B = 64, 1100
+    rs = np.random.RandomState(5)
+    if kind == "u8":
+        X = rs.randint(0, 256, size=(B, J)).astype(np.float32)
+        init = (gen.random_map(W * H, J, 42) * np.float32(100) + np.float32(100)).astype(np.float32)
+    else:
+        X = gen.blobs(B, J, 6, 1, 2, sigma=0.5)
+        init = gen.random_map(W * H, J, 42)
+    X[:, [0, 1, 2, 17, 18, 40, 41, 42, 43, 63]] = 0.0        # retired columns (one whole quad among them)
+    o = po.OracleSom(W, H, J)
+    o.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_state(map=init)
+    ctx.upload_chunk(X)
+    lb_o, sq_o = _oracle_bmu(o, X)
+    for mode in (capi.BMU_SHORTLIST, capi.BMU_EXACT):
+        idx, dist = _run(ctx, mode)
+        assert beq(idx, lb_o) and beq(dist, sq_o), (kind, mode)
+    lb = np.zeros(B, np.uint64)
+    o.batch_epoch(X, lb, 10.0, True, nthreads=16)
+    ctx.set_bmu_mode(capi.BMU_SHORTLIST)
+    ctx.batch_epoch(10.0, True)
+    assert beq(ctx.get_last_bmu(), lb), kind
+    st = ctx.get_state()
+    assert beq(st["map"], o.map) and beq(st["sigma"], o.sigma), kind
+    lb_o, sq_o = _oracle_bmu(o, X)
+    ctx.upload_chunk(X)
+    idx, dist = _run(ctx, capi.BMU_SHORTLIST)
+    assert beq(idx, lb_o) and beq(dist, sq_o), kind + " trained"
+    ctx.close()
