@@ -553,6 +553,10 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
 // (32 (t >> 1) + 4 (t & 1) + {0..3, 8..11, 16..19, 24..27}); every node of every tile with tmin <= row minimum + T_s
 // (the bound of sl_select_kernel, same terms) is evaluated in the reference's order, 8 lanes per node, node 0 always.
 // More than `tmax` such tiles, or a sample / map the bound does not cover: the redo list.
+// WPS = wavefronts per sample: 1 for short rows (four samples per workgroup); 4 for long ones (a workgroup per sample, the
+// (tile, half) items dealt round robin: a 784-element row is seven dependent load batches per evaluation, and ~21 candidate
+// nodes are three passes of eight for one wavefront -- 69 us at C3 -- but one pass for four).
+template <int WPS>
 __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1, int N, int D,
                                                       const float *__restrict__ tmin, int ntl,
                                                       const unsigned *__restrict__ scal, float c_g1, float c_g2,
@@ -562,16 +566,22 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
                                                       const float *__restrict__ l1x, unsigned lstride, float c_l1,
                                                       const unsigned *__restrict__ xflag, const float *__restrict__ nrm0)
 {
-    // candidate statistics: one global atomic per workgroup (the last of its four wavefronts to arrive sends the sum)
+    // candidate statistics: one global atomic per workgroup (WPS = 1: the last of its four wavefronts to arrive sends the sum)
     __shared__ unsigned s_tot, s_arr;
+    __shared__ u64 s_best[4];
     if (threadIdx.x == 0) {
         s_tot = 0u;
         s_arr = 0u;
     }
-    __syncthreads();      // the only barrier: every wavefront passes it before any leaves
+    __syncthreads();      // WPS = 1: the only barrier: every wavefront passes it before any leaves
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = s0 + blockIdx.x * 4 + wave;
+    const int s = WPS == 1 ? s0 + blockIdx.x * 4 + wave : s0 + (int)blockIdx.x;
     auto leave = [&](unsigned cands) {
+        if (WPS != 1) {
+            if (threadIdx.x == 0 && cands)
+                atomicAdd(&stats[12 + 32 * (blockIdx.x & 31)], cands);
+            return;
+        }
         if (lane == 0) {
             atomicAdd(&s_tot, cands);
             __threadfence_block();
@@ -582,7 +592,7 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
             }
         }
     };
-    if (s >= s1) {        // wavefront-uniform
+    if (s >= s1) {        // wavefront-uniform (WPS = 4: workgroup-uniform)
         leave(0u);
         return;
     }
@@ -593,12 +603,23 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
     const float nmax = __uint_as_float(scal[8]), epsmax = __uint_as_float(scal[9]), l1mmax = __uint_as_float(scal[10]);
     bool bad = (scal[1] != 0u) || !(nx <= 3.0e38f);
     const bool zero_map = scal[SLI_NONZERO] == 0u;       // sl_select_kernel: every node ties, node 0 wins
-    float m = __uint_as_float(0x7F800000u);
-    for (int i = lane; i < ntl; i += 64) {
+    // the sample's tile minima: up to 1024 of them (a 128 x 128 map) stay in registers for the candidate pass below -- 16
+    // loads in flight once instead of one dependent load per 64 tiles twice over
+    constexpr int TV = 16;
+    const float inf = __uint_as_float(0x7F800000u);
+    float tv[TV];
+#pragma unroll
+    for (int i = 0; i < TV; ++i)
+        tv[i] = i * 64 + lane < ntl ? tm[i * 64 + lane] : inf;
+    float m = inf;
+#pragma unroll
+    for (int i = 0; i < TV; ++i)
+        m = tv[i] < m ? tv[i] : m;
+    for (int i = TV * 64 + lane; i < ntl; i += 64) {
         const float v = tm[i];
         m = v < m ? v : m;
     }
-    m = sl_min32_dpp(m);                                 // (entries are never NaN: sl_k64_kernel's fminf)
+    m = sl_min32_dpp(m);                                 // (entries are never NaN: the contraction kernels' fminf)
     m = fminf(__shfl(m, 31), __shfl(m, 63));
     // T_s as in sl_select_kernel (integer contraction, fp32 epilogue)
     float ea = c_g1 * (nmax + nx);
@@ -628,11 +649,20 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
         d0 = __shfl(d0, 0);
         best = vsom_key(d0, 0u);
     }
-    unsigned ntiles = 0;
+    unsigned ntiles = 0, item = 0;
     if (!bad && !zero_map && !nan0) {
+#pragma unroll 1
         for (int t0 = 0; t0 < ntl; t0 += 64) {
-            const int t = t0 + lane;
-            u64 hm = __ballot(t < ntl && tm[t] <= thr);
+            const int t = t0 + lane, ti = t0 >> 6;
+            float tval = inf;
+            if (ti < TV) {
+#pragma unroll
+                for (int i = 0; i < TV; ++i)             // (a register array indexed by a loop counter: a select chain)
+                    tval = ti == i ? tv[i] : tval;
+            } else if (t < ntl) {
+                tval = tm[t];
+            }
+            u64 hm = __ballot(tval <= thr);
             ntiles += (unsigned)__popcll(hm);
             if (ntiles > tmax) {
                 bad = true;
@@ -644,6 +674,8 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
                 const int nbase = 32 * (tl >> 1) + 4 * (tl & 1);
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
+                    if (WPS != 1 && (int)(item++ % WPS) != wave)
+                        continue;                        // another wavefront's item
                     const int j = pass * 8 + grp;
                     const int node = nbase + (j & 3) + 8 * (j >> 2);
                     const bool ok = node < N;
@@ -654,8 +686,8 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
             }
         }
     }
-    if (bad) {   // wavefront-uniform
-        if (lane == 0) {
+    if (bad) {   // wavefront-uniform (WPS = 4: every wavefront reaches the same verdict)
+        if (lane == 0 && (WPS == 1 || wave == 0)) {
             const unsigned slot = atomicAdd(redo_count, 1u);
             redo_list[slot] = s;
             atomicAdd(&stats[0], 1u);
@@ -666,6 +698,15 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
     for (int off = 32; off >= 8; off >>= 1) {
         const u64 o = __shfl_xor(best, off);
         best = o < best ? o : best;
+    }
+    if (WPS != 1) {
+        if (lane == 0)
+            s_best[wave] = best;
+        __syncthreads();
+        if (wave != 0)
+            return;
+        for (int w = 1; w < 4; ++w)
+            best = s_best[w] < best ? s_best[w] : best;
     }
     leave(16u * ntiles);
     if (lane == 0) {
@@ -681,7 +722,8 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
 
 // host side ------------------------------------------------------------------------------------
 int launch_bmu_full_exact_list(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount, const SlFeedback *fb);
-int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag, bool gless);   // vsom_sl_i8.hip
+int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag, int plan);   // vsom_sl_i8.hip
+int sl_i8_plan(vsom_ctx *c, size_t s0, size_t s1);
 
 static int launch_bmu_full_shortlist_clr(vsom_ctx *c, size_t s0, size_t s1);
 
@@ -696,8 +738,10 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     // for chunks of small non-negative integers (MNIST pixels), three for any other data -- which of the two is a
     // device-side fact of the staged chunk (`xflag`) that the kernels read; nothing is decided here
     const bool i8 = c->xpitch <= 4096;
-    // at most 64 contracted columns: tile minima only, no B x N matrix (sl_k64_kernel + sl_pick_kernel)
-    const bool gless = i8 && ((c->cc_valid ? c->cpitch : c->xpitch) + 63) / 64 == 1;
+    // no B x N matrix where the contraction kernels keep 16-node tile minima only (rows of at most 64 values; big
+    // problems of at most 960 contracted columns): sl_pick_kernel refines
+    const int plan = i8 ? sl_i8_plan(c, s0, s1) : 0;
+    const bool gless = plan != 0;
     const size_t ldg = ((size_t)c->N + 127) / 128 * 128;
     const size_t need = gless ? 0 : nrows * ldg;
     if (need > c->sl_cap) {
@@ -738,7 +782,7 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     const double u = 5.9604644775390625e-08;   // 2^-24
     const double g2 = ((double)c->D / 8.0 + 10.0) * u;
     if (i8) {
-        int rc = launch_sl_i8(c, s0, s1, ldg, ntm, scal, xflag, gless);
+        int rc = launch_sl_i8(c, s0, s1, ldg, ntm, scal, xflag, plan);
         if (rc)
             return rc;
     } else {
@@ -770,8 +814,13 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     const double g1 = ((double)GK + K / GK + 3.0) * u;
     // integer contraction: |G - (|M|^2 - 2<x,M>)| <= 2 (e_s L1Mmax + l1eff_s eps_max) + 5.1u (nMmax + |x|^2) + 2^-7 eps_max
     // (vsom_sl_i8.hip; 3.1u with the fp64 epilogue, 5.1u with the two-rounding fp32 one of the uint8 kind)
-    if (gless)
-        hipLaunchKernelGGL(sl_pick_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N,
+    if (gless && c->D <= 64)
+        hipLaunchKernelGGL(sl_pick_kernel<1>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N,
+                           (int)c->D, c->sl_tmin, (int)ntm, scal, (float)(5.5 * u), (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2,
+                           c->sl_list, scal + 4, 64u, (const float *)c->sl_l1, (unsigned)c->Bcap, 2.0f, (const unsigned *)xflag,
+                           (const float *)c->sl_nrm);
+    else if (gless)
+        hipLaunchKernelGGL(sl_pick_kernel<4>, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N,
                            (int)c->D, c->sl_tmin, (int)ntm, scal, (float)(5.5 * u), (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2,
                            c->sl_list, scal + 4, 64u, (const float *)c->sl_l1, (unsigned)c->Bcap, 2.0f, (const unsigned *)xflag,
                            (const float *)c->sl_nrm);

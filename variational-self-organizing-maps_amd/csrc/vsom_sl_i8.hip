@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256, XD == 1 ? 3 : 2) void sl_gemm_i8_kernel(const 
 #define RT_S 256
 #define RT_N 128
 #define RING_BYTES 147456      // max(3 x 40960, 2 x 73728)
-template <int XD, int WM, int NS, bool FAST>
+template <int XD, int WM, int NS, bool FAST, bool GLESS = false>
 __device__ __forceinline__ void sl_gemm_i8_ring_body(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
                                                      const signed char *__restrict__ q, int N, int kp, int kp8,
                                                      const float *__restrict__ nrm, const double *__restrict__ qscale,
@@ -895,11 +895,55 @@ __device__ __forceinline__ void sl_gemm_i8_ring_body(const signed char *__restri
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
-                            acc[pl + l][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pl][i], b[l][j], acc[pl + l][i][j], 0, 0, 0);
+                            acc[pl + l][i][j] = GLESS      // (G-less: nodes along the accumulator registers, samples along the lanes)
+                                                    ? __builtin_amdgcn_mfma_i32_32x32x32_i8(b[l][j], a[pl][i], acc[pl + l][i][j], 0, 0, 0)
+                                                    : __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pl][i], b[l][j], acc[pl + l][i][j], 0, 0, 0);
         }
     }
     if (dbg & 2)
         return;
+    if (GLESS) {
+        // No G (FAST only: K <= 960).  As sl_k64_kernel below: with the tile transposed a lane's minimum over the 16
+        // registers of a 32 x 32 block is ONE sample's minimum over 16 nodes -- no cross-lane step, no B x N matrix (268 MB
+        // at C3, a quarter of this kernel's time to write and most of the refinement's to read): tmin[sample][tile], tile
+        // t = 2 (node block of 32) + (lane >> 5) = the nodes 32 (t >> 1) + 4 (t & 1) + {0..3, 8..11, 16..19, 24..27}, and
+        // sl_pick_kernel evaluates every node of the tiles within the bound in the reference's order.  The 128 nodes'
+        // constants go through the ring's memory (free once every wavefront has left the K loop).
+        float *s_nrm = reinterpret_cast<float *>(ring);
+        int4 *s_f = reinterpret_cast<int4 *>(ring + 512);
+        __syncthreads();
+        if (tid < RT_N) {
+            const int n = nbase + tid;
+            s_nrm[tid] = n < N ? nrm[n] : __uint_as_float(0x7F800000u);     // past N: +inf (f = 0): never a minimum
+            s_f[tid] = n < N ? qfast[n] : make_int4(0, 0, 0, 0);
+        }
+        float ts[2];
+        int srow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            srow[i] = sbase + wm * 64 + i * 32 + lr;
+            ts[i] = XD == 3 ? xscale[srow[i] < s1 ? srow[i] : s1 - 1] : 1.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nblk = nbase + wn * 64 + j * 32;   // first node of this block (wavefront-uniform)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float mn = __uint_as_float(0x7F800000u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int nl = wn * 64 + j * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+                    const float g = XD == 1 ? sl_i8_value_fast(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], s_f[nl], s_nrm[nl])
+                                            : sl_i8_value_fast3(acc[0][i][j][r], acc[1][i][j][r], acc[2][i][j][r], s_f[nl], ts[i], s_nrm[nl]);
+                    mn = fminf(mn, g);                   // a NaN (a NaN row of the map) never replaces the minimum
+                }
+                if (srow[i] < s1 && nblk < N)
+                    tmin[(size_t)(srow[i] - s0) * ntm + (nblk >> 4) + lh] = mn;
+            }
+        }
+        return;
+    }
     // epilogue; a wavefront's 64 columns are exactly one 64-node tile of `tmin`.  Three phases, so that no load is pending
     // while values are formed and stored: with the constants loaded under `if (col < N)` and a conditional store behind
     // every value, hipcc put `s_waitcnt vmcnt(0)` in front of EVERY value -- 64 times the latency of the previous store per
@@ -998,6 +1042,26 @@ __global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_kernel(const signed ch
         sl_gemm_i8_ring_body<1, 4, 3, true>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
     else
         sl_gemm_i8_ring_body<1, 4, 3, false>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, qscale, qcorr, xscale, G, ldg, tmin, ntm, ring, qfast);
+}
+
+// the same without G (sl_pick_kernel refines): K <= 960 contracted columns
+__global__ __launch_bounds__(512, 1) void sl_gemm_i8_ring_gless_kernel(const signed char *__restrict__ xi, size_t xplane, int s0, int s1,
+                                                                       const signed char *__restrict__ q, int N, int kp,
+                                                                       const unsigned *__restrict__ kp_dev, int kp8,
+                                                                       const float *__restrict__ nrm, const float *__restrict__ xscale,
+                                                                       float *__restrict__ tmin, int ntl,
+                                                                       const unsigned *__restrict__ xflag,
+                                                                       const int4 *__restrict__ qfast, unsigned *__restrict__ scal)
+{
+    if (kp_dev)
+        kp = (int)kp_dev[2];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64)
+        sl_fold_maxima(scal);
+    extern __shared__ __attribute__((aligned(1024))) signed char ring[];
+    if (xflag[0] != 0u)          // wavefront-uniform (a scalar load)
+        sl_gemm_i8_ring_body<3, 4, 2, true, true>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, nullptr, nullptr, xscale, nullptr, 0, tmin, ntl, ring, qfast);
+    else
+        sl_gemm_i8_ring_body<1, 4, 3, true, true>(xi, xplane, s0, s1, q, N, kp, kp8, nrm, nullptr, nullptr, xscale, nullptr, 0, tmin, ntl, ring, qfast);
 }
 
 // ---- at most 64 contracted columns: no G at all ----------------------------------------------------------------------------
@@ -1186,8 +1250,28 @@ int launch_sl_gather_quant(vsom_ctx *c, size_t B, hipStream_t stream, const int 
 // prepares the int8 images and computes G / tmin for samples [s0, s1) (ldg, ntm as the fp32 path lays them out: 64-node
 // tile minima); scal = the counter set THIS search's select / feedback kernels read (the two sets alternate,
 // vsom_shortlist.hip), already reset
-int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag, bool gless)
+// Which form a search of samples [s0, s1) takes: 0 = G and 64-node tile minima (sl_select_kernel refines), 1 = no G, 16-node
+// tile minima from sl_k64_kernel (at most 64 contracted columns), 2 = no G, from the ring kernel (big problems, K <= 960);
+// 1 and 2 are refined by sl_pick_kernel.  (The attribute is per DEVICE -- a group drives several from one process -- so it
+// is raised on every call, as launch_phase2 does.)
+int sl_i8_plan(vsom_ctx *c, size_t s0, size_t s1)
 {
+    const uint32_t kp8 = ((c->cc_valid ? c->cpitch : c->xpitch) + 63) / 64 * 64;
+    if (kp8 == 64)
+        return 1;
+    const size_t big_tiles = ((size_t)c->N + RT_N - 1) / RT_N * ((s1 - s0 + RT_S - 1) / RT_S);
+    if (kp8 <= 960 && big_tiles >= 1024) {
+        if (hipFuncSetAttribute((const void *)sl_gemm_i8_ring_gless_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                RING_BYTES) == hipSuccess)
+            return 2;
+        (void)hipGetLastError();
+    }
+    return 0;
+}
+
+int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsigned *scal, unsigned *xflag, int plan)
+{
+    const bool gless = plan == 1;
     const bool compact = c->cc_valid;
     const uint32_t kmax = compact ? c->cpitch : c->xpitch;
     const uint32_t kp8 = (kmax + 63) / 64 * 64;
@@ -1234,6 +1318,14 @@ int launch_sl_i8(vsom_ctx *c, size_t s0, size_t s1, size_t ldg, size_t ntm, unsi
         dim3 grid((unsigned)((c->N + K64_NB * 32 - 1) / (K64_NB * 32)), (unsigned)((s1 - s0 + 128 * K64_SB - 1) / (128 * K64_SB)));
         hipLaunchKernelGGL(sl_k64_kernel, grid, dim3(256), 0, c->stream, c->sl_xi, xplane, (int)s0, (int)s1, c->sl_q, (int)c->N,
                            c->sl_nrm, (const int4 *)c->sl_qfast, xscale, c->sl_tmin, (int)ntm, (const unsigned *)xflag, scal);
+        VSOM_HIP_CHECK(hipGetLastError());
+        return VSOM_OK;
+    }
+    if (plan == 2) {         // the ring kernel without G (ntm = 16-node tiles)
+        dim3 grid((unsigned)((c->N + RT_N - 1) / RT_N), (unsigned)((s1 - s0 + RT_S - 1) / RT_S));
+        hipLaunchKernelGGL(sl_gemm_i8_ring_gless_kernel, grid, dim3(512), RING_BYTES, c->stream, c->sl_xi, xplane, (int)s0, (int)s1,
+                           c->sl_q, (int)c->N, (int)kmax, kp_dev, (int)kp8, c->sl_nrm, xscale, c->sl_tmin, (int)ntm,
+                           (const unsigned *)xflag, (const int4 *)c->sl_qfast, scal);
         VSOM_HIP_CHECK(hipGetLastError());
         return VSOM_OK;
     }
