@@ -1260,7 +1260,7 @@ int sl_i8_plan(vsom_ctx *c, size_t s0, size_t s1)
     if (kp8 == 64)
         return 1;
     const size_t big_tiles = ((size_t)c->N + RT_N - 1) / RT_N * ((s1 - s0 + RT_S - 1) / RT_S);
-    if (kp8 <= 960 && big_tiles >= 1024) {
+    if (kp8 <= 960 && big_tiles >= 256) {
         if (hipFuncSetAttribute((const void *)sl_gemm_i8_ring_gless_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 RING_BYTES) == hipSuccess)
             return 2;
