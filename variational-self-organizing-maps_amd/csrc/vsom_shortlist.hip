@@ -575,10 +575,11 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
     }
     __syncthreads();      // WPS = 1: the only barrier: every wavefront passes it before any leaves
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = WPS == 1 ? s0 + blockIdx.x * 4 + wave : s0 + (int)blockIdx.x;
+    const int s = s0 + (int)blockIdx.x * (4 / WPS) + wave / WPS;   // WPS wavefronts per sample, 4 / WPS samples per workgroup
+    const int sub = wave % WPS;
     auto leave = [&](unsigned cands) {
         if (WPS != 1) {
-            if (threadIdx.x == 0 && cands)
+            if (lane == 0 && sub == 0 && cands)
                 atomicAdd(&stats[12 + 32 * (blockIdx.x & 31)], cands);
             return;
         }
@@ -592,8 +593,8 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
             }
         }
     };
-    if (s >= s1) {        // wavefront-uniform (WPS = 4: workgroup-uniform)
-        leave(0u);
+    if (s >= s1) {        // wavefront-uniform, and uniform over the wavefronts of a sample (WPS > 1: they meet at a barrier
+        leave(0u);        // below; wavefronts that have ended no longer count for it)
         return;
     }
     const float *xr = a.xa + (size_t)s * a.ldx;
@@ -674,7 +675,7 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
                 const int nbase = 32 * (tl >> 1) + 4 * (tl & 1);
 #pragma unroll
                 for (int pass = 0; pass < 2; ++pass) {
-                    if (WPS != 1 && (int)(item++ % WPS) != wave)
+                    if (WPS != 1 && (int)(item++ % WPS) != sub)
                         continue;                        // another wavefront's item
                     const int j = pass * 8 + grp;
                     const int node = nbase + (j & 3) + 8 * (j >> 2);
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
         }
     }
     if (bad) {   // wavefront-uniform (WPS = 4: every wavefront reaches the same verdict)
-        if (lane == 0 && (WPS == 1 || wave == 0)) {
+        if (lane == 0 && sub == 0) {
             const unsigned slot = atomicAdd(redo_count, 1u);
             redo_list[slot] = s;
             atomicAdd(&stats[0], 1u);
@@ -703,10 +704,10 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
         if (lane == 0)
             s_best[wave] = best;
         __syncthreads();
-        if (wave != 0)
+        if (sub != 0)
             return;
-        for (int w = 1; w < 4; ++w)
-            best = s_best[w] < best ? s_best[w] : best;
+        for (int w = 1; w < WPS; ++w)
+            best = s_best[wave + w] < best ? s_best[wave + w] : best;
     }
     leave(16u * ntiles);
     if (lane == 0) {
@@ -820,7 +821,7 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
                            c->sl_list, scal + 4, 64u, (const float *)c->sl_l1, (unsigned)c->Bcap, 2.0f, (const unsigned *)xflag,
                            (const float *)c->sl_nrm);
     else if (gless)
-        hipLaunchKernelGGL(sl_pick_kernel<4>, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N,
+        hipLaunchKernelGGL(sl_pick_kernel<2>, dim3((unsigned)((nrows + 1) / 2)), dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N,
                            (int)c->D, c->sl_tmin, (int)ntm, scal, (float)(5.5 * u), (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2,
                            c->sl_list, scal + 4, 64u, (const float *)c->sl_l1, (unsigned)c->Bcap, 2.0f, (const unsigned *)xflag,
                            (const float *)c->sl_nrm);
