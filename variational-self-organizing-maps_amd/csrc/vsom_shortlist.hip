@@ -553,9 +553,10 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
 // (32 (t >> 1) + 4 (t & 1) + {0..3, 8..11, 16..19, 24..27}); every node of every tile with tmin <= row minimum + T_s
 // (the bound of sl_select_kernel, same terms) is evaluated in the reference's order, 8 lanes per node, node 0 always.
 // More than `tmax` such tiles, or a sample / map the bound does not cover: the redo list.
-// WPS = wavefronts per sample: 1 for short rows (four samples per workgroup); 4 for long ones (a workgroup per sample, the
-// (tile, half) items dealt round robin: a 784-element row is seven dependent load batches per evaluation, and ~21 candidate
-// nodes are three passes of eight for one wavefront -- 69 us at C3 -- but one pass for four).
+// WPS = wavefronts per sample: 1 for short rows (four samples per workgroup); 2 for long ones (the (tile, half) items dealt
+// round robin to the sample's wavefronts: a 784-element row is seven dependent load batches per evaluation, and the ~21
+// candidate nodes of a C3 sample are three passes of eight for one wavefront.  Measured at C3: 69 us with one wavefront
+// per sample, 58 with four -- a workgroup per sample is 2.7 rounds of resident workgroups -- 53 with two).
 template <int WPS>
 __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1, int N, int D,
                                                       const float *__restrict__ tmin, int ntl,
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
             }
         }
     }
-    if (bad) {   // wavefront-uniform (WPS = 4: every wavefront reaches the same verdict)
+    if (bad) {   // wavefront-uniform (every wavefront of a sample reaches the same verdict)
         if (lane == 0 && sub == 0) {
             const unsigned slot = atomicAdd(redo_count, 1u);
             redo_list[slot] = s;
