@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256) void sl_select_kernel(DistArgs a, int s0, int 
 // (32 (t >> 1) + 4 (t & 1) + {0..3, 8..11, 16..19, 24..27}); every node of every tile with tmin <= row minimum + T_s
 // (the bound of sl_select_kernel, same terms) is evaluated in the reference's order, 8 lanes per node, node 0 always.
 // More than `tmax` such tiles, or a sample / map the bound does not cover: the redo list.
-// WPS = wavefronts per sample: 1 for short rows (four samples per workgroup); 2 for long ones (the (tile, half) items dealt
+// WPS = wavefronts per sample: 1 for short rows (four samples per workgroup); 2 or 4 for long ones (the (tile, half) items dealt
 // round robin to the sample's wavefronts: a 784-element row is seven dependent load batches per evaluation, and the ~21
 // candidate nodes of a C3 sample are three passes of eight for one wavefront.  Measured at C3: 69 us with one wavefront
 // per sample, 58 with four -- a workgroup per sample is 2.7 rounds of resident workgroups -- 53 with two).
@@ -818,6 +818,11 @@ int launch_bmu_full_shortlist(vsom_ctx *c, size_t s0, size_t s1)
     // (vsom_sl_i8.hip; 3.1u with the fp64 epilogue, 5.1u with the two-rounding fp32 one of the uint8 kind)
     if (gless && c->D <= 64)
         hipLaunchKernelGGL(sl_pick_kernel<1>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N,
+                           (int)c->D, c->sl_tmin, (int)ntm, scal, (float)(5.5 * u), (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2,
+                           c->sl_list, scal + 4, 64u, (const float *)c->sl_l1, (unsigned)c->Bcap, 2.0f, (const unsigned *)xflag,
+                           (const float *)c->sl_nrm);
+    else if (gless && nrows < 4096)     // few samples (a rank's share of a chunk): a workgroup per sample (0.109 -> 0.089 ms at 512)
+        hipLaunchKernelGGL(sl_pick_kernel<4>, dim3((unsigned)nrows), dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N,
                            (int)c->D, c->sl_tmin, (int)ntm, scal, (float)(5.5 * u), (float)(2.1 * g2), c->lastbmu, c->sqres, scal + 2,
                            c->sl_list, scal + 4, 64u, (const float *)c->sl_l1, (unsigned)c->Bcap, 2.0f, (const unsigned *)xflag,
                            (const float *)c->sl_nrm);
