@@ -1,3 +1,4 @@
+# Development: everything profiles/ holds for a round, in one GPU call (profile set, A/B records, rank simulation, reference-API run, default bench line).
 cd $GRAFT_REPO_ROOT
 bash tools/prof_all.sh
 bash tools/exp/r5_records.sh

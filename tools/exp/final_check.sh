@@ -1,3 +1,4 @@
+# Development: the validation run before a commit of kernel changes (full GPU suite, a 400-case search sweep, C4 profiles, the default bench line).
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r5fin
