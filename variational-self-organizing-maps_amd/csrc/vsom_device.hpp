@@ -106,7 +106,9 @@ __device__ __forceinline__ float vsom_group_acc_block(float acc, const float *xa
     return acc;
 }
 
-template <bool CLR>
+// BIG = elements per class fetched together on long rows (14; 28 where the sample row sits in LDS and only the model row's
+// loads need registers: sl_pick_kernel).
+template <bool CLR, int BIG = 14>
 __device__ __forceinline__ float vsom_group_dist_lat(const float *xa, const float *xb,
                                                      const float *ma, const float *mb, int L, int k)
 {
@@ -115,7 +117,10 @@ __device__ __forceinline__ float vsom_group_dist_lat(const float *xa, const floa
     float acc = 0.f;
     for (int base = 0; base < ni;) {
         const int left = ni - base;
-        if (left > 16) {          // long rows: 14 at a time, like vsom_group_dist (49 at a time measured slower)
+        if (left > BIG + 2) {     // long rows: 14 at a time, like vsom_group_dist (49 at a time measured slower)
+            acc = vsom_group_acc_block<CLR, BIG>(acc, xa, xb, ma, mb, k, base, BIG);
+            base += BIG;
+        } else if (BIG > 16 && left > 16) {
             acc = vsom_group_acc_block<CLR, 14>(acc, xa, xb, ma, mb, k, base, 14);
             base += 14;
         } else if (left > 4) {

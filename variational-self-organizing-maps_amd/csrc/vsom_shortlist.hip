@@ -570,14 +570,24 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
     // candidate statistics: one global atomic per workgroup (WPS = 1: the last of its four wavefronts to arrive sends the sum)
     __shared__ unsigned s_tot, s_arr;
     __shared__ u64 s_best[4];
+    // long rows (WPS > 1, at most 1024 values): the sample's row in LDS -- the evaluations then fetch model rows only, 28
+    // elements per class at a time instead of 14 + 14
+    constexpr int XL = WPS == 1 ? 4 : 1024;
+    __shared__ __attribute__((aligned(16))) float s_x[WPS == 1 ? 1 : 4 / WPS][XL];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = s0 + (int)blockIdx.x * (4 / WPS) + wave / WPS;   // WPS wavefronts per sample, 4 / WPS samples per workgroup
+    const int sub = wave % WPS;
+    const bool xlds = WPS != 1 && a.L <= XL;             // kernel-uniform
+    if (xlds && s < s1) {
+        const float4 *src = reinterpret_cast<const float4 *>(a.xa + (size_t)s * a.ldx);
+        for (int i = sub * 64 + lane; i < ((a.L + 3) >> 2); i += 64 * WPS)     // rows are zero padded to a multiple of 32
+            reinterpret_cast<float4 *>(s_x[wave / WPS])[i] = src[i];
+    }
     if (threadIdx.x == 0) {
         s_tot = 0u;
         s_arr = 0u;
     }
     __syncthreads();      // WPS = 1: the only barrier: every wavefront passes it before any leaves
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = s0 + (int)blockIdx.x * (4 / WPS) + wave / WPS;   // WPS wavefronts per sample, 4 / WPS samples per workgroup
-    const int sub = wave % WPS;
     auto leave = [&](unsigned cands) {
         if (WPS != 1) {
             if (lane == 0 && sub == 0 && cands)
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
         leave(0u);        // below; wavefronts that have ended no longer count for it)
         return;
     }
-    const float *xr = a.xa + (size_t)s * a.ldx;
+    const float *xr = xlds ? s_x[wave / WPS] : a.xa + (size_t)s * a.ldx;
     const float *tm = tmin + (size_t)(s - s0) * ntl;
     // |x|^2 from the quantisation pass (plane 4 of l1x), the map-wide maxima from sl_k64_kernel (scal[8..10])
     const float nx = l1x[4 * (size_t)lstride + s];
@@ -607,7 +617,7 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
     const bool zero_map = scal[SLI_NONZERO] == 0u;       // sl_select_kernel: every node ties, node 0 wins
     // the sample's tile minima: up to 1024 of them (a 128 x 128 map) stay in registers for the candidate pass below -- 16
     // loads in flight once instead of one dependent load per 64 tiles twice over
-    constexpr int TV = 16;
+    constexpr int TV = WPS == 1 ? 4 : 16;                // (short rows: small maps' 256 tiles; fewer registers, more wavefronts)
     const float inf = __uint_as_float(0x7F800000u);
     float tv[TV];
 #pragma unroll
@@ -681,7 +691,9 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
                     const int j = pass * 8 + grp;
                     const int node = nbase + (j & 3) + 8 * (j >> 2);
                     const bool ok = node < N;
-                    const float d = vsom_group_dist_lat<false>(xr, xr, a.ma + (size_t)(ok ? node : 0) * a.ldm, a.ma, a.L, k);
+                    const float *mrow = a.ma + (size_t)(ok ? node : 0) * a.ldm;
+                    const float d = xlds ? vsom_group_dist_lat<false, 28>(s_x[wave / WPS], s_x[wave / WPS], mrow, a.ma, a.L, k)
+                                         : vsom_group_dist_lat<false>(xr, xr, mrow, a.ma, a.L, k);
                     const u64 key = ok ? vsom_key(d, (unsigned)node) : ~0ull;
                     best = key < best ? key : best;
                 }
