@@ -570,3 +570,35 @@ def test_short_rows_search_with_retired_columns(kind):
     idx, dist = _run(ctx, capi.BMU_SHORTLIST)
     assert beq(idx, lb_o) and beq(dist, sq_o), kind + " trained"
     ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["u8", "float"])
+def test_sharded_search_ranges_equal_the_whole_search(kind):
+    """A rank of the strong split searches samples [s0, s1) with s0 > 0 (vsom_batch_phase1_async): at C3's map size three
+    ragged ranges (each large enough for the G-less ring kernel) must give the indices and distances of one search over the
+    whole chunk and of the exact-order kernel."""
+    W = H = 128
+    J, B = 784, 2048
+    X = gen.mnist_like(B, 3, J)
+    if kind == "float":
+        X = (X / np.float32(255)).astype(np.float32)
+        init = gen.random_map(W * H, J, 42).astype(np.float32)
+    else:
+        init = (gen.random_map(W * H, J, 42) * np.float32(100) + np.float32(100)).astype(np.float32)
+    ctx = vsom_amd.Context(W, H, J)
+    ctx.set_state(map=init)
+    ctx.upload_chunk(X)
+    i_e, d_e = _run(ctx, capi.BMU_EXACT)
+    ctx.set_bmu_mode(capi.BMU_AUTO)
+    ctx.upload_chunk(X)
+    ctx.batch_phase1_async(0, B, True)
+    ctx.synchronize()
+    i_w, d_w = ctx.get_last_bmu(), ctx.get_sqres()
+    ctx.upload_chunk(X)
+    for a, b in ((0, 700), (700, 1500), (1500, B)):
+        ctx.batch_phase1_async(a, b, True)
+    ctx.synchronize()
+    i_r, d_r = ctx.get_last_bmu(), ctx.get_sqres()
+    assert beq(i_w, i_e) and beq(d_w, d_e), kind
+    assert beq(i_r, i_e) and beq(d_r, d_e), kind
+    ctx.close()
