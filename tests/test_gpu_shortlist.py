@@ -45,6 +45,9 @@ CASES = [
     ("gless_u8_d48_n1295", 37, 35, 48, 333, "mnist"),
     ("gless_d64", 40, 40, 64, 500, "blobs"),
     ("gless_d20_n1023", 33, 31, 20, 150, "blobs"),
+    # the G-less ring kernel (>= 256 tiles of 256 x 128) with ragged edges: 9000 nodes = 70.3 tiles, 1000 samples = 3.9
+    ("ring_gless_ragged_u8", 100, 90, 300, 1000, "mnist"),
+    ("ring_gless_ragged_general", 100, 90, 200, 1000, "blobs"),
 ]
 
 
