@@ -486,6 +486,10 @@ def _sl_sweep_cases(n, seed):
         W, H = int(rs.randint(6, 72)), int(rs.randint(6, 72))
         J = int(rs.choice([rs.randint(2, 65), rs.randint(2, 65), rs.randint(65, 140)]))      # mostly the G-less form (<= 64)
         B = int(rs.choice([rs.randint(1, 130), rs.randint(130, 700)]))
+        if i % 6 == 5:       # large enough for the G-less ring kernel (>= 256 tiles of 256 x 128), ragged edges
+            W, H = int(rs.randint(90, 129)), int(rs.randint(90, 129))
+            J = int(rs.randint(65, 400))
+            B = int(rs.randint(600, 1500))
         kind = str(rs.choice(["u8", "u8_sparse", "float", "float_sparse", "tiny", "huge", "mixed_scales"]))
         mapk = str(rs.choice(["random", "trained", "duplicates", "offset"]))
         out.append((f"sl{i}_{W}x{H}x{J}_B{B}_{kind}_{mapk}", W, H, J, B, kind, mapk, int(rs.randint(1, 1 << 30))))
