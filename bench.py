@@ -377,10 +377,11 @@ def main():
     # the staging kernels of chunk i+1 (rows, live columns, int8 images: map-independent) are enqueued right after the
     # epoch of chunk i and run beside its chains; the step then starts with a commit that launches nothing
     pipelined = (not online and not sharded and args.host_chunks == "off" and not args.no_stage_ahead)
+    mode = {"pipelined": pipelined}              # (switched off for the like-for-like figure `staged_in_step` below)
 
     def step(sp, i):
         with torch.cuda.stream(stream):
-            if pipelined:
+            if mode["pipelined"]:
                 ctx.commit_chunk()                                   # chunk i (staged during step i-1)
                 eng._bind_chunk()
                 trainer.epoch(sigma, is_first)
@@ -416,8 +417,8 @@ def main():
     # per-phase breakdown (`kernel_ms_per_step`)
     dominant = "online" if online else "update"
 
-    def timed(sp, nwarm, nsteps, groups=(dominant,)):
-        if pipelined:
+    def timed(sp, nwarm, nsteps, groups=(dominant,), keep_pending=False):
+        if mode["pipelined"]:
             ctx.stage_next_device(sp.own[0].data_ptr(), sp.own[0].shape[0])   # the chunk of step 0
         for i in range(nwarm):
             step(sp, i)
@@ -439,6 +440,13 @@ def main():
         dt = time.perf_counter() - t0
         tm = ctx.get_timing(reset=True)
         ctx.enable_timing(False)
+        if mode["pipelined"] and not keep_pending:
+            # the context still holds step nsteps's chunk as "next" (a pointer into sp.own, possibly staged ahead): swap in
+            # an empty one, so that the caller may free sp.own
+            with torch.cuda.stream(stream):
+                ctx.stage_next_device(0, 0)
+                ctx.commit_chunk()
+            torch.cuda.synchronize()
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -451,6 +459,12 @@ def main():
     dt, timing = timed(split, args.warmup, args.steps)
     mse = float(ctx.get_mse())
     sl_stats = ctx.shortlist_stats() if not online else None
+    # like for like with rounds 1-4 and BASELINE: the same steps with every chunk staged at the start of its own step
+    dt_in_step = None
+    if pipelined:
+        mode["pipelined"] = False
+        dt_in_step, _ = timed(split, 2, args.steps)
+        mode["pipelined"] = True
     bsteps = max(1, min(args.steps, 10))
     _, breakdown = timed(split, 1, bsteps, groups=capi.TIMER_NAMES)      # every group timed: the per-phase figures
 
@@ -580,13 +594,19 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(dt / steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": split.kind if sharded else "weak",
+            # the split this command line applies as N grows (the driver compares the per-N lines of ONE command): strong for
+            # the batch path (BASELINE config 3: the 4096-row chunk sharded), weak for the online path (replicas)
+            "scaling": "weak" if online else args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "update_arithmetic": arith,
             "staging": ("chunk i+1 staged beside the chains of chunk i (vsom_stage_next_device + vsom_commit_chunk; every step "
                         "still stages exactly one chunk)" if pipelined else "every chunk staged at the start of its own step"),
+            "staged_in_step": ({"value": round(steps * units_of(split) / dt_in_step, 3),
+                                "ms_per_step": round(dt_in_step / steps * 1e3, 4),
+                                "note": "the same steps with every chunk staged at the start of its own step (--no-stage-ahead: "
+                                        "how rounds 1-4 and the BENCH_r01-r04 lines were timed)"} if dt_in_step else None),
             "backend": ({"nccl": "nccl (RCCL)", "gloo": "gloo (CPU rehearsal of the N > 1 flow, not RCCL)"}[backend]
                         if backend else "none (1 GPU)"),
             "collective_ranks": coll_ranks,

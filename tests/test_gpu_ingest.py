@@ -154,6 +154,51 @@ def test_chunks_staged_beside_the_running_epoch_match_oracle(source, tr, W):
             hip.hipFree(b)
 
 
+def test_search_between_staged_ahead_prefetch_and_commit_is_refused():
+    """Once the next chunk is staged ahead its rows sit in the staged-row buffers while B / lastBMU still describe the
+    current chunk: every entry point that reads the rows must refuse (VSOM_ERR_INVALID) until vsom_commit_chunk -- also
+    when the staged-ahead chunk has been abandoned for another one in the meantime -- and the committed chunk then
+    trains like an uploaded one."""
+    W = H = 48
+    J = 196
+    xs = [gen.mnist_like(1100, seed=70 + i, dim=J) for i in range(3)]
+    init = (gen.random_map(W * H, J, seed=42) * np.float32(100) + np.float32(100)).astype(np.float32)
+    orc = po.OracleSom(W, H, J, po.STANDARD)
+    orc.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, po.STANDARD)
+    ctx.set_state(map=init)
+    bufs = []
+    for x in xs:
+        pb = capi.PinnedBuffer(x.shape)
+        pb.array[...] = x
+        bufs.append(pb)
+    ctx.upload_chunk(xs[0])
+    ctx.batch_epoch_async(10.0, True)
+    ctx.prefetch_chunk(bufs[1].array)            # staged beside the chains of chunk 0
+    lb = np.zeros(1100, np.uint64)
+    orc.batch_epoch(xs[0], lb, 10.0, True, nthreads=16)
+    assert (ctx.get_last_bmu() == lb).all()       # results of the current chunk stay readable
+    for call in (ctx.bmu_batch, lambda: ctx.batch_epoch_async(9.0, False), lambda: ctx.train_online_chunk(0.1, 3.0, capi.EXPONENTIAL)):
+        with pytest.raises(capi.VsomError, match="commit"):
+            call()
+    ctx.get_mse()                                 # (an entry point in between: the next prefetch cannot stage ahead)
+    ctx.prefetch_chunk(bufs[2].array)            # abandons chunk 1, whose rows still sit in the buffers
+    with pytest.raises(capi.VsomError, match="commit"):
+        ctx.bmu_batch()
+    ctx.commit_chunk()
+    idx, _ = ctx.bmu_batch()
+    mse_g = ctx.batch_epoch(9.0, True)
+    lb = np.zeros(1100, np.uint64)
+    mse_o = orc.batch_epoch(xs[2], lb, 9.0, True, nthreads=16)
+    assert (idx == lb).all() and (ctx.get_last_bmu() == lb).all()
+    assert np.float32(mse_g) == np.float32(mse_o)
+    st = ctx.get_state()
+    assert (_bits(st["map"]) == _bits(orc.map)).all() and (_bits(st["sigma"]) == _bits(orc.sigma)).all()
+    ctx.close()
+    for b in bufs:
+        b.free()
+
+
 def test_commit_without_prefetch_is_an_error():
     ctx = vsom_amd.Context(4, 4, 8)
     with pytest.raises(capi.VsomError):

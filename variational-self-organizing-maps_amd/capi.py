@@ -65,6 +65,33 @@ def build(force=False):
     return _INTREE
 
 
+def hip_runtimes():
+    """paths of the libamdhip64 copies mapped into this process (/proc/self/maps)"""
+    found = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                at = line.find("/")
+                if at >= 0 and "libamdhip64.so" in line:
+                    found.add(line[at:].strip())
+    except OSError:
+        pass
+    return sorted(found)
+
+
+def assert_single_hip_runtime(what):
+    """PyTorch's wheel bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Loaded FIRST, it is the one copy
+    libvsom_hip.so binds to as well; loaded AFTER libvsom_hip.so has pulled in /opt/rocm's, the process holds two HIP
+    runtimes: torch streams / tensors handed to the library belong to the other runtime, and RCCL initialises against
+    a runtime that never came up ("no ROCm-capable device is detected" in ncclCommInitAll).  Everything that mixes
+    the two -- dist.HipEngine, Group, bench.py -- calls this and fails with the cause instead."""
+    libs = hip_runtimes()
+    if len(libs) > 1:
+        raise VsomError(f"{what}: two HIP runtimes are mapped into this process ({', '.join(libs)}). "
+                        "Import torch BEFORE the first vsom_amd call (tests/conftest.py and bench.py do), "
+                        "so that libvsom_hip.so binds to the copy torch brings.")
+
+
 _lib = None
 
 
@@ -455,6 +482,8 @@ class Group:
         if devices is not None:
             ndev = len(devices)
             devs = (C.c_int * ndev)(*[int(d) for d in devices])
+        lib()
+        assert_single_hip_runtime("vsom_group_create (RCCL)")
         check(lib().vsom_group_create(C.byref(self._h), int(ndev), devs, int(width), int(height), int(in_len),
                                       int(transform)))
         self.size = int(lib().vsom_group_size(self._h))

@@ -113,11 +113,14 @@ int launch_stage_chunk(vsom_ctx *c, const float *x_dev, size_t B)
     c->xq_valid = false;
     c->xi_valid = false;
     c->rows_free_valid = false;
-    if (c->ahead_valid || c->next_dev_pending) {
-        // a chunk staged ahead is overwritten by this one: the rows are staged anew when it is committed
+    if (c->ahead_rows) {
+        // staging kernels of a chunk staged ahead (adopted or abandoned since) may still be writing the buffers this
+        // staging writes: order behind them.  A chunk staged ahead is overwritten by this one; its rows are staged anew
+        // when it is committed.
         VSOM_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
-        c->ahead_valid = false;
+        c->ahead_rows = false;
     }
+    c->ahead_valid = false;
     bool cc = false, xi = false;
     int rc = stage_chunk_on(c, x_dev, B, c->stream, c->lastbmu, c->cc_idx, c->cc_inv, c->cc_meta, &cc, &xi);
     c->cc_valid = cc;
@@ -148,6 +151,7 @@ int launch_stage_chunk_ahead(vsom_ctx *c, const float *x_dev, size_t B)
     if (rc)
         return rc;
     VSOM_HIP_CHECK(hipEventRecord(c->ev_ahead, c->copy_stream));
+    c->ahead_rows = true;     // until c->stream has waited for ev_ahead (adoption, or the next staging on c->stream)
     c->ahead_valid = true;
     c->ahead_B = B;
     c->ahead_cc = cc;
@@ -159,6 +163,7 @@ int launch_stage_chunk_ahead(vsom_ctx *c, const float *x_dev, size_t B)
 int vsom_adopt_ahead(vsom_ctx *c)
 {
     VSOM_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_ahead, 0));
+    c->ahead_rows = false;
     std::swap(c->lastbmu, c->lastbmu_alt);
     std::swap(c->cc_idx, c->cc_idx_alt);
     std::swap(c->cc_inv, c->cc_inv_alt);

@@ -52,6 +52,16 @@ static inline uint32_t roundup(uint32_t v, uint32_t m) { return (v + m - 1) / m 
             return _rc;                                                \
         (ctx)->rows_free_valid = false;   /* whatever follows may read the staged rows again */ \
     } while (0)
+// Entry points that READ the staged rows (Xs / XP / YP, the gathered rows, the int8 images): once the NEXT chunk has been
+// staged ahead (vsom_prefetch_chunk / vsom_stage_next_device beside a running epoch) those buffers hold the next chunk's
+// rows while B, lastBMU and the compaction record still describe the current one -- a search would silently mix the two.
+// (ahead_rows, not ahead_valid: a staged-ahead chunk that was abandoned for another one has overwritten the rows all the same.)
+#define CHECK_ROWS(ctx)                                                \
+    do {                                                               \
+        if ((ctx)->ahead_rows)                                         \
+            return vsom_fail(VSOM_ERR_INVALID,                         \
+                             "the next chunk is staged ahead over the current chunk's rows: vsom_commit_chunk first"); \
+    } while (0)
 // phase 2 runs beside the side stream's work and joins it at its end
 #define CHECK_CTX_NOJOIN(ctx)                                          \
     do {                                                               \
@@ -559,7 +569,7 @@ int vsom_host_free(void *p)
 // stream, beside the epoch of the current chunk -- when that is possible now (vsom_can_stage_ahead), else at commit
 static int stage_ahead_if_possible(vsom_ctx *c, const float *x_dev, size_t B)
 {
-    c->ahead_valid = false;
+    c->ahead_valid = false;       // (an abandoned ahead staging may still be running: ahead_rows stays set)
     if (!vsom_can_stage_ahead(c, B))
         return VSOM_OK;
     return launch_stage_chunk_ahead(c, x_dev, B);
@@ -668,6 +678,7 @@ static int copy_search_results(vsom_ctx *c, uint64_t *idx, float *dist)
 int vsom_bmu_batch(vsom_ctx *c, uint64_t *idx_out_host, float *dist_out_host)
 {
     CHECK_CTX(c);
+    CHECK_ROWS(c);
     int rc = launch_bmu_full(c, 0, c->B);
     if (rc)
         return rc;
@@ -677,6 +688,7 @@ int vsom_bmu_batch(vsom_ctx *c, uint64_t *idx_out_host, float *dist_out_host)
 int vsom_bmu_local_batch(vsom_ctx *c, uint64_t *idx_out_host, float *dist_out_host)
 {
     CHECK_CTX(c);
+    CHECK_ROWS(c);
     int rc = launch_bmu_local(c, 0, c->B);
     if (rc)
         return rc;
@@ -687,6 +699,7 @@ int vsom_distances(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *rows
                    float *dist_out_host)
 {
     CHECK_CTX(c);
+    CHECK_ROWS(c);
     if (count == 0)
         return VSOM_OK;
     if (!nodes_host || !rows_host || !dist_out_host)
@@ -724,6 +737,7 @@ int vsom_distances(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *rows
 int vsom_bmu_restricted_batch(vsom_ctx *c, uint64_t min_hits, uint64_t *idx_out_host, float *dist_out_host)
 {
     CHECK_CTX(c);
+    CHECK_ROWS(c);
     if (c->B == 0)
         return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
     int rc = launch_bmu_restricted(c, min_hits);
@@ -735,6 +749,7 @@ int vsom_bmu_restricted_batch(vsom_ctx *c, uint64_t min_hits, uint64_t *idx_out_
 int vsom_distances_row(vsom_ctx *c, size_t row, float *dist_out_host)
 {
     CHECK_CTX(c);
+    CHECK_ROWS(c);
     if (row >= c->B || !dist_out_host)
         return vsom_fail(VSOM_ERR_INVALID, "row out of range or null output");
     float *dd = nullptr;
@@ -753,6 +768,8 @@ int vsom_distances_raw(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *
                        int from_map, float *dist_out_host)
 {
     CHECK_CTX(c);
+    if (!from_map)
+        CHECK_ROWS(c);
     if (count == 0)
         return VSOM_OK;
     if (!nodes_host || !vrows_host || !dist_out_host)
@@ -788,6 +805,7 @@ int vsom_distances_raw(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *
 int vsom_batch_phase1_async(vsom_ctx *c, size_t s0, size_t s1, int is_first)
 {
     CHECK_CTX(c);
+    CHECK_ROWS(c);
     if (s0 > s1 || s1 > c->B)
         return vsom_fail(VSOM_ERR_INVALID, "sample range out of bounds");
     return is_first ? launch_bmu_full(c, s0, s1) : launch_bmu_local(c, s0, s1);
@@ -804,6 +822,8 @@ int vsom_batch_finish_async(vsom_ctx *c)
 int vsom_batch_phase2_async(vsom_ctx *c, double sigma, size_t n0, size_t n1)
 {
     CHECK_CTX_NOJOIN(c);
+    if (!c->xq_valid)             // (a further node range of the same epoch works on the transposed chunk it already has)
+        CHECK_ROWS(c);
     if (n0 > n1 || n1 > c->N)
         return vsom_fail(VSOM_ERR_INVALID, "node range out of bounds");
     if (!c->chunk_loaded)   // an EMPTY chunk is legal: the reference's epoch then zeroes the map
@@ -814,6 +834,7 @@ int vsom_batch_phase2_async(vsom_ctx *c, double sigma, size_t n0, size_t n1)
 int vsom_batch_epoch_async(vsom_ctx *c, double sigma, int is_first)
 {
     CHECK_CTX(c);
+    CHECK_ROWS(c);
     if (!c->chunk_loaded)   // an EMPTY chunk is legal: the reference's epoch then zeroes the map
         return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
     if (vsom_tiny_applies(c))

@@ -84,6 +84,10 @@ struct vsom_ctx {
     hipEvent_t ev_rows_free = nullptr, ev_ahead = nullptr;
     bool rows_free_valid = false;   // ev_rows_free belongs to the last enqueued work on this context
     bool ahead_valid = false;       // a chunk is staged ahead (ahead_B rows; its compaction / int8-image state below)
+    // staging kernels of a chunk staged ahead have been launched over the staged-row buffers and `stream` has neither
+    // adopted them nor staged a chunk of its own since (whatever ahead_valid says: the ahead chunk may have been abandoned):
+    // `stream` must wait for ev_ahead before it writes those buffers, and nobody may read the current chunk's rows
+    bool ahead_rows = false;
     size_t ahead_B = 0;
     bool ahead_cc = false, ahead_xi = false;
     const float *next_dev = nullptr;   // vsom_stage_next_device: rows in HBM waiting for vsom_commit_chunk
@@ -167,11 +171,17 @@ struct vsom_ctx {
 // error plumbing -----------------------------------------------------------------------------
 void vsom_set_error(const std::string &msg);
 int vsom_fail(int code, const std::string &msg);
+// (an allocation that does not fit is VSOM_ERR_NOMEM and leaves the context usable: every allocation site drops the old
+// buffer and its capacity first, and the runtime's last-error slot is cleared so that the next hipGetLastError() of a
+// launch sequence does not report it again)
 #define VSOM_HIP_CHECK(expr)                                                             \
     do {                                                                                 \
         hipError_t _e = (expr);                                                          \
-        if (_e != hipSuccess)                                                            \
-            return vsom_fail(VSOM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+        if (_e != hipSuccess) {                                                          \
+            (void)hipGetLastError();                                                     \
+            return vsom_fail(_e == hipErrorOutOfMemory ? VSOM_ERR_NOMEM : VSOM_ERR_HIP,  \
+                             std::string(#expr) + ": " + hipGetErrorString(_e));         \
+        }                                                                                \
     } while (0)
 
 struct TimerScope {

@@ -689,6 +689,9 @@ int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay
         return vsom_fail(VSOM_ERR_INVALID, "online training needs Exponential or InverseProportional");
     if (!c->chunk_loaded)   // an empty chunk is a no-op for the sample loop (Som.cpp:1161)
         return vsom_fail(VSOM_ERR_INVALID, "no chunk loaded");
+    if (c->ahead_rows)      // (CHECK_ROWS of vsom_capi.hip: the staged rows already belong to the next chunk)
+        return vsom_fail(VSOM_ERR_INVALID,
+                         "the next chunk is staged ahead over the current chunk's rows: vsom_commit_chunk first");
     const double *lutd = nullptr;
     int lutw = 0;
     int rc = ensure_lutd(c, sigma, &lutd, &lutw);

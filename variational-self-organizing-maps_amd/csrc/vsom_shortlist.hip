@@ -575,10 +575,15 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
     constexpr int XL = WPS == 1 ? 4 : 1024;
     __shared__ __attribute__((aligned(16))) float s_x[WPS == 1 ? 1 : 4 / WPS][XL];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = s0 + (int)blockIdx.x * (4 / WPS) + wave / WPS;   // WPS wavefronts per sample, 4 / WPS samples per workgroup
+    const int s_own = s0 + (int)blockIdx.x * (4 / WPS) + wave / WPS;   // WPS wavefronts per sample, 4 / WPS samples per workgroup
     const int sub = wave % WPS;
+    // WPS > 1: the wavefronts of a workgroup meet at a barrier at the end, so none may leave before it.  The wavefronts of a
+    // sample past the range (the last workgroup of an odd range) work on the range's last sample with every side effect
+    // switched off (`active`) instead of returning early.
+    const bool active = s_own < s1;
+    const int s = (WPS == 1 || active) ? s_own : s1 - 1;
     const bool xlds = WPS != 1 && a.L <= XL;             // kernel-uniform
-    if (xlds && s < s1) {
+    if (xlds) {
         const float4 *src = reinterpret_cast<const float4 *>(a.xa + (size_t)s * a.ldx);
         for (int i = sub * 64 + lane; i < ((a.L + 3) >> 2); i += 64 * WPS)     // rows are zero padded to a multiple of 32
             reinterpret_cast<float4 *>(s_x[wave / WPS])[i] = src[i];
@@ -604,8 +609,8 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
             }
         }
     };
-    if (s >= s1) {        // wavefront-uniform, and uniform over the wavefronts of a sample (WPS > 1: they meet at a barrier
-        leave(0u);        // below; wavefronts that have ended no longer count for it)
+    if (WPS == 1 && s >= s1) {   // wavefront-uniform (the barrier above was this form's only one)
+        leave(0u);
         return;
     }
     const float *xr = xlds ? s_x[wave / WPS] : a.xa + (size_t)s * a.ldx;
@@ -700,13 +705,16 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
             }
         }
     }
-    if (bad) {   // wavefront-uniform (every wavefront of a sample reaches the same verdict)
+    auto redo = [&]() {   // `bad` is wavefront-uniform, and every wavefront of a sample reaches the same verdict
         if (lane == 0 && sub == 0) {
             const unsigned slot = atomicAdd(redo_count, 1u);
             redo_list[slot] = s;
             atomicAdd(&stats[0], 1u);
         }
         leave(0u);
+    };
+    if (WPS == 1 && bad) {
+        redo();
         return;
     }
     for (int off = 32; off >= 8; off >>= 1) {
@@ -716,9 +724,13 @@ __global__ __launch_bounds__(256) void sl_pick_kernel(DistArgs a, int s0, int s1
     if (WPS != 1) {
         if (lane == 0)
             s_best[wave] = best;
-        __syncthreads();
-        if (sub != 0)
+        __syncthreads();                                 // every wavefront of the workgroup arrives here
+        if (sub != 0 || !active)
             return;
+        if (bad) {
+            redo();
+            return;
+        }
         for (int w = 1; w < WPS; ++w)
             best = s_best[wave + w] < best ? s_best[wave + w] : best;
     }

@@ -260,15 +260,16 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
                                                             unsigned *__restrict__ xflag)
 {
     __shared__ __attribute__((aligned(16))) float s_row[4][1024];      // the rows of the four wavefronts (rows of <= 1024 values)
-    const int n = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n_own = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x < 64)
         sl_kind_fold(xflag);
     const bool small = kp8 <= 1024 && Dp <= 1024;        // workgroup-uniform
-    if (n >= N) {
-        if (small)
-            __syncthreads();                             // (the barrier of the path below)
+    // wavefronts past the last node: the `small` path has a workgroup barrier, which every wavefront must reach -- they
+    // load the last node's row and leave right behind the barrier, before anything is written
+    const bool live = n_own < N;
+    const int n = live ? n_own : N - 1;
+    if (!small && !live)
         return;
-    }
     const int kalloc = kp;                               // entries of idx (those past the live columns hold -1)
     if (kp_dev)
         kp = (int)kp_dev[2];
@@ -312,6 +313,8 @@ __global__ __launch_bounds__(256) void sl_prepare_i8_kernel(const float *__restr
             nz |= !(rv[j].x == 0.f) || !(rv[j].y == 0.f) || !(rv[j].z == 0.f) || !(rv[j].w == 0.f);
         }
         __syncthreads();
+        if (!live)
+            return;                                      // (no barrier follows)
         float gv[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j)

@@ -48,6 +48,8 @@ class HipEngine:
         one when None).  The context adopts it (vsom_set_stream) and ShardedBatchTrainer makes it
         torch's current stream around every epoch()/flush(), so that kernels and collectives are
         ordered on ONE stream whatever stream the caller happens to be on."""
+        # a torch stream / torch tensors handed to the library: both must live in ONE HIP runtime
+        capi.assert_single_hip_runtime("dist.HipEngine")
         self.ctx = ctx
         self.device = torch.device(device)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)

@@ -180,6 +180,10 @@ std::vector<RowData> MnistDataLoader::readRows(size_t skip, size_t limit) const
 bool MnistDataLoader::peekFlat(size_t &rows)
 {
     rows = rowsAvailable(m_currentIndex, m_maxLoadCount.value_or(0));
+    // The flat path writes rows x cols + 10 values per row into a buffer the caller sized with getDepth() (794).  An IDX
+    // file whose images are not 28 x 28 does not fit that: no flat path -- load() clips every row to the depth instead.
+    if (rows > 0 && (size_t)be32(_img.data() + 8) * be32(_img.data() + 12) + 10 != getDepth())
+        return false;
     return true;
 }
 

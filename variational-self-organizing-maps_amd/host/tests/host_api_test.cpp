@@ -9,7 +9,10 @@
 #include "Transformation.hpp"
 #include "MnistDataLoader.hpp"
 
+#include <atomic>
 #include <chrono>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -207,6 +210,227 @@ static int perf_e2e(int argc, char **argv)
     return 0;
 }
 
+// `host_api_test ref_harness <fixture_rows.f32> [scale]`: every scenario of the reference's own performance harness
+// (tests/performance/perf_tests.cpp:74-402) through the mirror's reference API, one JSON line each.  The harness's
+// database fixture (the `ican` table: 20 rows x 9 columns) arrives as a binary row file (tests/golden/ican_fixture.json
+// holds it as data); its per-call loops keep their counts except the two million-call ones, which run `scale` times
+// fewer calls and report the time per call like the others.
+static int ref_harness(const char *fixture, size_t scale)
+{
+    const size_t FR = 20, FJ = 9;
+    std::vector<float> fx(FR * FJ);
+    {
+        std::ifstream f(fixture, std::ios::binary);
+        f.read((char *)fx.data(), (std::streamsize)(fx.size() * 4));
+        if (!f) {
+            std::fprintf(stderr, "cannot read %s\n", fixture);
+            return 2;
+        }
+    }
+    using clk = std::chrono::steady_clock;
+    auto us_since = [](clk::time_point t0) { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
+    auto line = [](const char *scenario, const char *ref, size_t calls, double us_total, const char *unit) {
+        std::cout.clear();
+        std::printf("{\"scenario\": \"%s\", \"reference\": \"tests/performance/perf_tests.cpp:%s\", \"calls\": %zu, \"%s\": %.2f}\n",
+                    scenario, ref, calls, unit, us_total / (double)calls);
+        std::fflush(stdout);
+        std::cout.setstate(std::ios_base::failbit);
+    };
+    std::cout.setstate(std::ios_base::failbit);          // the drivers print per epoch
+    const size_t runs = 100;
+    // ---- Som::randomInitialize (:162-178)
+    {
+        Som sut{100, 100, 100};
+        sut.randomInitialize(1, 1);                      // (first call: allocations)
+        const auto t0 = clk::now();
+        sut.randomInitialize(1, 1);
+        sut.updateUMatrix(Eigen::VectorXf::Random(100));
+        auto a = sut.getUMatrix();
+        (void)a;
+        for (size_t i = 0; i < runs; ++i)
+            sut.randomInitialize(1, 1);
+        line("Som::randomInitialize() 100x100x100", "162-178", runs, us_since(t0), "us_per_call");
+    }
+    // ---- Som::train x 3 decay functions, 10x10 map on the 20 x 9 fixture, 300 epochs (:74-112, 390-392)
+    const Som::WeigthDecayFunction fns[3] = {Som::WeigthDecayFunction::Exponential, Som::WeigthDecayFunction::BatchMap,
+                                             Som::WeigthDecayFunction::InverseProportional};
+    const char *fn_names[3] = {"Som::train(exponentialWeightDecay) 10x10x9, 20 rows, 300 epochs",
+                               "Som::train(batchMap) 10x10x9, 20 rows, 300 epochs asked (sigma < 1 ends it after 231)",
+                               "Som::train(inverseProportionalWeightDecay) 10x10x9, 20 rows, 300 epochs"};
+    for (int m = 0; m < 3; ++m) {
+        ArrayDataLoader loader(fx.data(), FR, FJ);
+        DataSet ds(loader);
+        Som sut{10, 10, ds, Transformation::Standard(loader.getNames())};
+        sut.randomInitialize(7, 1);
+        sut.train(ds, 3, 0.001, 0.01, 10.0, 0.01, fns[m]);          // warm-up: allocations, code objects
+        sut.randomInitialize(7, 1);
+        const auto t0 = clk::now();
+        sut.train(ds, 300, 0.001, 0.01, 10.0, 0.01, fns[m]);
+        (void)sut.getNeuron(size_t{0});
+        // the reference divides by the 300 epochs it asked for (:109-111)
+        line(fn_names[m], "74-112", 300, us_since(t0), "us_per_epoch");
+    }
+    // ---- evaluate / measureSimilarity / variationalAutoEncoder on a 100x100 map over the fixture (:142-160, 297-318, 346-368)
+    {
+        ArrayDataLoader loader(fx.data(), FR, FJ);
+        DataSet ds(loader);
+        ds.loadNextDataFromStream();
+        Som sut{100, 100, ds.vectorLength(), Transformation::Standard(ds.getNames())};
+        sut.randomInitialize(7, 1);
+        (void)sut.evaluate(ds);
+        auto t0 = clk::now();
+        for (size_t r = 0; r < runs; ++r)
+            (void)sut.evaluate(ds);
+        line("Som::evaluate() 100x100x9 over 20 rows", "142-160", runs, us_since(t0), "us_per_call");
+        (void)sut.measureSimilarity(&ds, 1, 1);
+        t0 = clk::now();
+        for (size_t r = 0; r < runs; ++r)
+            (void)sut.measureSimilarity(&ds, 1, 1);
+        line("Som::measureSimilarity() 100x100x9 over 20 rows", "297-318", runs, us_since(t0), "us_per_call");
+        (void)sut.variationalAutoEncoder(&ds, 0);
+        t0 = clk::now();
+        for (size_t r = 0; r < runs; ++r)
+            (void)sut.variationalAutoEncoder(&ds, 0);
+        line("Som::variationalAutoEncoder() 100x100x9 over 20 rows", "346-368", runs, us_since(t0), "us_per_call");
+    }
+    // ---- updateUMatrix on a 100x100 CombinatorialLinearRegression map of depth J(J-1) = 72 (:320-344)
+    {
+        ArrayDataLoader loader(fx.data(), FR, FJ);
+        DataSet ds(loader);
+        ds.loadNextDataFromStream();
+        Som sut{100, 100, ds.vectorLength() * (ds.vectorLength() - 1), Transformation::CombinatorialLinearRegression(ds.getNames())};
+        sut.randomInitialize(7, 1);
+        sut.updateUMatrix(ds.getWeights());
+        const auto t0 = clk::now();
+        for (size_t r = 0; r < runs; ++r)
+            sut.updateUMatrix(ds.getWeights());
+        line("Som::updateUMatrix() 100x100 CLR map, depth 72", "320-344", runs, us_since(t0), "us_per_call");
+    }
+    // ---- the single-vector calls on a 100x100x100 map (:114-140, 181-295)
+    {
+        Som sut{100, 100, 100};
+        sut.randomInitialize(7, 1);
+        std::srand(12345);
+        std::vector<Eigen::VectorXf> samples(1000);
+        for (auto &v : samples)
+            v = Eigen::VectorXf::Random(100);
+        const Eigen::VectorXf ones = Eigen::VectorXf::Ones(100);
+        const Eigen::VectorXf mv = Eigen::VectorXf::Random(100);
+        std::vector<size_t> positions(1000);
+        for (auto &e : positions)
+            e = std::rand() % 100 * 100;                 // (the harness's expression: a multiple of 100 below 10000)
+        for (int m = 0; m < 2; ++m) {
+            const auto fn = m == 0 ? Som::WeigthDecayFunction::Exponential : Som::WeigthDecayFunction::InverseProportional;
+            sut.randomInitialize(7, 1);
+            size_t warm = 0;
+            for (size_t i = 0; i < 10; ++i)
+                (void)sut.trainSingle(samples[i], ones, ones, 0.1, 50, warm, fn);
+            const auto t0 = clk::now();
+            for (size_t i = 0; i < 1000; ++i)
+                (void)sut.trainSingle(samples[i], ones, ones, 0.1, 50, positions[i], fn);
+            line(m == 0 ? "Som::trainSingle(exponentialWeightDecay) 100x100x100, sigma 50"
+                        : "Som::trainSingle(inverseProportionalWeightDecay) 100x100x100, sigma 50",
+                 "114-140", 1000, us_since(t0), "us_per_call");
+        }
+        sut.randomInitialize(7, 1);
+        {
+            const size_t n = 1000000 / scale;
+            double res = 0;
+            (void)sut.euclidianWeightedDist(positions[0], mv, ones, ones);
+            const auto t0 = clk::now();
+            for (size_t i = 0; i < n; ++i)
+                res += sut.euclidianWeightedDist(positions[i % 1000], mv, ones, ones) / 1000000;
+            line("Som::euclidianWeightedDist() 100x100x100", "269-295", n, us_since(t0), "us_per_call");
+            std::fprintf(stderr, "%g\n", res);
+        }
+        {
+            (void)sut.findBmu(mv, ones, ones);
+            const auto t0 = clk::now();
+            for (size_t i = 0; i < 1000; ++i)
+                (void)sut.findBmu(mv, ones, ones);
+            line("Som::findBmu() 100x100x100", "181-199", 1000, us_since(t0), "us_per_call");
+        }
+        {
+            const size_t n = 1000000 / scale;
+            (void)sut.findLocalBmu(mv, ones, positions[0], ones);
+            const auto t0 = clk::now();
+            for (size_t i = 0; i < n; ++i)
+                (void)sut.findLocalBmu(mv, ones, positions[i % 1000], ones);
+            line("Som::findLocalBmu() 100x100x100", "200-222", n, us_since(t0), "us_per_call");
+        }
+        {
+            (void)sut.findRestrictedBmu(mv, ones, 1, ones);
+            auto t0 = clk::now();
+            for (size_t i = 0; i < 1000; ++i)
+                (void)sut.findRestrictedBmu(mv, ones, 1, ones);
+            line("Som::findRestrictedBmu(minBmuHits 1) 100x100x100", "223-246", 1000, us_since(t0), "us_per_call");
+            (void)sut.findRestrictedBmd(mv, ones, 0, ones);
+            t0 = clk::now();
+            for (size_t i = 0; i < 1000; ++i)
+                (void)sut.findRestrictedBmd(mv, ones, 0, ones);
+            line("Som::findRestrictedBmd(minBmuHits 0) 100x100x100", "247-268", 1000, us_since(t0), "us_per_call");
+        }
+    }
+    std::cout.clear();
+    return 0;
+}
+
+// `host_api_test threads <outdir>`: the boundary's threading contract (include/SOM.hpp:63,76: `_isTraining` is atomic,
+// `metricsMutex` is public so that a second thread may read the metrics while train() blocks).
+//   poll_batch.bin   Som::train(BatchMap) in a worker thread while this thread polls isTraining() and copies
+//                    getMetrics() under metricsMutex
+//   thr_a / thr_b    two Som objects on one device, trained at the same time from two host threads (one batch-map
+//                    schedule, one online schedule)
+// tests/test_gpu_robustness.py compares every dump with the oracle running the same schedules alone.
+static int threads_mode(const std::string &out)
+{
+    const size_t W = 24, H = 20, J = 16, NROWS = 600, CHUNK = 200;
+    auto rows_a = make_rows(NROWS, J, 4242u), rows_b = make_rows(NROWS, J, 777u);
+    {
+        ArrayDataLoader loader(rows_a.data(), NROWS, J, CHUNK);
+        DataSet ds(loader);
+        Som som{W, H, ds, Transformation::Standard(loader.getNames())};
+        som.randomInitialize(42, 1);
+        std::atomic<bool> done{false};
+        std::thread worker([&] {
+            som.train(ds, 6, 0.0, 0.0, 8.0, 0.2, Som::WeigthDecayFunction::BatchMap);
+            done = true;
+        });
+        size_t polls = 0, seen_training = 0, sizes_ok = 1;
+        while (!done) {
+            if (som.isTraining())
+                ++seen_training;
+            {
+                const std::lock_guard<std::mutex> lock(som.metricsMutex);
+                const auto m = som.getMetrics();
+                if (m.MeanSquaredError.size() != 0 && m.MeanSquaredError.size() != 6)
+                    sizes_ok = 0;
+            }
+            ++polls;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        worker.join();
+        std::cout << "poll: polls=" << polls << " seen_training=" << (seen_training ? 1 : 0) << " sizes_ok=" << sizes_ok
+                  << " still_training=" << (som.isTraining() ? 1 : 0) << "\n";
+        dump(out + "/poll_batch.bin", som, som.getMetrics().MeanSquaredError);
+    }
+    {
+        ArrayDataLoader la(rows_a.data(), NROWS, J, CHUNK), lb(rows_b.data(), NROWS, J, CHUNK);
+        DataSet da(la), db(lb);
+        Som a{W, H, da, Transformation::Standard(la.getNames())};
+        Som b{W, H, J, Transformation::StandardMedianEstimator({})};
+        a.randomInitialize(5, 1);
+        b.randomInitialize(6, 1);
+        std::thread ta([&] { a.train(da, 5, 0.0, 0.0, 7.0, 0.25, Som::WeigthDecayFunction::BatchMap); });
+        std::thread tb([&] { b.train(db, 3, 0.05, 0.1, 3.0, 0.3, Som::WeigthDecayFunction::Exponential); });
+        ta.join();
+        tb.join();
+        dump(out + "/thr_a.bin", a, a.getMetrics().MeanSquaredError);
+        dump(out + "/thr_b.bin", b, b.getMetrics().MeanSquaredError);
+    }
+    return 0;
+}
+
 // `host_api_test mnist <folder> <outdir>`: BASELINE configuration 2's plumbing at test size -- IDX files
 // -> MnistDataLoader (chunked) -> DataSet -> Som::train(BatchMap); the dump is compared with the oracle
 // run on the same rows and chunk boundaries (tests/test_gpu_host_cpp.py)
@@ -228,6 +452,10 @@ int main(int argc, char **argv)
         return perf();
     if (argc > 1 && std::string(argv[1]) == "perf_tiny")
         return perf_tiny();
+    if (argc > 2 && std::string(argv[1]) == "ref_harness")
+        return ref_harness(argv[2], argc > 3 ? std::stoul(argv[3]) : 100);
+    if (argc > 2 && std::string(argv[1]) == "threads")
+        return threads_mode(argv[2]);
     if (argc > 2 && std::string(argv[1]) == "perf_mnist")
         return perf_mnist(argv[2]);
     if (argc > 2 && std::string(argv[1]) == "perf_e2e")
