@@ -195,6 +195,12 @@ int vsom_bmu_batch(vsom_ctx *ctx, uint64_t *idx_out_host, float *dist_out_host);
  * tests/performance/perf_tests.cpp:181-199): one copy, one scan launch, 32 bytes back.  Does not
  * touch the staged chunk.  dist_out = euclidianWeightedDist(bmu, v) (NaN when node 0 is NaN). */
 int vsom_find_bmu(vsom_ctx *ctx, const float *v_host, uint64_t *bmu_out, float *dist_out);
+/* Som::euclidianWeightedDist(pos, v, ...) (Som.cpp:124-141) and Som::findLocalBmu(v, ..., lastBMU, ...)
+ * (Som.cpp:335-454) for ONE host vector (the perf harness calls them a million times each,
+ * tests/performance/perf_tests.cpp:200-222, 269-295): one copy, one single-wavefront launch, 16 bytes back,
+ * one synchronisation, no allocation.  Neither touches the staged chunk. */
+int vsom_dist_single(vsom_ctx *ctx, const float *v_host, uint64_t node, float *dist_out);
+int vsom_find_local_bmu(vsom_ctx *ctx, const float *v_host, uint64_t last_bmu, uint64_t *bmu_out, float *dist_out);
 /* Som::findLocalBmu from the current lastBMU of every sample (Som.cpp:335-454) */
 int vsom_bmu_local_batch(vsom_ctx *ctx, uint64_t *idx_out_host, float *dist_out_host);
 /* Som::euclidianWeightedDist(pos, v, ...) for `count` (node, sample-row) pairs of the chunk */

@@ -47,6 +47,119 @@ CASES = [
 ]
 
 
+def _run_online_case(W, H, J, tr, fn, B, sigma, X, init, eta, mode=None, reps=2):
+    o = po.OracleSom(W, H, J, tr)
+    o.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    if mode is not None:
+        ctx.set_bmu_mode(mode)
+    ctx.set_state(map=init)
+    for rep in range(reps):          # second pass accumulates weightMap/SMap further (Q9)
+        lb = np.zeros(B, np.uint64)
+        mse_o = o.train_online_chunk(X, lb, eta, sigma, fn)
+        ctx.upload_chunk(X)
+        mse_g = ctx.train_online_chunk(eta, sigma, fn)
+        got = ctx.get_last_bmu()
+        assert beq(got, lb), (rep, "lastBMU", np.nonzero(got != lb)[0][:8], got[got != lb][:8], lb[got != lb][:8])
+        st = ctx.get_state()
+        for k in ("map", "S", "sigma", "weight", "hits"):
+            assert beq(st[k], getattr(o, k)), (rep, k)
+        assert beq(np.float32(mse_g), np.float32(mse_o)), (rep, mse_g, mse_o)
+    ctx.close()
+
+
+# The chunk loop's image-bounded search (csrc/vsom_online.hip, "Image-bounded search": sigma > 1, Standard / Median):
+# VSOM_BMU_SHORTLIST forces it on every map size, so every case of the table above that it covers runs through it too --
+# ragged node counts, depths with every remainder class of Eigen's reduction, windows larger than the map
+I8_CASES = [c for c in CASES if c[4] != 2 and c[7] > 1]
+
+
+@pytest.mark.parametrize("name,W,H,J,tr,fn,B,sigma", I8_CASES, ids=[c[0] for c in I8_CASES])
+def test_online_chunk_through_the_image(name, W, H, J, tr, fn, B, sigma):
+    X = gen.mnist_like(B, 3, J) if J > 700 else gen.blobs(B, J, 4, 1, 2, sigma=0.3)
+    init = gen.random_map(W * H, J, seed=13)
+    _run_online_case(W, H, J, tr, fn, B, sigma, X, init, 0.05, mode=capi.BMU_SHORTLIST)
+
+
+@pytest.mark.parametrize("kind", ["uint8", "unit_floats", "signed_dense", "tiny_values", "huge_values"])
+def test_online_image_search_on_a_big_map(kind):
+    """A map large enough for VSOM_BMU_AUTO to pick the image-bounded search by itself (>= 8 MiB), rows of MNIST-like
+    pixels / the same over 255 / signed dense values / values near the bottom and the top of fp32's useful range: the
+    bound has to hold for every scale, and whatever it prunes, indices and distances are the exact-order evaluation's."""
+    W, H, J, B = 72, 64, 520, 40
+    if kind in ("uint8", "unit_floats"):
+        X = gen.mnist_like(B, 11, J)
+        init = (gen.random_map(W * H, J, seed=5) * np.float32(60) + np.float32(90)).astype(np.float32)
+        if kind == "unit_floats":
+            X = (X / np.float32(255)).astype(np.float32)
+            init = (init / np.float32(255)).astype(np.float32)
+    else:
+        X = gen.blobs(B, J, 6, 1, 2, sigma=0.5)
+        init = gen.random_map(W * H, J, seed=5)
+        scale = {"signed_dense": 1.0, "tiny_values": 1e-17, "huge_values": 3e15}[kind]
+        X = (X * np.float32(scale)).astype(np.float32)
+        init = (init * np.float32(scale)).astype(np.float32)
+    _run_online_case(W, H, J, po.STANDARD, capi.EXPONENTIAL, B, 4.0, X, init, 0.08)
+
+
+def test_online_image_search_with_nan_inf_rows_and_samples():
+    """Rows holding NaN / inf (always candidates, never winners unless the reference says so), duplicates (lowest index), a
+    NaN at node 0 (pins the BMU), and samples holding a NaN or an inf (every interval opens: the refinement evaluates all
+    nodes exactly) -- through the image-bounded search, both decay functions."""
+    W, H, J, B = 36, 30, 24, 43
+    X = gen.blobs(B, J, 5, 1, 2, sigma=0.4)
+    X[7, 3] = np.nan
+    X[19, 0] = np.inf
+    init = gen.random_map(W * H, J, seed=21)
+    init[500:520] = init[100:120]            # duplicates at higher indices
+    init[7, 3] = np.nan
+    init[640:700:9] = np.nan
+    init[333, 2] = np.inf
+    for nan0 in (False, True):
+        m = init.copy()
+        if nan0:
+            m[0, 5] = np.nan
+        for fn in (capi.EXPONENTIAL, capi.INVERSE_PROPORTIONAL):
+            _run_online_case(W, H, J, po.STANDARD, fn, B, 2.0, X, m, 0.05, mode=capi.BMU_SHORTLIST, reps=1)
+
+
+def test_online_image_search_one_and_two_sample_chunks():
+    """the pipeline's ends: a chunk of one sample (score, refine, window, finish) and of two"""
+    W, H, J = 20, 18, 40
+    init = gen.random_map(W * H, J, seed=9)
+    for B in (1, 2, 3):
+        X = gen.blobs(B, J, 3, 1, 4, sigma=0.3)
+        _run_online_case(W, H, J, po.MEDIAN, capi.INVERSE_PROPORTIONAL, B, 2.5, X, init, 0.05, mode=capi.BMU_SHORTLIST)
+
+
+@pytest.mark.parametrize("tr,W,H,J", [(po.STANDARD, 100, 100, 100), (po.STANDARD, 7, 5, 13), (po.MEDIAN, 12, 12, 9),
+                                      (po.CLR, 8, 8, 6)])
+def test_single_vector_distance_and_local_search(tr, W, H, J):
+    """vsom_dist_single / vsom_find_local_bmu (Som::euclidianWeightedDist / Som::findLocalBmu of one host vector, the perf
+    harness's million-call scenarios): bit-identical to the oracle; the staged chunk is left alone."""
+    D = po.length(tr, J)
+    init = gen.random_map(W * H, D, seed=42)
+    X = gen.correlated(30, J, seed=5) if tr == po.CLR else gen.blobs(30, J, 4, 1, 2)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    orc = po.OracleSom(W, H, J, tr)
+    ctx.set_state(map=init)
+    orc.set_state(map=init)
+    ctx.upload_chunk(X[:5])
+    rs = np.random.RandomState(3)
+    for i in range(len(X)):
+        node = int(rs.randint(W * H))
+        assert beq(ctx.dist_single(X[i], node), np.float32(orc.dist(node, X[i]))), (i, node)
+        start = int(rs.randint(W * H))
+        idx, dist = ctx.find_local_bmu(X[i], start)
+        want = orc.find_local_bmu(X[i], start)
+        assert idx == want, (i, start)
+        assert beq(dist, np.float32(orc.dist(want, X[i]))), (i, start)
+    assert ctx.chunk_size == 5
+    with pytest.raises(capi.VsomError):
+        ctx.dist_single(X[0], W * H)
+    ctx.close()
+
+
 @pytest.mark.parametrize("name,W,H,J,tr,fn,B,sigma", CASES, ids=[c[0] for c in CASES])
 def test_online_chunk(name, W, H, J, tr, fn, B, sigma):
     D = po.length(tr, J)

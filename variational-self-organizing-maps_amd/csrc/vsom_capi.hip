@@ -159,7 +159,8 @@ static int free_all(vsom_ctx *c)
                     c->lastbmu, c->sqres, c->mse, c->pair_i, c->pair_j, c->partial, c->nan0,
                     c->cw, c->lut, c->lutd, c->sl_G, c->sl_nrm, c->sl_scal, c->sl_list, c->sl_tmin, c->sl_fs, c->sl_fm, c->v_dev, c->res_dev, c->onl_state, c->onl_f,
                     c->cc_flags, c->cc_idx, c->cc_inv, c->cc_meta, c->Xc, c->Mc, c->Uc_map, c->Uc_S, c->Xq, c->zq, c->sl_xi, c->sl_l1, c->sl_q, c->sl_qscale, c->sl_qcorr,
-                    c->lastbmu_alt, c->cc_idx_alt, c->cc_inv_alt, c->cc_meta_alt, c->sl_a2, c->sl_qfast};
+                    c->lastbmu_alt, c->cc_idx_alt, c->cc_inv_alt, c->cc_meta_alt, c->sl_a2, c->sl_qfast,
+                    c->onl_img, c->onl_nsc, c->onl_lb, c->onl_u, c->onl_xsc, c->q_scratch};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -695,6 +696,23 @@ int vsom_bmu_local_batch(vsom_ctx *c, uint64_t *idx_out_host, float *dist_out_ho
     return copy_search_results(c, idx_out_host, dist_out_host);
 }
 
+// device scratch of the distance queries (pair lists in, distances out): grow-only, kept with the context -- a
+// hipMalloc / hipFree pair per call cost more than the queries' kernels (tests/perf/ref_harness.py)
+static int ensure_query_scratch(vsom_ctx *c, size_t bytes)
+{
+    if (bytes <= c->q_scratch_cap)
+        return VSOM_OK;
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->q_scratch)
+        (void)hipFree(c->q_scratch);
+    c->q_scratch = nullptr;
+    c->q_scratch_cap = 0;
+    const size_t cap = (bytes + 4095) / 4096 * 4096;
+    VSOM_HIP_CHECK(hipMalloc(&c->q_scratch, cap));
+    c->q_scratch_cap = cap;
+    return VSOM_OK;
+}
+
 int vsom_distances(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *rows_host, size_t count,
                    float *dist_out_host)
 {
@@ -709,29 +727,19 @@ int vsom_distances(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *rows
     for (size_t i = 0; i < count; ++i)
         if (nodes_host[i] >= c->N || rows_host[i] >= c->B)
             return vsom_fail(VSOM_ERR_INVALID, "pair index out of range");
-    u64 *dn = nullptr, *dr = nullptr;
-    float *dd = nullptr;
-    int rc = VSOM_OK;
-    if (hipMalloc(&dn, count * 8) != hipSuccess || hipMalloc(&dr, count * 8) != hipSuccess ||
-        hipMalloc(&dd, count * 4) != hipSuccess) {
-        rc = vsom_fail(VSOM_ERR_NOMEM, "hipMalloc failed");
-    } else {
-        (void)hipMemcpyAsync(dn, nodes_host, count * 8, hipMemcpyHostToDevice, c->stream);
-        (void)hipMemcpyAsync(dr, rows_host, count * 8, hipMemcpyHostToDevice, c->stream);
-        rc = launch_pair_dist(c, dn, dr, count, dd);
-        if (rc == VSOM_OK) {
-            (void)hipMemcpyAsync(dist_out_host, dd, count * 4, hipMemcpyDeviceToHost, c->stream);
-            if (hipStreamSynchronize(c->stream) != hipSuccess)
-                rc = vsom_fail(VSOM_ERR_HIP, "distance kernel failed");
-        }
-    }
-    if (dn)
-        (void)hipFree(dn);
-    if (dr)
-        (void)hipFree(dr);
-    if (dd)
-        (void)hipFree(dd);
-    return rc;
+    const size_t c8 = (count * 8 + 255) / 256 * 256;
+    int rc = ensure_query_scratch(c, 2 * c8 + count * 4);
+    if (rc)
+        return rc;
+    u64 *dn = reinterpret_cast<u64 *>(c->q_scratch), *dr = reinterpret_cast<u64 *>((char *)c->q_scratch + c8);
+    float *dd = reinterpret_cast<float *>((char *)c->q_scratch + 2 * c8);
+    VSOM_HIP_CHECK(hipMemcpyAsync(dn, nodes_host, count * 8, hipMemcpyHostToDevice, c->stream));
+    VSOM_HIP_CHECK(hipMemcpyAsync(dr, rows_host, count * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_pair_dist(c, dn, dr, count, dd)))
+        return rc;
+    VSOM_HIP_CHECK(hipMemcpyAsync(dist_out_host, dd, count * 4, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
 }
 
 int vsom_bmu_restricted_batch(vsom_ctx *c, uint64_t min_hits, uint64_t *idx_out_host, float *dist_out_host)
@@ -752,16 +760,15 @@ int vsom_distances_row(vsom_ctx *c, size_t row, float *dist_out_host)
     CHECK_ROWS(c);
     if (row >= c->B || !dist_out_host)
         return vsom_fail(VSOM_ERR_INVALID, "row out of range or null output");
-    float *dd = nullptr;
-    VSOM_HIP_CHECK(hipMalloc(&dd, (size_t)c->N * 4));
-    int rc = launch_row_dist(c, row, dd);
-    if (rc == VSOM_OK) {
-        (void)hipMemcpyAsync(dist_out_host, dd, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->stream);
-        if (hipStreamSynchronize(c->stream) != hipSuccess)
-            rc = vsom_fail(VSOM_ERR_HIP, "row distance kernel failed");
-    }
-    (void)hipFree(dd);
-    return rc;
+    int rc = ensure_query_scratch(c, (size_t)c->N * 4);
+    if (rc)
+        return rc;
+    float *dd = reinterpret_cast<float *>(c->q_scratch);
+    if ((rc = launch_row_dist(c, row, dd)))
+        return rc;
+    VSOM_HIP_CHECK(hipMemcpyAsync(dist_out_host, dd, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
 }
 
 int vsom_distances_raw(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *vrows_host, size_t count,
@@ -777,29 +784,19 @@ int vsom_distances_raw(vsom_ctx *c, const uint64_t *nodes_host, const uint64_t *
     for (size_t i = 0; i < count; ++i)
         if (nodes_host[i] >= c->N || vrows_host[i] >= (from_map ? (uint64_t)c->N : (uint64_t)c->B))
             return vsom_fail(VSOM_ERR_INVALID, "pair index out of range");
-    u64 *dn = nullptr, *dr = nullptr;
-    float *dd = nullptr;
-    int rc = VSOM_OK;
-    if (hipMalloc(&dn, count * 8) != hipSuccess || hipMalloc(&dr, count * 8) != hipSuccess ||
-        hipMalloc(&dd, count * 4) != hipSuccess) {
-        rc = vsom_fail(VSOM_ERR_NOMEM, "hipMalloc failed");
-    } else {
-        (void)hipMemcpyAsync(dn, nodes_host, count * 8, hipMemcpyHostToDevice, c->stream);
-        (void)hipMemcpyAsync(dr, vrows_host, count * 8, hipMemcpyHostToDevice, c->stream);
-        rc = launch_raw_dist(c, dn, dr, count, from_map, dd);
-        if (rc == VSOM_OK) {
-            (void)hipMemcpyAsync(dist_out_host, dd, count * 4, hipMemcpyDeviceToHost, c->stream);
-            if (hipStreamSynchronize(c->stream) != hipSuccess)
-                rc = vsom_fail(VSOM_ERR_HIP, "raw distance kernel failed");
-        }
-    }
-    if (dn)
-        (void)hipFree(dn);
-    if (dr)
-        (void)hipFree(dr);
-    if (dd)
-        (void)hipFree(dd);
-    return rc;
+    const size_t c8 = (count * 8 + 255) / 256 * 256;
+    int rc = ensure_query_scratch(c, 2 * c8 + count * 4);
+    if (rc)
+        return rc;
+    u64 *dn = reinterpret_cast<u64 *>(c->q_scratch), *dr = reinterpret_cast<u64 *>((char *)c->q_scratch + c8);
+    float *dd = reinterpret_cast<float *>((char *)c->q_scratch + 2 * c8);
+    VSOM_HIP_CHECK(hipMemcpyAsync(dn, nodes_host, count * 8, hipMemcpyHostToDevice, c->stream));
+    VSOM_HIP_CHECK(hipMemcpyAsync(dr, vrows_host, count * 8, hipMemcpyHostToDevice, c->stream));
+    if ((rc = launch_raw_dist(c, dn, dr, count, from_map, dd)))
+        return rc;
+    VSOM_HIP_CHECK(hipMemcpyAsync(dist_out_host, dd, count * 4, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return VSOM_OK;
 }
 
 int vsom_batch_phase1_async(vsom_ctx *c, size_t s0, size_t s1, int is_first)

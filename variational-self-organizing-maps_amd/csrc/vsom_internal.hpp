@@ -158,6 +158,13 @@ struct vsom_ctx {
     float *res_dev = nullptr;       // residual
     u64 *onl_state = nullptr;       // argmin key slots + flags of the online scan (vsom_online.hip)
     float *onl_f = nullptr;         // [4]: dist, mse
+    // image-bounded search of the online chunk loop (vsom_online.hip): one byte per model value + 4 scalars per node,
+    // lower bounds of the sample being searched, min-upper-bound slots, per-sample bound terms
+    unsigned char *onl_img = nullptr; void *onl_nsc = nullptr; float *onl_lb = nullptr; unsigned *onl_u = nullptr;
+    void *onl_xsc = nullptr; size_t onl_xsc_cap = 0;
+
+    // device scratch of the distance queries (vsom_distances / _row / _raw): grow-only
+    void *q_scratch = nullptr; size_t q_scratch_cap = 0;
 
     // timing
     uint32_t timing = 0;            // bit (1u << VSOM_T_*): that kernel group is timed with HIP events

@@ -211,7 +211,7 @@ __device__ __forceinline__ void online_node_update(size_t n, double h, int tid, 
                                                    const float *__restrict__ xs, const float *__restrict__ xp,
                                                    const float *__restrict__ yp, int D, int P, int ppitch, int pitch,
                                                    double eta, int decay_fn, float *map, float *Smap, float *sigmap,
-                                                   float *weight)
+                                                   float *weight, float *mkeep = nullptr)   // mkeep[4]: the new M of elements tid + u * nthr
 {
     float *M = map + n * pitch, *S = Smap + n * pitch, *sg = sigmap + n * pitch;
     // workgroup form, Standard / Median: this thread's first four elements are requested BEFORE the barrier below, so that
@@ -291,6 +291,8 @@ __device__ __forceinline__ void online_node_update(size_t n, double h, int tid, 
             M[d] = m;
             S[d] = s;
             sg[d] = sqrtf(fabsf(s / twf));                   // :942
+            if (mkeep && u < 4)
+                mkeep[u < 4 ? u : 0] = m;
         }
     }
 }
@@ -432,6 +434,518 @@ __global__ void online_init_kernel(u64 *state, float *fstate, int keep_mse)
     fstate[0] = 0.f;
     if (!keep_mse)
         fstate[1] = 0.f;   // else: the epoch's running MSE continues across chunks (Som.cpp:1153,1167)
+}
+
+// =====================================================================================================================
+// Image-bounded search of the chunk loop (sigma > 1, Standard / Median, rows of at most 1024 values).
+//
+// The exact scan streams the fp32 map once per SAMPLE (4 N D bytes: 51 MB at 128 x 128 x 784).  Here the search reads a
+// one-digit image of it instead -- one byte per model value, u = q + 128 with M_nk = s_n q_nk + r_nk, s_n a power of two,
+// q in [-127, 127], plus four scalars per node -- and only PRUNES with it: every index and distance still comes from an
+// exact-order evaluation (onl_refine_kernel: vsom_group_dist's arithmetic on the fp32 rows of the nodes that survive),
+// so results are bit-identical to the exact scan's.  Two launches per sample, as before, but differently cut:
+//
+//   onl_fused_kernel    window update of sample j  ||  image scan for sample j + 1.  The window workgroups rewrite their
+//                       node's fp32 rows exactly as online_window_kernel does, then re-digit the row they hold in
+//                       registers and score it against sample j + 1; the scan workgroups score the nodes OUTSIDE the window
+//                       from the image (8 lanes per node, 16 bytes per load, every load of a lane in flight at once).  A
+//                       score is an interval [L_n, U_n] that provably contains the exact-order fp32 distance e_n (minus
+//                       the sample's |x|^2): L_n goes to onl_lb[n], min_n U_n into 64 line-sized slots.
+//   onl_refine_kernel   candidates {n : L_n <= min U} (the argmin of the exact-order distances is always one of them: its
+//                       L is below its own e, which is below every e_m <= U_m), evaluated in the reference's order, argmin
+//                       by the same (distance, index) key and node-0-NaN flag as online_scan_kernel; its extra workgroup
+//                       finishes sample j - 1 (residual / distance after the update, addBmu, MSE, lastBMU).
+//
+// Bound.  u = 2^-24, K = columns.  Per node (stored by the digit passes): s_n, nM_n ~ |M_n|^2, eps_n = max_k |r_nk|,
+// rho_n >= |r_n|_2; per sample (onl_prep_kernel): l1 >= |x|_1, nx ~ |x|^2, sx = sum x.  With T' the fp32 value of
+// <x, q_n> (scan: fma chain of x_k * float(u_nk) over <= 128 elements per lane + 3 adds, then - 128 sx; |T' - <x,q>| <=
+// 35000 u l1) and A_n = fma(-2 s_n, T', nM_n):
+//     |A_n - (d_n - |x|^2)| <= w_n := 2 min(l1 eps_n, |x|_2 rho_n) + s_n l1 (2 * 35000 + 256) u + 25 u nM_n
+//     |e_n - d_n| <= g2 d_n,  g2 = (K / 8 + 16) u        (exact-order evaluation: products + Eigen's sum tree)
+//     e_n - |x|^2 in [A_n - slack_n, A_n + slack_n],  slack_n = 1.01 w_n + 1.05 g2 (max(A_n + nx, 0) + w_n) + 4 u |A_n| + 1e-30
+// Anything non-finite on the way (a NaN / inf in the row or in the sample, an overflow) gives L = -inf, U = +inf: the
+// node is always a candidate and never lowers the threshold -- a sample with a NaN then costs a full exact evaluation,
+// spread over the refinement's workgroups.  Node 0 is always evaluated (Som.cpp:293-299: a NaN there pins the BMU).
+constexpr int ONL_USLOTS = 64;                           // min U: 64 line-sized slots per parity (one lane of a wavefront each)
+constexpr size_t ONL_U_BYTES = 2 * ONL_USLOTS * 128;
+constexpr int ONL_REF_NODES = 128;                       // nodes per refinement workgroup
+
+struct OnlI8 {
+    unsigned char *img;      // [N][ipitch] u = q + 128 (pad bytes 128)
+    float4 *nsc;             // [N] {s, nM, eps, rho}; s = NaN: row holds a non-finite value
+    float *lb;               // [N] L_n of the sample being searched
+    unsigned *uslots;        // [2][ONL_USLOTS][32]
+    const float4 *xsc;       // [B] {l1, nx, sx, -}
+    int ipitch, ni;          // ni = ipitch / 128: 16-byte pieces per lane
+    float cT, g2c;           // (2 * 35000 + 256) u ; 1.05 (K / 8 + 16) u
+};
+
+// order-preserving key of a (signed, finite) float for the unsigned atomicMin; 0xFFFFFFFF = "no finite U yet"
+__device__ __forceinline__ unsigned onl_fkey(float v)
+{
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float onl_funkey(unsigned k)
+{
+    if (k == 0xFFFFFFFFu)
+        return __uint_as_float(0x7F800000u);
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// [L, U] of a node from its approximate value A and the bound terms; non-finite -> (-inf, +inf)
+__device__ __forceinline__ void onl_interval(float A, float s, float nM, float eps, float rho, float4 xs, float cT, float g2c,
+                                             float &L, float &U)
+{
+    const float l1 = xs.x, nx = xs.y;
+    const float x2 = sqrtf(nx * 1.0001f) * 1.0001f;
+    const float w = (2.f * fminf(l1 * eps, x2 * rho) + s * l1 * cT + 1.5e-6f * nM) * 1.01f;     // 25 u = 1.49e-6
+    const float dpos = fmaxf(A + nx * 1.0001f, 0.f);
+    const float slack = w + g2c * (dpos + w) + 2.4e-7f * fabsf(A) + 1e-30f;
+    const bool ok = slack < 3.0e38f && fabsf(A) < 3.0e38f;                                       // NaN fails both
+    const float inf = __uint_as_float(0x7F800000u);
+    L = ok ? A - slack : -inf;
+    U = ok ? A + slack : inf;
+}
+
+// scale 2^E of a row whose largest finite magnitude is mx: |M| / s < 128 (rows below 2^-44 keep E = -50)
+__device__ __forceinline__ void onl_row_scale(float mx, float &s, float &is)
+{
+    int e = mx > 0.f ? (int)((__float_as_uint(mx) >> 23) & 0xFF) - 127 : -100;
+    e = mx > 0.f && ((__float_as_uint(mx) >> 23) & 0xFF) == 0 ? -126 : e;
+    int E = e - 6;
+    E = E < -50 ? -50 : E;
+    s = __uint_as_float((unsigned)(E + 127) << 23);
+    is = __uint_as_float((unsigned)(127 - E) << 23);
+}
+
+// digit of one value on the grid of scale s: q in [-127, 127]; r = m - q s is exact in fp32 (Sterbenz: q s and m are
+// within a factor of two of each other whenever q != 0)
+__device__ __forceinline__ void onl_digit(float m, float s, float is, float &q, float &r)
+{
+    const float mm = fabsf(m) <= 3.0e38f ? m : 0.f;
+    float t = rintf(mm * is);
+    t = fminf(fmaxf(t, -127.f), 127.f);
+    q = t;
+    r = mm - t * s;
+}
+
+// per chunk: the whole map -> image + node scalars.  One wavefront per node (rows of at most 1024 values: 16 per lane).
+__global__ __launch_bounds__(256) void onl_digit_kernel(const float *__restrict__ map, int ldm, int D, int N, OnlI8 o)
+{
+    const int n = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N)
+        return;
+    const float *row = map + (size_t)n * ldm;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int d = lane * 16 + 4 * j;                 // rows are zero padded to a multiple of 32 floats
+        const float4 t = d < D ? *reinterpret_cast<const float4 *>(row + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[4 * j] = t.x;
+        v[4 * j + 1] = t.y;
+        v[4 * j + 2] = t.z;
+        v[4 * j + 3] = t.w;
+    }
+    float mx = 0.f, nm = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float a = fabsf(v[i]);
+        const bool fin = a <= 3.0e38f;
+        bad |= !fin;
+        mx = (fin && a > mx) ? a : mx;
+        nm = nm + v[i] * v[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_xor(mx, off);
+        mx = om > mx ? om : mx;
+        nm += __shfl_xor(nm, off);
+    }
+    bad = __ballot(bad) != 0ull;
+    float s, is;
+    onl_row_scale(mx, s, is);
+    float eps = 0.f, r2 = 0.f;
+    unsigned w4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned pk = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float q, r;
+            onl_digit(v[4 * j + i], s, is, q, r);
+            const int d = lane * 16 + 4 * j + i;
+            const unsigned ub = d < D ? (unsigned)((int)q + 128) : 128u;
+            pk |= ub << (8 * i);
+            const float ar = fabsf(r);
+            eps = ar > eps ? ar : eps;
+            r2 = r2 + r * r;
+        }
+        w4[j] = pk;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float oe = __shfl_xor(eps, off);
+        eps = oe > eps ? oe : eps;
+        r2 += __shfl_xor(r2, off);
+    }
+    if (lane * 16 < o.ipitch)
+        *reinterpret_cast<uint4 *>(o.img + (size_t)n * o.ipitch + lane * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    if (lane == 0)
+        o.nsc[n] = make_float4(bad ? __uint_as_float(0x7FC00000u) : s, nm, eps, sqrtf(r2 * 1.0001f) * 1.0001f);
+}
+
+// per chunk: the bound terms of every sample.  One wavefront per sample.
+__global__ __launch_bounds__(256) void onl_prep_kernel(const float *__restrict__ X, int ldx, int D, int B, float4 *__restrict__ xsc)
+{
+    const int s = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= B)
+        return;
+    const float *row = X + (size_t)s * ldx;
+    float l1 = 0.f, nx = 0.f;
+    double sx = 0.0;
+    for (int d = lane; d < D; d += 64) {
+        const float v = row[d];
+        l1 += fabsf(v);
+        nx += v * v;
+        sx += (double)v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        l1 += __shfl_xor(l1, off);
+        nx += __shfl_xor(nx, off);
+        sx += __shfl_xor(sx, off);
+    }
+    if (lane == 0)
+        xsc[s] = make_float4(l1 * 1.0001f, nx, (float)sx, 0.f);   // (a NaN / inf in the row makes l1 / nx non-finite: every interval opens)
+}
+
+// min U of the sample of parity `par` (whole wavefronts call this: one slot per lane)
+__device__ __forceinline__ float onl_umin(const unsigned *uslots, int par)
+{
+    unsigned k = uslots[(par * ONL_USLOTS + ((int)threadIdx.x & 63)) * 32];
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)k, off);
+        k = o < k ? o : k;
+    }
+    return onl_funkey(k);
+}
+
+struct OnlFusedArgs {
+    OnlineArgs a;            // a.d.xa = row of sample j (the window's sample), a.par = parity of sample j
+    const float *xnext;      // row of sample j + 1 (the one being scored)
+    int jnext;               // its index into xsc
+    int do_window, do_scan;
+    int nwin_x, nwin_y;      // maximal window extents = window workgroups (do_window)
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void onl_fused_kernel(
+    OnlFusedArgs f, OnlI8 o, const double *__restrict__ lutd, int lutw, int D, int pitch, double eta, double sigma, int decay_fn,
+    float *map, float *Smap, float *sigmap, float *weight)   // no __restrict__: f.a.d.ma aliases map
+{
+    __shared__ __attribute__((aligned(16))) float s_x[1024];
+    __shared__ float s_red[4][4];
+    __shared__ unsigned s_u[4];
+    const OnlineArgs &a = f.a;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nwin = f.do_window ? f.nwin_x * f.nwin_y : 0;
+    const int parn = a.par ^ 1;                          // parity of the sample being scored
+    const float inf = __uint_as_float(0x7F800000u);
+    if ((int)blockIdx.x < nwin) {
+        // ---- window role: one workgroup per node of the (maximal) window of sample j
+        float xn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                    // (independent of the BMU: in flight beside the resolve)
+            const int d = tid + u * 256;
+            xn[u] = (f.do_scan && d < D) ? f.xnext[d] : 0.f;
+        }
+        const u64 bmu = online_resolve(a.state, a.par);
+        int bx, by;
+        u64 startX, startY, endX, endY;
+        online_window(bmu, a.W, a.H, sigma, bx, by, startX, startY, endX, endY);
+        const u64 i = startX + (u64)((int)blockIdx.x % f.nwin_x), j = startY + (u64)((int)blockIdx.x / f.nwin_x);
+        if (i >= endX || j >= endY)
+            return;
+        const size_t n = (size_t)(j * (u64)a.W + i);
+        int dx = (int)i - bx, dy = (int)j - by;
+        dx = dx < 0 ? -dx : dx;
+        dy = dy < 0 ? -dy : dy;
+        const double h = lutd[(size_t)dy * lutw + dx];   // calculateNeighbourhoodWeight(i,j,bx,by,sigma) :915
+        float mk[4] = {0.f, 0.f, 0.f, 0.f};
+        online_node_update<KIND, true>(n, h, tid, 256, a.d.xa, nullptr, nullptr, D, 0, 0, pitch, eta, decay_fn,
+                                       map, Smap, sigmap, weight, mk);
+        if (!f.do_scan)
+            return;
+        // re-digit the row this workgroup holds and score it against sample j + 1
+        float mx = 0.f;
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float av = fabsf(mk[u]);
+            const bool fin = av <= 3.0e38f;
+            bad |= !fin;
+            mx = (fin && av > mx) ? av : mx;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float om = __shfl_xor(mx, off);
+            mx = om > mx ? om : mx;
+        }
+        bad = __ballot(bad) != 0ull;
+        if (lane == 0) {
+            s_red[wave][0] = mx;
+            s_u[wave] = bad ? 1u : 0u;
+        }
+        __syncthreads();
+        mx = fmaxf(fmaxf(s_red[0][0], s_red[1][0]), fmaxf(s_red[2][0], s_red[3][0]));
+        bad = (s_u[0] | s_u[1] | s_u[2] | s_u[3]) != 0u;
+        __syncthreads();
+        float s, is;
+        onl_row_scale(mx, s, is);
+        float dot = 0.f, nm = 0.f, r2 = 0.f, eps = 0.f;
+        unsigned char *irow = o.img + n * (size_t)o.ipitch;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = tid + u * 256;
+            float q, r;
+            onl_digit(mk[u], s, is, q, r);
+            if (d < D) {
+                irow[d] = (unsigned char)((int)q + 128);
+                dot = fmaf(xn[u], q, dot);
+                nm = nm + mk[u] * mk[u];
+                r2 = r2 + r * r;
+                const float ar = fabsf(r);
+                eps = ar > eps ? ar : eps;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            dot += __shfl_xor(dot, off);
+            nm += __shfl_xor(nm, off);
+            r2 += __shfl_xor(r2, off);
+            const float oe = __shfl_xor(eps, off);
+            eps = oe > eps ? oe : eps;
+        }
+        if (lane == 0) {
+            s_red[wave][0] = dot;
+            s_red[wave][1] = nm;
+            s_red[wave][2] = r2;
+            s_red[wave][3] = eps;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            dot = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+            nm = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+            r2 = (s_red[0][2] + s_red[1][2]) + (s_red[2][2] + s_red[3][2]);
+            eps = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
+            const float rho = sqrtf(r2 * 1.0001f) * 1.0001f;
+            const float sn = bad ? __uint_as_float(0x7FC00000u) : s;
+            o.nsc[n] = make_float4(sn, nm, eps, rho);
+            const float4 xs = o.xsc[f.jnext];
+            const float A = fmaf(-2.f * sn, dot, nm);
+            float L, U;
+            onl_interval(A, sn, nm, eps, rho, xs, o.cT, o.g2c, L, U);
+            o.lb[n] = L;
+            if (U < inf)
+                atomicMin(&o.uslots[(parn * ONL_USLOTS + ((int)blockIdx.x & (ONL_USLOTS - 1))) * 32], onl_fkey(U));
+        }
+        return;
+    }
+    // ---- scan role: 32 nodes per workgroup, 8 lanes per node, from the image
+    if (!f.do_scan)
+        return;
+    const int sb = (int)blockIdx.x - nwin;
+    if (sb == 0 && tid < ONL_USLOTS)                     // nobody reads or writes the other parity's slots during this launch
+        o.uslots[((a.par) * ONL_USLOTS + tid) * 32] = 0xFFFFFFFFu;
+    const int node = sb * 32 + (tid >> 3), k = tid & 7;
+    const int nc = node < a.N ? node : a.N - 1;
+    uint4 pc[8];
+    const unsigned char *irow = o.img + (size_t)nc * o.ipitch + 16 * k;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < o.ni)
+            pc[i] = *reinterpret_cast<const uint4 *>(irow + 128 * i);
+    {
+        const int d = tid * 4;
+        const float4 t = d < D ? *reinterpret_cast<const float4 *>(f.xnext + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(s_x + d) = t;        // rows are zero padded to a multiple of 32 floats
+    }
+    const float4 nsc = o.nsc[nc];
+    const float4 xs = o.xsc[f.jnext];
+    bool inwin = false;
+    if (f.do_window) {                                   // nodes of the window are scored by their own workgroups
+        const u64 bmu = online_resolve(a.state, a.par);
+        int bx, by;
+        u64 startX, startY, endX, endY;
+        online_window(bmu, a.W, a.H, sigma, bx, by, startX, startY, endX, endY);
+        const u64 nx_ = (u64)nc % (u64)a.W, ny_ = (u64)nc / (u64)a.W;
+        inwin = nx_ >= startX && nx_ < endX && ny_ >= startY && ny_ < endY;
+    }
+    __syncthreads();
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < o.ni) {
+            const float4 *xp = reinterpret_cast<const float4 *>(s_x + (i * 8 + k) * 16);
+            const unsigned wv[4] = {pc[i].x, pc[i].y, pc[i].z, pc[i].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 xv = xp[c];
+                const unsigned w = wv[c];
+                t0 = fmaf(xv.x, (float)(w & 0xFFu), t0);
+                t1 = fmaf(xv.y, (float)((w >> 8) & 0xFFu), t1);
+                t0 = fmaf(xv.z, (float)((w >> 16) & 0xFFu), t0);
+                t1 = fmaf(xv.w, (float)(w >> 24), t1);
+            }
+        }
+    }
+    float T = t0 + t1;
+    T += __shfl_xor(T, 1);
+    T += __shfl_xor(T, 2);
+    T += __shfl_xor(T, 4);
+    const float Tq = fmaf(-128.f, xs.z, T);              // <x, q> = <x, u> - 128 sum x
+    const float A = fmaf(-2.f * nsc.x, Tq, nsc.y);
+    float L, U;
+    onl_interval(A, nsc.x, nsc.y, nsc.z, nsc.w, xs, o.cT, o.g2c, L, U);
+    const bool mine = node < a.N && !inwin;
+    if (mine && k == 0)
+        o.lb[node] = L;
+    unsigned uk = (mine && U < inf) ? onl_fkey(U) : 0xFFFFFFFFu;
+    for (int off = 32; off >= 8; off >>= 1) {
+        const unsigned ou = (unsigned)__shfl_xor((int)uk, off);
+        uk = ou < uk ? ou : uk;
+    }
+    if (lane == 0)
+        s_u[wave] = uk;
+    __syncthreads();
+    if (tid == 0) {
+        uk = min(min(s_u[0], s_u[1]), min(s_u[2], s_u[3]));
+        if (uk != 0xFFFFFFFFu)
+            atomicMin(&o.uslots[(parn * ONL_USLOTS + (sb & (ONL_USLOTS - 1))) * 32], uk);
+    }
+}
+
+// exact-order distance with every element of the lane's accumulator class requested before the first is used (one
+// memory round trip; rows of at most 8 * MAXI values): the operations and their order per class are vsom_group_dist's
+template <int MAXI>
+__device__ __forceinline__ float onl_dist_all(const float *__restrict__ x, const float *__restrict__ m, int L, int k)
+{
+    const int L8 = L & ~7, ni = L8 >> 3;
+    float mv[MAXI];
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u)
+        mv[u] = m[k + 8 * (u < ni ? u : (ni > 0 ? ni - 1 : 0))];
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXI; ++u) {
+        if (u < ni) {
+            const float r = mv[u] - x[k + 8 * u];
+            const float p = r * r;
+            acc = acc + p;
+        }
+    }
+    float q = acc + __shfl_xor(acc, 4);
+    const int rem = L - L8;
+    if (rem >= 4) {
+        const int d = L8 + (k & 3);
+        const float r = m[d] - x[d];
+        const float p = r * r;
+        q = q + p;
+    }
+    const float t = q + __shfl_xor(q, 2);
+    float res = t + __shfl_xor(t, 1);
+    for (int tt = (rem >= 4 ? 4 : 0); tt < rem; ++tt) {
+        const int d = L8 + tt;
+        const float r = m[d] - x[d];
+        const float p = r * r;
+        res = res + p;
+    }
+    return res;
+}
+
+// refinement of sample j (a.par, row a.d.xa) + the post step of sample j - 1 (rows a.pxa) in the last workgroup
+template <int MAXI>   // rows of at most 8 * MAXI values
+__global__ __launch_bounds__(256) void onl_refine_kernel(OnlineArgs a, OnlI8 o, int do_refine, u64 *hits, u64 *lastbmu_out, float fB,
+                                                         int add_hit)
+{
+    __shared__ __attribute__((aligned(16))) float s_x[1024];
+    __shared__ int s_list[ONL_REF_NODES];
+    __shared__ int s_cnt[2];
+    __shared__ u64 skey[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (blockIdx.x == gridDim.x - 1) {
+        if (a.do_post && tid < 64) {
+            const u64 bmu = online_resolve(a.state, a.par ^ 1);
+            online_post<false>(a, a.pxa, a.pxb, bmu, tid, hits, lastbmu_out, nullptr, fB, add_hit);
+            if (tid < ONL_SLOTS)
+                *online_slot(a.state, a.par ^ 1, tid) = ~0ull;    // the key set of the sample after this one
+        }
+        return;
+    }
+    if (!do_refine)
+        return;
+    const int nbase = (int)blockIdx.x * ONL_REF_NODES;
+    {
+        const int d = tid * 4;
+        const float4 t = d < a.d.L ? *reinterpret_cast<const float4 *>(a.d.xa + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(s_x + d) = t;
+    }
+    const float umin = onl_umin(o.uslots, a.par);
+    bool cand = false;
+    if (tid < ONL_REF_NODES) {
+        const int n = nbase + tid;
+        if (n < a.N) {
+            const float L = o.lb[n];
+            cand = !(L > umin) || n == 0;                // (node 0 seeds the reference's search, Som.cpp:293-299)
+        }
+    }
+    if (wave < 2) {
+        const u64 bm = __ballot(cand);
+        if (lane == 0)
+            s_cnt[wave] = __popcll(bm);
+    }
+    __syncthreads();
+    if (wave < 2 && cand) {
+        const u64 bm = __ballot(cand);   // (re-evaluated inside the divergent region: mask of the active lanes = the candidates)
+        const int pos = __popcll(bm & ((1ull << lane) - 1ull)) + (wave == 1 ? s_cnt[0] : 0);
+        s_list[pos] = nbase + tid;
+    }
+    __syncthreads();
+    const int cnt = s_cnt[0] + s_cnt[1];
+    if (cnt == 0)
+        return;
+    const int grp = tid >> 3, k = tid & 7;
+    u64 best = ~0ull;
+    for (int c0 = 0; c0 < cnt; c0 += 32) {
+        const int c = c0 + grp;
+        const int node = s_list[c < cnt ? c : cnt - 1];
+        const float *mrow = a.d.ma + (size_t)node * a.d.ldm;
+        const float d = onl_dist_all<MAXI>(s_x, mrow, a.d.L, k);
+        if (c < cnt) {
+            const u64 key = vsom_key(d, (uint32_t)node);
+            best = key < best ? key : best;
+            if (node == 0 && k == 0)
+                a.state[ONL_FLAG + a.par] = (d != d) ? 1ull : 0ull;
+        }
+    }
+    for (int off = 32; off >= 8; off >>= 1) {
+        const u64 ob = __shfl_xor(best, off);
+        best = ob < best ? ob : best;
+    }
+    if (lane == 0)
+        skey[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+        u64 m = skey[0];
+        for (int i = 1; i < 4; ++i)
+            m = skey[i] < m ? skey[i] : m;
+        if (m != ~0ull)
+            atomicMin(online_slot(a.state, a.par, (int)(blockIdx.x % ONL_SLOTS)), m);
+    }
+}
+
+__global__ void onl_uslots_init_kernel(unsigned *uslots)
+{
+    const int t = threadIdx.x;
+    if (t < 2 * ONL_USLOTS)
+        uslots[t * 32] = 0xFFFFFFFFu;
 }
 
 // double-precision table of calculateNeighbourhoodWeight for the online path (the batch path
@@ -617,6 +1131,154 @@ static int stage_single(vsom_ctx *c, const float *v_host)
     return VSOM_OK;
 }
 
+// ---- single-vector queries (Som::euclidianWeightedDist / Som::findLocalBmu of ONE host vector) ----------------------
+// one wavefront; results into the 16-byte tail behind the single-sample rows: {u64 index, float distance}
+template <bool CLR>
+__global__ __launch_bounds__(64) void single_dist_kernel(DistArgs d, u64 node, u64 *out_idx, float *out_dist)
+{
+    const int lane = threadIdx.x;
+    const float v = vsom_group_dist_lat<CLR>(d.xa, d.xb, d.ma + (size_t)node * d.ldm, d.mb + (size_t)node * d.ldm, d.L, lane & 7);
+    if (lane == 0) {
+        *out_idx = node;
+        *out_dist = v;
+    }
+}
+
+template <bool CLR>
+__global__ __launch_bounds__(64) void single_local_kernel(DistArgs d, u64 W, u64 H, u64 start, u64 *out_idx, float *out_dist)
+{
+    u64 idx;
+    float dist;
+    vsom_local_walk<CLR>(d, d.xa, d.xb, W, H, start, (int)threadIdx.x, idx, dist);
+    if (threadIdx.x == 0) {
+        *out_idx = idx;
+        *out_dist = dist;
+    }
+}
+
+// ---- host side of the image-bounded search ------------------------------------------------------------------------
+// Does the chunk loop of this context search through the image?  VSOM_BMU_EXACT: never; VSOM_BMU_SHORTLIST: whenever the
+// kernels apply (Standard / Median, rows of at most 1024 values, sigma > 1); VSOM_BMU_AUTO: where it pays -- a map of at
+// least 8 MiB (below that the exact scan is a few microseconds of launch latency either way) and a chunk long enough to
+// repay the per-chunk digit pass over the whole map.
+static bool onl_i8_applies(const vsom_ctx *c, double sigma)
+{
+    if (c->transform == VSOM_CLR || c->part_len > 1024 || !(sigma > 1) || c->bmu_mode == VSOM_BMU_EXACT || c->B == 0)
+        return false;
+    if (c->bmu_mode == VSOM_BMU_SHORTLIST)
+        return true;
+    return (size_t)c->N * c->pitch * 4 >= ((size_t)8 << 20) && c->B >= 16;
+}
+
+static int onl_i8_ensure(vsom_ctx *c, OnlI8 *o)
+{
+    const uint32_t ipitch = (c->part_len + 127) / 128 * 128;
+    if (!c->onl_img) {
+        VSOM_HIP_CHECK(hipMalloc(&c->onl_img, (size_t)c->N * ipitch));
+        VSOM_HIP_CHECK(hipMalloc(&c->onl_nsc, (size_t)c->N * sizeof(float4)));
+        VSOM_HIP_CHECK(hipMalloc(&c->onl_lb, (size_t)c->N * sizeof(float)));
+        VSOM_HIP_CHECK(hipMalloc(&c->onl_u, ONL_U_BYTES));
+    }
+    if (c->onl_xsc_cap < c->B) {
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->onl_xsc)
+            (void)hipFree(c->onl_xsc);
+        c->onl_xsc = nullptr;
+        c->onl_xsc_cap = 0;
+        VSOM_HIP_CHECK(hipMalloc(&c->onl_xsc, c->Bcap * sizeof(float4)));
+        c->onl_xsc_cap = c->Bcap;
+    }
+    const double u = 5.9604644775390625e-8;
+    o->img = c->onl_img;
+    o->nsc = (float4 *)c->onl_nsc;
+    o->lb = c->onl_lb;
+    o->uslots = c->onl_u;
+    o->xsc = (const float4 *)c->onl_xsc;
+    o->ipitch = (int)ipitch;
+    o->ni = (int)(ipitch / 128);
+    o->cT = (float)((2.0 * 35000.0 + 256.0) * u);
+    o->g2c = (float)(1.05 * ((double)c->part_len / 8.0 + 16.0) * u);
+    return VSOM_OK;
+}
+
+// the chunk loop through the image: per chunk a digit pass over the map and the samples' bound terms, then per sample
+// onl_refine_kernel (sample j; finishes sample j - 1) and onl_fused_kernel (window of sample j || image scan for j + 1)
+static int enqueue_chunk_i8(vsom_ctx *c, double eta, double sigma, int decay_fn, const double *lutd, int lutw)
+{
+    OnlI8 o;
+    if (int rc = onl_i8_ensure(c, &o))
+        return rc;
+    const int N = (int)c->N, D = (int)c->part_len;
+    const size_t B = c->B;
+    hipLaunchKernelGGL(onl_digit_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, c->map, (int)c->pitch, D, N, o);
+    hipLaunchKernelGGL(onl_prep_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, c->stream, c->Xs, (int)c->xpitch, D, (int)B,
+                       (float4 *)c->onl_xsc);
+    hipLaunchKernelGGL(onl_uslots_init_kernel, dim3(1), dim3(128), 0, c->stream, c->onl_u);
+    OnlineArgs a;
+    a.d.ldx = 0;
+    a.d.ma = a.d.mb = c->map;
+    a.d.ldm = (int)c->pitch;
+    a.d.L = D;
+    a.state = c->onl_state;
+    a.fstate = c->onl_f;
+    a.N = N;
+    a.W = (int)c->W;
+    a.H = (int)c->H;
+    a.do_scan = 1;
+    const float fB = (float)B;
+    double ext = std::floor(5.0 * sigma) + 2.0;          // maximal window extents (enqueue_single)
+    const int gx = (int)std::min<double>((double)c->W, ext), gy = (int)std::min<double>((double)c->H, ext);
+    const unsigned nscan = (unsigned)((N + 31) / 32), nref = (unsigned)((N + ONL_REF_NODES - 1) / ONL_REF_NODES);
+    const bool med = c->transform == VSOM_MEDIAN;
+    auto fused = [&](const float *xs_j, int par_j, const float *xs_next, size_t jnext, bool win, bool scan) {
+        OnlFusedArgs f;
+        f.a = a;
+        f.a.d.xa = f.a.d.xb = xs_j;
+        f.a.par = par_j;
+        f.xnext = xs_next;
+        f.jnext = (int)jnext;
+        f.do_window = win ? 1 : 0;
+        f.do_scan = scan ? 1 : 0;
+        f.nwin_x = gx > 0 ? gx : 1;
+        f.nwin_y = gy > 0 ? gy : 1;
+        const unsigned grid = (win ? (unsigned)(f.nwin_x * f.nwin_y) : 0u) + (scan ? nscan : 0u);
+        if (med)
+            hipLaunchKernelGGL(onl_fused_kernel<VSOM_MEDIAN>, dim3(grid), dim3(256), 0, c->stream, f, o, lutd, lutw, D, (int)c->pitch,
+                               eta, sigma, decay_fn, c->map, c->S, c->sigma, c->weight);
+        else
+            hipLaunchKernelGGL(onl_fused_kernel<VSOM_STANDARD>, dim3(grid), dim3(256), 0, c->stream, f, o, lutd, lutw, D, (int)c->pitch,
+                               eta, sigma, decay_fn, c->map, c->S, c->sigma, c->weight);
+    };
+    auto refine = [&](const float *xs_j, int par_j, const float *xs_prev, u64 *lb_prev, bool do_refine) {
+        OnlineArgs r = a;
+        r.d.xa = r.d.xb = xs_j;
+        r.par = par_j;
+        r.pxa = r.pxb = xs_prev;
+        r.do_post = xs_prev != nullptr;
+        const dim3 grid((do_refine ? nref : 0u) + 1u);
+        const int dr = do_refine ? 1 : 0;
+        if (D <= 128)
+            hipLaunchKernelGGL(onl_refine_kernel<16>, grid, dim3(256), 0, c->stream, r, o, dr, c->hits, lb_prev, fB, 1);
+        else if (D <= 512)
+            hipLaunchKernelGGL(onl_refine_kernel<64>, grid, dim3(256), 0, c->stream, r, o, dr, c->hits, lb_prev, fB, 1);
+        else
+            hipLaunchKernelGGL(onl_refine_kernel<128>, grid, dim3(256), 0, c->stream, r, o, dr, c->hits, lb_prev, fB, 1);
+    };
+    // scores of sample 0 (no window yet): the launch works on "sample -1" of parity 1
+    fused(c->Xs, 1, c->Xs, 0, false, true);
+    const float *prev = nullptr;
+    for (size_t j = 0; j < B; ++j) {
+        const float *xs = c->Xs + j * c->xpitch;
+        refine(xs, (int)(j & 1), prev, j ? c->lastbmu + (j - 1) : nullptr, true);
+        const bool more = j + 1 < B;
+        fused(xs, (int)(j & 1), more ? xs + c->xpitch : xs, more ? j + 1 : j, true, more);
+        prev = xs;
+    }
+    // finish the last sample: its post step runs as the "previous sample" of a launch of the other parity
+    refine(prev, (int)(B & 1), prev, c->lastbmu + (B - 1), false);
+    return VSOM_OK;
+}
+
 extern "C" {
 
 // Som::findBmu(v) for ONE host vector (Som.cpp:283-309) without touching the staged chunk: copy,
@@ -677,6 +1339,69 @@ int vsom_find_bmu(vsom_ctx *c, const float *v_host, uint64_t *bmu_out, float *di
     return VSOM_OK;
 }
 
+// shared by the two single-vector queries below: stage v, launch `which` (0: distance to `node`; 1: local search from
+// `node`), 16 bytes back -- one synchronisation, no allocation, the staged chunk untouched
+static int single_query(vsom_ctx *c, const float *v_host, uint64_t node, int which, uint64_t *idx_out, float *dist_out)
+{
+    if (!c)
+        return vsom_fail(VSOM_ERR_INVALID, "null context");
+    VSOM_HIP_CHECK(hipSetDevice(c->device));
+    if (int jrc = vsom_join_aux(c))
+        return jrc;
+    if (!v_host)
+        return vsom_fail(VSOM_ERR_INVALID, "null argument");
+    if (node >= c->N)
+        return vsom_fail(VSOM_ERR_INVALID, "node index out of range");
+    int rc = stage_single(c, v_host);
+    if (rc)
+        return rc;
+    const bool clr = c->transform == VSOM_CLR;
+    const size_t xs_n = c->xpitch, pp = c->part_pitch;
+    float *xs = c->v_dev, *xp = c->v_dev + xs_n, *yp = xp + pp, *tail = yp + 2 * pp;
+    DistArgs d;
+    d.xa = clr ? xp : xs;
+    d.xb = clr ? yp : xs;
+    d.ldx = 0;
+    d.ma = c->map;
+    d.mb = clr ? c->map + c->part_pitch : c->map;
+    d.ldm = (int)c->pitch;
+    d.L = (int)c->part_len;
+    u64 *oi = reinterpret_cast<u64 *>(tail);
+    float *od = tail + 2;
+    if (which == 0) {
+        if (clr)
+            hipLaunchKernelGGL(single_dist_kernel<true>, dim3(1), dim3(64), 0, c->stream, d, (u64)node, oi, od);
+        else
+            hipLaunchKernelGGL(single_dist_kernel<false>, dim3(1), dim3(64), 0, c->stream, d, (u64)node, oi, od);
+    } else {
+        if (clr)
+            hipLaunchKernelGGL(single_local_kernel<true>, dim3(1), dim3(64), 0, c->stream, d, (u64)c->W, (u64)c->H, (u64)node, oi, od);
+        else
+            hipLaunchKernelGGL(single_local_kernel<false>, dim3(1), dim3(64), 0, c->stream, d, (u64)c->W, (u64)c->H, (u64)node, oi, od);
+    }
+    VSOM_HIP_CHECK(hipGetLastError());
+    float *pout = c->v_pinned + xs_n + 3 * pp;           // host image of the tail
+    VSOM_HIP_CHECK(hipMemcpyAsync(pout, tail, 16, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (idx_out)
+        std::memcpy(idx_out, pout, 8);
+    if (dist_out)
+        *dist_out = pout[2];
+    return VSOM_OK;
+}
+
+// Som::euclidianWeightedDist(pos, v, ...) for ONE host vector (Som.cpp:124-141)
+int vsom_dist_single(vsom_ctx *c, const float *v_host, uint64_t node, float *dist_out)
+{
+    return single_query(c, v_host, node, 0, nullptr, dist_out);
+}
+
+// Som::findLocalBmu(v, ..., lastBMU, ...) for ONE host vector (Som.cpp:335-454)
+int vsom_find_local_bmu(vsom_ctx *c, const float *v_host, uint64_t last_bmu, uint64_t *bmu_out, float *dist_out)
+{
+    return single_query(c, v_host, last_bmu, 1, bmu_out, dist_out);
+}
+
 int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay_fn, int first_chunk,
                                 float *mse_out)
 {
@@ -701,6 +1426,10 @@ int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay
         TimerScope ts(c, VSOM_T_ONLINE);
         hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f,
                            first_chunk ? 0 : 1);
+        if (onl_i8_applies(c, sigma)) {
+            if ((rc = enqueue_chunk_i8(c, eta, sigma, decay_fn, lutd, lutw)))
+                return rc;
+        } else {
         const float fB = (float)c->B;
         const bool pipelined = sigma > 1;     // the search launch of sample j finishes sample j-1 (online_scan_kernel)
         const float *pxs = nullptr, *pxp = nullptr, *pyp = nullptr;
@@ -719,6 +1448,7 @@ int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay
         if (pipelined && c->B > 0 &&
             (rc = enqueue_chunk_tail(c, pxs, pxp, pyp, c->lastbmu + (c->B - 1), fB, (int)((c->B - 1) & 1))))
             return rc;
+        }
         VSOM_HIP_CHECK(hipGetLastError());
     }
     // vsom_get_mse reports the chunk's MSE for callers that passed mse_out = NULL (asynchronous use)

@@ -256,7 +256,10 @@ float Som::hostBatchEpoch(DataSet &dataset, double currentSigma, bool isFirst)
 // Som.cpp:716-754
 void Som::hostTrainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, double sigmaDecay, bool updateUMatrixAfterEpoch)
 {
-    metrics = Som::Metrics(numberOfEpochs);
+    {
+        const std::lock_guard<std::mutex> lock(metricsMutex);   // (the reference resets without it: vsom_host.cpp, trainBatchSom)
+        metrics = Som::Metrics(numberOfEpochs);
+    }
     for (size_t i = 0; i < numberOfEpochs; ++i) {
         std::cout << "Training VSOM epoch " << i << "/" << numberOfEpochs << '\n';
         const double sigma = sigma0 * std::exp(-sigmaDecay * static_cast<double>(i));
@@ -333,7 +336,10 @@ Som::TrainingReturnValue Som::hostTrainSingle(const Vec &v, const Vec &valid, co
 void Som::hostTrainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, double etaDecay, double sigma0, double sigmaDecay,
                             WeigthDecayFunction fn, bool updateUMatrixAfterEpoch)
 {
-    metrics = Som::Metrics(numberOfEpochs);
+    {
+        const std::lock_guard<std::mutex> lock(metricsMutex);   // (the reference resets without it: vsom_host.cpp, trainBatchSom)
+        metrics = Som::Metrics(numberOfEpochs);
+    }
     const Vec weights = data.getWeights();
     for (size_t i = 0; i < numberOfEpochs; ++i) {
         const double eta = eta0 * std::exp(-etaDecay * static_cast<double>(i));

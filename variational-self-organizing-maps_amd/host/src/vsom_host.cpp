@@ -953,10 +953,10 @@ SomIndex Som::findLocalBmu(const Eigen::VectorXf &v, const Eigen::VectorXf &vali
         const size_t idx = hostFindLocalBmu(v, valid, lastBMUref, weights);
         return SomIndex(idx % width, idx / width);
     }
-    stageOne(v);
+    if ((size_t)v.size() != inLen)
+        throw std::invalid_argument("sample length does not match the map");
     uint64_t idx = lastBMUref;
-    check(vsom_set_last_bmu(ctx, &idx), "vsom_set_last_bmu");
-    check(vsom_bmu_local_batch(ctx, &idx, nullptr), "vsom_bmu_local_batch");
+    check(vsom_find_local_bmu(ctx, v.data(), lastBMUref, &idx, nullptr), "vsom_find_local_bmu");
     return SomIndex((size_t)idx % width, (size_t)idx / width);
 }
 
@@ -971,10 +971,10 @@ double Som::euclidianWeightedDist(const size_t &pos, const Eigen::VectorXf &v, c
 {
     if (!ctx)
         return hostDist(pos, v, valid, weights);
-    stageOne(v);
-    uint64_t node = pos, row = 0;
+    if ((size_t)v.size() != inLen)
+        throw std::invalid_argument("sample length does not match the map");
     float d = 0.f;
-    check(vsom_distances(ctx, &node, &row, 1, &d), "vsom_distances");
+    check(vsom_dist_single(ctx, v.data(), pos, &d), "vsom_dist_single");
     return (double)d;
 }
 
@@ -1021,7 +1021,11 @@ void Som::trainBatchSom(DataSet &data, size_t numberOfEpochs, double sigma0, dou
 {
     if (!ctx)
         return hostTrainBatchSom(data, numberOfEpochs, sigma0, sigmaDecay, updateUMatrixAfterEpoch);
-    metrics = Som::Metrics(numberOfEpochs);   // Som.cpp:719
+    {   // Som.cpp:719 resets the metrics WITHOUT the mutex (a thread copying them under it races with the reassignment);
+        // here the reset takes it, like every later write
+        const std::lock_guard<std::mutex> lock(metricsMutex);
+        metrics = Som::Metrics(numberOfEpochs);
+    }
     auto sigmaOf = [&](size_t e) { return sigma0 * std::exp(-sigmaDecay * static_cast<double>(e)); };   // :727
     bool have = false;                // a loaded chunk is waiting in `data`, its copy is in flight
     size_t B = 0;
@@ -1152,7 +1156,10 @@ void Som::trainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, doubl
         check(vsom_group_synchronize(grp), "vsom_group_synchronize");
         replicasStale = true;                 // the online path trains member 0 only (sequential in samples)
     }
-    metrics = Som::Metrics(numberOfEpochs);   // Som.cpp:1139
+    {   // Som.cpp:1139, under the mutex here (see trainBatchSom)
+        const std::lock_guard<std::mutex> lock(metricsMutex);
+        metrics = Som::Metrics(numberOfEpochs);
+    }
     for (size_t i = 0; i < numberOfEpochs; ++i) {
         auto eta = eta0 * std::exp(-etaDecay * static_cast<double>(i));         // :1145
         auto sigma = sigma0 * std::exp(-sigmaDecay * static_cast<double>(i));   // :1146

@@ -403,7 +403,8 @@ static int threads_mode(const std::string &out)
             {
                 const std::lock_guard<std::mutex> lock(som.metricsMutex);
                 const auto m = som.getMetrics();
-                if (m.MeanSquaredError.size() != 0 && m.MeanSquaredError.size() != 6)
+                // the constructor sizes the metrics by the depth (Som.cpp:47), train() by the epochs (:719) -- nothing else
+                if (m.MeanSquaredError.size() != J && m.MeanSquaredError.size() != 6)
                     sizes_ok = 0;
             }
             ++polls;
