@@ -104,6 +104,9 @@ def parse():
     ap.add_argument("--no-stage-ahead", action="store_true",
                     help="N = 1 batch steps: stage every chunk at the start of its own step (rounds 1-4) instead of beside "
                          "the chains of the previous step (vsom_stage_next_device / vsom_commit_chunk)")
+    ap.add_argument("--online-search", choices=["auto", "exact", "image"], default="auto",
+                    help="--config online: how the chunk loop finds each sample's BMU (vsom_set_bmu_mode): exact = the fp32 "
+                         "scan of the whole map per sample; image = the one-byte image + exact refinement; auto = the library's choice")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--nchunks", type=int, default=4, help="distinct resident chunks cycled over")
@@ -330,6 +333,8 @@ def main():
     D = ctx.depth
     init_map = make_map(cfg, D, args.data)
     ctx.set_state(map=init_map)
+    if online and args.online_search != "auto":
+        ctx.set_bmu_mode({"exact": capi.BMU_EXACT, "image": capi.BMU_SHORTLIST}[args.online_search])
     eng = vdist.HipEngine(ctx, dev, stream)      # the context adopts `stream`; collectives run on it too
     trainer = vdist.ShardedBatchTrainer(eng, rank if sharded else 0, world if sharded else 1)
     is_first = not args.local
