@@ -464,6 +464,7 @@ def main():
     dt, timing = timed(split, args.warmup, args.steps)
     mse = float(ctx.get_mse())
     sl_stats = ctx.shortlist_stats() if not online else None
+    onl_stats = ctx.online_search_stats() if online else None
     # like for like with rounds 1-4 and BASELINE: the same steps with every chunk staged at the start of its own step
     dt_in_step = None
     if pipelined:
@@ -639,6 +640,14 @@ def main():
             "mse_last": mse,
             "bmu_shortlist_last": sl_stats,
         }
+        if onl_stats is not None:
+            n_s = max(onl_stats["samples"], 1)
+            out["online_search"] = {
+                "mode": args.online_search,
+                "through_the_image": onl_stats["samples"] > 0,
+                "samples": onl_stats["samples"],
+                "exact_evaluations_per_sample": round(onl_stats["exact_evaluations"] / n_s, 2),
+                "refine_workgroups_per_sample": round(onl_stats["refine_workgroups"] / n_s, 2)}
         if others:
             out["other_arithmetics"] = []
             for oname, dto, tmo in others:

@@ -253,6 +253,10 @@ int vsom_train_online_chunk(vsom_ctx *ctx, double eta, double sigma, int decay_f
  * vsom_train_online_chunk = first_chunk 1. */
 int vsom_train_online_chunk_acc(vsom_ctx *ctx, double eta, double sigma, int decay_fn, int first_chunk,
                                 float *mse_out);
+/* diagnostics of the chunk loop's image-bounded search (csrc/vsom_online.hip; synchronises): out[0] = samples searched
+ * through the image since the last reset, out[1] = nodes evaluated exactly for them (the candidates that survived the
+ * bound), out[2] = refinement workgroups that had a candidate, out[3] = 0.  All zero while the exact scan is in use. */
+int vsom_get_online_search_stats(vsom_ctx *ctx, uint64_t *out /*[4]*/, int reset);
 
 /* ---- multi-GPU batch epoch, one process, the GPUs of one node ------------------------
  * Som::trainBatchSomEpoch's two loops shard differently: phase 1 (Som.cpp:764-782 / 786-805) is

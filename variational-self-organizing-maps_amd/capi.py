@@ -33,7 +33,7 @@ SYMBOLS = [
     "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_find_bmu", "vsom_dist_single", "vsom_find_local_bmu", "vsom_bmu_local_batch",
     "vsom_distances", "vsom_bmu_restricted_batch", "vsom_distances_row", "vsom_distances_raw", "vsom_batch_phase1_async", "vsom_batch_finish_async",
     "vsom_batch_phase2_async", "vsom_batch_epoch_async", "vsom_batch_epoch", "vsom_get_mse",
-    "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk", "vsom_train_online_chunk_acc",
+    "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk", "vsom_train_online_chunk_acc", "vsom_get_online_search_stats",
     "vsom_neighbourhood_weight", "vsom_device_ptr", "vsom_chunk_size", "vsom_pitch",
     "vsom_chunk_pitch", "vsom_small_map_chains", "vsom_enable_timing", "vsom_enable_timing_of", "vsom_get_timing",
     "vsom_group_create", "vsom_group_destroy", "vsom_group_size", "vsom_group_ctx", "vsom_group_transport",
@@ -151,6 +151,7 @@ def lib():
     L.vsom_batch_epoch.argtypes = [vp, C.c_double, C.c_int, fp]
     L.vsom_get_mse.argtypes = [vp, fp]
     L.vsom_train_single.argtypes = [vp, fp, C.c_double, C.c_double, u64p, C.c_int, fp, fp, u64p]
+    L.vsom_get_online_search_stats.argtypes = [vp, u64p, C.c_int]
     L.vsom_dist_single.argtypes = [vp, fp, C.c_uint64, fp]
     L.vsom_find_local_bmu.argtypes = [vp, fp, C.c_uint64, u64p, fp]
     L.vsom_train_online_chunk.argtypes = [vp, C.c_double, C.c_double, C.c_int, fp]
@@ -467,6 +468,13 @@ class Context:
         check(lib().vsom_train_online_chunk_acc(self._h, float(eta), float(sigma), int(decay_fn),
                                                 int(bool(first_chunk)), C.byref(mse)))
         return np.float32(mse.value)
+
+    def online_search_stats(self, reset=False):
+        """image-bounded search of the online chunk loop: samples searched, nodes evaluated exactly, refinement workgroups
+        with work (all zero while the exact scan is in use)"""
+        out = np.zeros(4, np.uint64)
+        check(lib().vsom_get_online_search_stats(self._h, _u(out), int(bool(reset))))
+        return {"samples": int(out[0]), "exact_evaluations": int(out[1]), "refine_workgroups": int(out[2])}
 
     # ---- measurement ---------------------------------------------------
     def enable_timing(self, on=True, groups=None):

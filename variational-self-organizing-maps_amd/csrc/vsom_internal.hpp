@@ -162,6 +162,7 @@ struct vsom_ctx {
     // lower bounds of the sample being searched, min-upper-bound slots, per-sample bound terms
     unsigned char *onl_img = nullptr; void *onl_nsc = nullptr; float *onl_lb = nullptr; unsigned *onl_u = nullptr;
     void *onl_xsc = nullptr; size_t onl_xsc_cap = 0;
+    unsigned char *onl_dirty = nullptr;      // [N] nodes whose sigmaMap row is written at the end of the chunk
 
     // device scratch of the distance queries (vsom_distances / _row / _raw): grow-only
     void *q_scratch = nullptr; size_t q_scratch_cap = 0;

@@ -206,7 +206,20 @@ __device__ __forceinline__ float onl_sign(float a)
 
 // update of ONE window node (Som.cpp:911-943) by the `nthr` threads tid = 0..nthr-1 of a group
 // (a workgroup with BLOCK_SYNC, or a single wavefront running in lockstep without)
-template <int KIND, bool BLOCK_SYNC>
+// store flavours of the window update's rows: 0 plain; 1 nontemporal; 2 write-through (sc1: the line does not stay dirty in
+// the XCD's L2 until the end-of-kernel write-back)
+template <int ST>
+__device__ __forceinline__ void onl_store(float *p, float v)
+{
+    if (ST == 1)
+        __builtin_nontemporal_store(v, p);
+    else if (ST == 2)
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
+template <int KIND, bool BLOCK_SYNC, int ST = 0, bool SIG = true>   // SIG = false: sigmaMap is written later (onl_sigma_kernel)
 __device__ __forceinline__ void online_node_update(size_t n, double h, int tid, int nthr,
                                                    const float *__restrict__ xs, const float *__restrict__ xp,
                                                    const float *__restrict__ yp, int D, int P, int ppitch, int pitch,
@@ -288,9 +301,10 @@ __device__ __forceinline__ void online_node_update(size_t n, double h, int tid, 
             float pr = dl * dl2;
             float uu = hf * pr;
             float s = s_old + uu;                            // :941
-            M[d] = m;
-            S[d] = s;
-            sg[d] = sqrtf(fabsf(s / twf));                   // :942
+            onl_store<ST>(M + d, m);
+            onl_store<ST>(S + d, s);
+            if (SIG)
+                onl_store<ST>(sg + d, sqrtf(fabsf(s / twf)));    // :942
             if (mkeep && u < 4)
                 mkeep[u < 4 ? u : 0] = m;
         }
@@ -466,9 +480,28 @@ __global__ void online_init_kernel(u64 *state, float *fstate, int keep_mse)
 // Anything non-finite on the way (a NaN / inf in the row or in the sample, an overflow) gives L = -inf, U = +inf: the
 // node is always a candidate and never lowers the threshold -- a sample with a NaN then costs a full exact evaluation,
 // spread over the refinement's workgroups.  Node 0 is always evaluated (Som.cpp:293-299: a NaN there pins the BMU).
+#ifdef VSOM_DEVELOPMENT
+// phase stamps of the two kernels (100 MHz wall clock), one writer per role: tools/exp/onl_stamps.py
+__device__ unsigned long long vsom_onl_stamps[32];
+#define ONL_STAMP(i) (vsom_onl_stamps[i] = wall_clock64())
+extern "C" int vsom_dev_onl_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vsom_onl_stamps), sizeof(vsom_onl_stamps)) == hipSuccess ? 0 : -2;
+}
+// entry / exit time of every workgroup of the last fused launch that had both roles
+__device__ unsigned long long vsom_onl_trace[2 * 4096];
+#define ONL_TRACE(slot) do { if (f.do_scan && f.do_window && threadIdx.x == 0 && blockIdx.x < 4096) vsom_onl_trace[2 * blockIdx.x + (slot)] = wall_clock64(); } while (0)
+extern "C" int vsom_dev_onl_trace(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vsom_onl_trace), sizeof(vsom_onl_trace)) == hipSuccess ? 0 : -2;
+}
+#else
+#define ONL_STAMP(i) ((void)0)
+#define ONL_TRACE(slot) ((void)0)
+#endif
 constexpr int ONL_USLOTS = 64;                           // min U: 64 line-sized slots per parity (one lane of a wavefront each)
 constexpr size_t ONL_U_BYTES = 2 * ONL_USLOTS * 128;
-constexpr int ONL_REF_NODES = 128;                       // nodes per refinement workgroup
+constexpr int ONL_REF_NODES = 32;                        // nodes per refinement workgroup (one wavefront per candidate)
 
 struct OnlI8 {
     unsigned char *img;      // [N][ipitch] u = q + 128 (pad bytes 128)
@@ -478,6 +511,8 @@ struct OnlI8 {
     const float4 *xsc;       // [B] {l1, nx, sx, -}
     int ipitch, ni;          // ni = ipitch / 128: 16-byte pieces per lane
     float cT, g2c;           // (2 * 35000 + 256) u ; 1.05 (K / 8 + 16) u
+    u64 *stats;              // [0] samples searched, [1] nodes evaluated exactly, [2] refinement workgroups with work
+    unsigned char *dirty;    // [N] the node's sigmaMap row is owed
 };
 
 // order-preserving key of a (signed, finite) float for the unsigned atomicMin; 0xFFFFFFFF = "no finite U yet"
@@ -635,10 +670,11 @@ struct OnlFusedArgs {
     int jnext;               // its index into xsc
     int do_window, do_scan;
     int nwin_x, nwin_y;      // maximal window extents = window workgroups (do_window)
+    int nscan, passes;       // scan workgroups (do_scan), groups of 32 nodes each of them scores
 };
 
-template <int KIND>
-__global__ __launch_bounds__(256) void onl_fused_kernel(
+template <int KIND, int ST, int PASSES>   // PASSES: groups of 32 nodes per scan workgroup (compile-time: the one-group form keeps 64 VGPRs)
+__global__ __launch_bounds__(256, PASSES == 1 ? 8 : 1) void onl_fused_kernel(
     OnlFusedArgs f, OnlI8 o, const double *__restrict__ lutd, int lutw, int D, int pitch, double eta, double sigma, int decay_fn,
     float *map, float *Smap, float *sigmap, float *weight)   // no __restrict__: f.a.d.ma aliases map
 {
@@ -647,10 +683,22 @@ __global__ __launch_bounds__(256) void onl_fused_kernel(
     __shared__ unsigned s_u[4];
     const OnlineArgs &a = f.a;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int nwin = f.do_window ? f.nwin_x * f.nwin_y : 0;
+    ONL_TRACE(0);
+    // The scan workgroups come FIRST in dispatch order: their loads are in flight from the start, and a window larger than
+    // one round of resident workgroups does not keep them waiting.  (Window first, 512 scan workgroups behind 1764 window
+    // workgroups at sigma = 8: the chip holds 2048, the last 228 scan workgroups started when window workgroups ended and
+    // the launch took the SUM of both roles, 11.3 us under the profiler against 5.1 + 5.7 alone.)
+    const int nscan = f.do_scan ? f.nscan : 0;
     const int parn = a.par ^ 1;                          // parity of the sample being scored
     const float inf = __uint_as_float(0x7F800000u);
-    if ((int)blockIdx.x < nwin) {
+    if ((int)blockIdx.x >= nscan) {
+        const int wb = (int)blockIdx.x - nscan;
+        const bool st_ = tid == 0 && wb == (f.nwin_x * f.nwin_y) / 2 + f.nwin_x / 2;
+        if (st_)
+            ONL_STAMP(8);
+        if (tid == 0 && blockIdx.x == gridDim.x - 1 && f.do_scan)
+            ONL_STAMP(21);
+        const float4 xs = o.xsc[f.do_scan ? f.jnext : 0];   // (uniform address, requested before anything depends on it)
         // ---- window role: one workgroup per node of the (maximal) window of sample j
         float xn[4];
 #pragma unroll
@@ -659,20 +707,28 @@ __global__ __launch_bounds__(256) void onl_fused_kernel(
             xn[u] = (f.do_scan && d < D) ? f.xnext[d] : 0.f;
         }
         const u64 bmu = online_resolve(a.state, a.par);
+        if (st_)
+            ONL_STAMP(9);
         int bx, by;
         u64 startX, startY, endX, endY;
         online_window(bmu, a.W, a.H, sigma, bx, by, startX, startY, endX, endY);
-        const u64 i = startX + (u64)((int)blockIdx.x % f.nwin_x), j = startY + (u64)((int)blockIdx.x / f.nwin_x);
-        if (i >= endX || j >= endY)
+        const u64 i = startX + (u64)(wb % f.nwin_x), j = startY + (u64)(wb / f.nwin_x);
+        if (i >= endX || j >= endY) {
+            ONL_TRACE(1);
             return;
+        }
         const size_t n = (size_t)(j * (u64)a.W + i);
         int dx = (int)i - bx, dy = (int)j - by;
         dx = dx < 0 ? -dx : dx;
         dy = dy < 0 ? -dy : dy;
         const double h = lutd[(size_t)dy * lutw + dx];   // calculateNeighbourhoodWeight(i,j,bx,by,sigma) :915
         float mk[4] = {0.f, 0.f, 0.f, 0.f};
-        online_node_update<KIND, true>(n, h, tid, 256, a.d.xa, nullptr, nullptr, D, 0, 0, pitch, eta, decay_fn,
-                                       map, Smap, sigmap, weight, mk);
+        online_node_update<KIND, true, ST, false>(n, h, tid, 256, a.d.xa, nullptr, nullptr, D, 0, 0, pitch, eta, decay_fn,
+                                                  map, Smap, sigmap, weight, mk);
+        if (tid == 0)
+            o.dirty[n] = 1;                              // sigmaMap[n] = sqrt(|S / w|) is owed (onl_sigma_kernel, end of the chunk)
+        if (st_)
+            ONL_STAMP(10);
         if (!f.do_scan)
             return;
         // re-digit the row this workgroup holds and score it against sample j + 1
@@ -730,6 +786,8 @@ __global__ __launch_bounds__(256) void onl_fused_kernel(
             s_red[wave][3] = eps;
         }
         __syncthreads();
+        if (st_)
+            ONL_STAMP(11);
         if (tid == 0) {
             dot = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
             nm = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
@@ -738,142 +796,205 @@ __global__ __launch_bounds__(256) void onl_fused_kernel(
             const float rho = sqrtf(r2 * 1.0001f) * 1.0001f;
             const float sn = bad ? __uint_as_float(0x7FC00000u) : s;
             o.nsc[n] = make_float4(sn, nm, eps, rho);
-            const float4 xs = o.xsc[f.jnext];
             const float A = fmaf(-2.f * sn, dot, nm);
             float L, U;
             onl_interval(A, sn, nm, eps, rho, xs, o.cT, o.g2c, L, U);
             o.lb[n] = L;
             if (U < inf)
-                atomicMin(&o.uslots[(parn * ONL_USLOTS + ((int)blockIdx.x & (ONL_USLOTS - 1))) * 32], onl_fkey(U));
+                atomicMin(&o.uslots[(parn * ONL_USLOTS + (wb & (ONL_USLOTS - 1))) * 32], onl_fkey(U));
+            if (st_)
+                ONL_STAMP(12);
+            if (blockIdx.x == gridDim.x - 1)
+                ONL_STAMP(22);
         }
+        ONL_TRACE(1);
         return;
     }
-    // ---- scan role: 32 nodes per workgroup, 8 lanes per node, from the image
-    if (!f.do_scan)
-        return;
-    const int sb = (int)blockIdx.x - nwin;
+    // ---- scan role: f.passes groups of 32 nodes per workgroup, one after the other; 8 lanes per node, from the image
+    const int sb = (int)blockIdx.x;
+    const bool st_ = tid == 0 && sb == nscan / 2;
+    if (st_)
+        ONL_STAMP(16);
+    if (tid == 0 && sb == 0)
+        ONL_STAMP(20);
     if (sb == 0 && tid < ONL_USLOTS)                     // nobody reads or writes the other parity's slots during this launch
         o.uslots[((a.par) * ONL_USLOTS + tid) * 32] = 0xFFFFFFFFu;
-    const int node = sb * 32 + (tid >> 3), k = tid & 7;
-    const int nc = node < a.N ? node : a.N - 1;
-    uint4 pc[8];
-    const unsigned char *irow = o.img + (size_t)nc * o.ipitch + 16 * k;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (i < o.ni)
-            pc[i] = *reinterpret_cast<const uint4 *>(irow + 128 * i);
+    const int k = tid & 7;
     {
         const int d = tid * 4;
         const float4 t = d < D ? *reinterpret_cast<const float4 *>(f.xnext + d) : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4 *>(s_x + d) = t;        // rows are zero padded to a multiple of 32 floats
     }
-    const float4 nsc = o.nsc[nc];
     const float4 xs = o.xsc[f.jnext];
-    bool inwin = false;
-    if (f.do_window) {                                   // nodes of the window are scored by their own workgroups
+    u64 startX = 0, startY = 0, endX = 0, endY = 0;       // (no window: empty)
+    uint4 pc[8];
+    if (f.do_window) {                                   // nodes of the window are scored by their own workgroups: not even loaded
         const u64 bmu = online_resolve(a.state, a.par);
         int bx, by;
-        u64 startX, startY, endX, endY;
         online_window(bmu, a.W, a.H, sigma, bx, by, startX, startY, endX, endY);
-        const u64 nx_ = (u64)nc % (u64)a.W, ny_ = (u64)nc / (u64)a.W;
-        inwin = nx_ >= startX && nx_ < endX && ny_ >= startY && ny_ < endY;
     }
+    const unsigned wx0 = (unsigned)startX, wx1 = (unsigned)endX, wy0 = (unsigned)startY, wy1 = (unsigned)endY, mapw = (unsigned)a.W;
+    auto in_window = [&](int nc) {                       // (32-bit: the bounds are at most the map's sides)
+        const unsigned ny_ = (unsigned)nc / mapw, nx_ = (unsigned)nc - ny_ * mapw;
+        return nx_ >= wx0 && nx_ < wx1 && ny_ >= wy0 && ny_ < wy1;
+    };
+    auto issue = [&](int n_) {
+        const bool live = n_ < a.N && !in_window(n_);
+        const unsigned char *irow = o.img + (size_t)(n_ < a.N ? n_ : a.N - 1) * o.ipitch + 16 * k;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < o.ni)                                // (the last round of a row is ragged: 16-byte pieces past it are not read)
+                pc[i] = (live && 128 * i + 16 * k < o.ipitch) ? *reinterpret_cast<const uint4 *>(irow + 128 * i) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    int node = sb * 32 * PASSES + (tid >> 3);
+    issue(node);
     __syncthreads();
-    float t0 = 0.f, t1 = 0.f;
+    if (st_)
+        ONL_STAMP(17);
+    unsigned ukmin = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (int pass = 0; pass < PASSES; ++pass, node += 32) {
+        const int nc = node < a.N ? node : a.N - 1;
+        const float4 nsc = o.nsc[nc];
+        float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i < o.ni) {
-            const float4 *xp = reinterpret_cast<const float4 *>(s_x + (i * 8 + k) * 16);
-            const unsigned wv[4] = {pc[i].x, pc[i].y, pc[i].z, pc[i].w};
+        for (int i = 0; i < 8; ++i) {
+            if (i < o.ni) {
+                const float4 *xp = reinterpret_cast<const float4 *>(s_x + (i * 8 + k) * 16);
+                const unsigned wv[4] = {pc[i].x, pc[i].y, pc[i].z, pc[i].w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 xv = xp[c];
-                const unsigned w = wv[c];
-                t0 = fmaf(xv.x, (float)(w & 0xFFu), t0);
-                t1 = fmaf(xv.y, (float)((w >> 8) & 0xFFu), t1);
-                t0 = fmaf(xv.z, (float)((w >> 16) & 0xFFu), t0);
-                t1 = fmaf(xv.w, (float)(w >> 24), t1);
+                for (int c = 0; c < 4; ++c) {
+                    const float4 xv = xp[c];
+                    const unsigned w = wv[c];
+                    t0 = fmaf(xv.x, (float)(w & 0xFFu), t0);
+                    t1 = fmaf(xv.y, (float)((w >> 8) & 0xFFu), t1);
+                    t0 = fmaf(xv.z, (float)((w >> 16) & 0xFFu), t0);
+                    t1 = fmaf(xv.w, (float)(w >> 24), t1);
+                }
             }
         }
+        if (pass + 1 < PASSES)                           // the next group's rows travel while this one's interval is formed
+            issue(node + 32);
+        float T = t0 + t1;
+        T += __shfl_xor(T, 1);
+        T += __shfl_xor(T, 2);
+        T += __shfl_xor(T, 4);
+        const float Tq = fmaf(-128.f, xs.z, T);          // <x, q> = <x, u> - 128 sum x
+        const float A = fmaf(-2.f * nsc.x, Tq, nsc.y);
+        float L, U;
+        onl_interval(A, nsc.x, nsc.y, nsc.z, nsc.w, xs, o.cT, o.g2c, L, U);
+        const bool mine = node < a.N && !in_window(nc);
+        if (mine && k == 0)
+            o.lb[node] = L;
+        const unsigned uk = (mine && U < inf) ? onl_fkey(U) : 0xFFFFFFFFu;
+        ukmin = uk < ukmin ? uk : ukmin;
     }
-    float T = t0 + t1;
-    T += __shfl_xor(T, 1);
-    T += __shfl_xor(T, 2);
-    T += __shfl_xor(T, 4);
-    const float Tq = fmaf(-128.f, xs.z, T);              // <x, q> = <x, u> - 128 sum x
-    const float A = fmaf(-2.f * nsc.x, Tq, nsc.y);
-    float L, U;
-    onl_interval(A, nsc.x, nsc.y, nsc.z, nsc.w, xs, o.cT, o.g2c, L, U);
-    const bool mine = node < a.N && !inwin;
-    if (mine && k == 0)
-        o.lb[node] = L;
-    unsigned uk = (mine && U < inf) ? onl_fkey(U) : 0xFFFFFFFFu;
+    if (st_)
+        ONL_STAMP(18);
     for (int off = 32; off >= 8; off >>= 1) {
-        const unsigned ou = (unsigned)__shfl_xor((int)uk, off);
-        uk = ou < uk ? ou : uk;
+        const unsigned ou = (unsigned)__shfl_xor((int)ukmin, off);
+        ukmin = ou < ukmin ? ou : ukmin;
     }
     if (lane == 0)
-        s_u[wave] = uk;
+        s_u[wave] = ukmin;
     __syncthreads();
     if (tid == 0) {
-        uk = min(min(s_u[0], s_u[1]), min(s_u[2], s_u[3]));
+        const unsigned uk = min(min(s_u[0], s_u[1]), min(s_u[2], s_u[3]));
         if (uk != 0xFFFFFFFFu)
             atomicMin(&o.uslots[(parn * ONL_USLOTS + (sb & (ONL_USLOTS - 1))) * 32], uk);
     }
+    ONL_TRACE(1);
 }
 
-// exact-order distance with every element of the lane's accumulator class requested before the first is used (one
-// memory round trip; rows of at most 8 * MAXI values): the operations and their order per class are vsom_group_dist's
-template <int MAXI>
-__device__ __forceinline__ float onl_dist_all(const float *__restrict__ x, const float *__restrict__ m, int L, int k)
+// Exact-order distance of ONE (sample, node) pair by ONE wavefront.  The reference's sum runs eight sequential accumulator
+// chains (Eigen's packet classes, vsom_group_dist) -- that part cannot be spread over more lanes -- but the loads and the
+// squares can: the 64 lanes fetch the model row as float4 (at most four each: ONE memory round trip, coalesced), form
+// p = fl(fl(m - x)^2) exactly as vsom_resid / vsom_group_dist do, and park the squares in LDS; eight lanes' worth of chains
+// (every group of eight lanes runs the same ones) then only add LDS values in the reference's order.  8 lanes per
+// candidate with 98 strided loads each took 7.9 us per pass through clamped 64-bit addresses and 3.2 us through a buffer
+// descriptor (profiles/EXPERIMENTS.md); this form is bound by one round trip + 98 dependent additions.
+//   mrow: the node's row (pitch a multiple of 32 floats, pad columns zero); x: the sample's row in LDS (1024 floats, zero
+//   beyond L); sp: this wavefront's 1024-float LDS scratch.
+__device__ __forceinline__ float onl_wave_dist(const float *__restrict__ mrow, const float *__restrict__ x, float *__restrict__ sp, int L,
+                                               int lane)
 {
-    const int L8 = L & ~7, ni = L8 >> 3;
-    float mv[MAXI];
+    float4 mv[4];
 #pragma unroll
-    for (int u = 0; u < MAXI; ++u)
-        mv[u] = m[k + 8 * (u < ni ? u : (ni > 0 ? ni - 1 : 0))];
-    float acc = 0.f;
+    for (int t = 0; t < 4; ++t) {
+        const int d = (lane + 64 * t) * 4;
+        mv[t] = d < L ? *reinterpret_cast<const float4 *>(mrow + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
-    for (int u = 0; u < MAXI; ++u) {
-        if (u < ni) {
-            const float r = mv[u] - x[k + 8 * u];
-            const float p = r * r;
-            acc = acc + p;
+    for (int t = 0; t < 4; ++t) {
+        const int d = (lane + 64 * t) * 4;
+        if (d < L) {
+            const float4 xv = *reinterpret_cast<const float4 *>(x + d);
+            float4 r, p;
+            r.x = mv[t].x - xv.x;
+            r.y = mv[t].y - xv.y;
+            r.z = mv[t].z - xv.z;
+            r.w = mv[t].w - xv.w;
+            p.x = r.x * r.x;
+            p.y = r.y * r.y;
+            p.z = r.z * r.z;
+            p.w = r.w * r.w;
+            *reinterpret_cast<float4 *>(sp + d) = p;
         }
     }
-    float q = acc + __shfl_xor(acc, 4);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this wavefront's LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    const int k = lane & 7, L8 = L & ~7, ni = L8 >> 3;
+    const float *pk = sp + k;
+    float acc = 0.f;
+#pragma unroll 14
+    for (int u = 0; u < ni; ++u)
+        acc = acc + pk[8 * u];
+    float q = acc + __shfl_xor(acc, 4);                  // p0_k + p1_k
     const int rem = L - L8;
-    if (rem >= 4) {
-        const int d = L8 + (k & 3);
-        const float r = m[d] - x[d];
-        const float p = r * r;
-        q = q + p;
-    }
-    const float t = q + __shfl_xor(q, 2);
-    float res = t + __shfl_xor(t, 1);
-    for (int tt = (rem >= 4 ? 4 : 0); tt < rem; ++tt) {
-        const int d = L8 + tt;
-        const float r = m[d] - x[d];
-        const float p = r * r;
-        res = res + p;
-    }
+    if (rem >= 4)
+        q = q + sp[L8 + (k & 3)];
+    const float t2 = q + __shfl_xor(q, 2);
+    float res = t2 + __shfl_xor(t2, 1);
+    for (int tt = (rem >= 4 ? 4 : 0); tt < rem; ++tt)
+        res = res + sp[L8 + tt];
+    __builtin_amdgcn_wave_barrier();                     // (the next evaluation overwrites sp)
     return res;
 }
 
 // refinement of sample j (a.par, row a.d.xa) + the post step of sample j - 1 (rows a.pxa) in the last workgroup
-template <int MAXI>   // rows of at most 8 * MAXI values
 __global__ __launch_bounds__(256) void onl_refine_kernel(OnlineArgs a, OnlI8 o, int do_refine, u64 *hits, u64 *lastbmu_out, float fB,
                                                          int add_hit)
 {
     __shared__ __attribute__((aligned(16))) float s_x[1024];
+    __shared__ __attribute__((aligned(16))) float s_p[4][1024];
     __shared__ int s_list[ONL_REF_NODES];
-    __shared__ int s_cnt[2];
+    __shared__ int s_cnt;
     __shared__ u64 skey[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (blockIdx.x == gridDim.x - 1) {
         if (a.do_post && tid < 64) {
+            if (tid == 0)
+                ONL_STAMP(5);
             const u64 bmu = online_resolve(a.state, a.par ^ 1);
-            online_post<false>(a, a.pxa, a.pxb, bmu, tid, hits, lastbmu_out, nullptr, fB, add_hit);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                // the row of the sample being finished (this wavefront only uses it)
+                const int d = (i * 64 + tid) * 4;
+                const float4 t = d < a.d.L ? *reinterpret_cast<const float4 *>(a.pxa + d) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(s_x + d) = t;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // residual / distance of the BMU after the update (:946), addBmu, MSE, lastBMU -- online_post's steps
+            const float dist = onl_wave_dist(a.d.ma + (size_t)bmu * a.d.ldm, s_x, s_p[0], a.d.L, tid);
+            if (tid == 0) {
+                a.fstate[0] = dist;
+                const float q = dist / fB;               // residual.squaredNorm() / epochSize  (:1167)
+                a.fstate[1] = a.fstate[1] + q;
+                if (add_hit)
+                    hits[bmu] += 1ull;                   // addBmu (:1165, :1189-1192)
+                *lastbmu_out = bmu;                      // lastBMU = by*W + bx (:895)
+                ONL_STAMP(6);
+            }
             if (tid < ONL_SLOTS)
                 *online_slot(a.state, a.par ^ 1, tid) = ~0ull;    // the key set of the sample after this one
         }
@@ -881,54 +1002,55 @@ __global__ __launch_bounds__(256) void onl_refine_kernel(OnlineArgs a, OnlI8 o, 
     }
     if (!do_refine)
         return;
-    const int nbase = (int)blockIdx.x * ONL_REF_NODES;
+    // Workgroup b owns the nodes b + t * nref (t < 32), NOT 32 consecutive ones: the candidates of a sample are its BMU's
+    // neighbours on the map -- consecutive indices -- and one wavefront evaluates one candidate at a time; with consecutive
+    // ownership the BMU's own row segment put 20-30 candidates into one workgroup (5-8 rounds of 1.4 us while 500
+    // workgroups sat idle: the next launch started 6 us after workgroup 0 was done).
+    const int nref = (int)gridDim.x - 1;
+    if (tid == 0 && blockIdx.x == 0)
+        ONL_STAMP(0);
     {
         const int d = tid * 4;
         const float4 t = d < a.d.L ? *reinterpret_cast<const float4 *>(a.d.xa + d) : make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4 *>(s_x + d) = t;
     }
-    const float umin = onl_umin(o.uslots, a.par);
-    bool cand = false;
-    if (tid < ONL_REF_NODES) {
-        const int n = nbase + tid;
-        if (n < a.N) {
+    if (wave == 0) {
+        const float umin = onl_umin(o.uslots, a.par);
+        bool cand = false;
+        const int n = (int)blockIdx.x + lane * nref;
+        if (lane < ONL_REF_NODES && n < a.N) {
             const float L = o.lb[n];
             cand = !(L > umin) || n == 0;                // (node 0 seeds the reference's search, Som.cpp:293-299)
         }
-    }
-    if (wave < 2) {
         const u64 bm = __ballot(cand);
+        if (cand)
+            s_list[__popcll(bm & ((1ull << lane) - 1ull))] = n;
         if (lane == 0)
-            s_cnt[wave] = __popcll(bm);
+            s_cnt = __popcll(bm);
     }
     __syncthreads();
-    if (wave < 2 && cand) {
-        const u64 bm = __ballot(cand);   // (re-evaluated inside the divergent region: mask of the active lanes = the candidates)
-        const int pos = __popcll(bm & ((1ull << lane) - 1ull)) + (wave == 1 ? s_cnt[0] : 0);
-        s_list[pos] = nbase + tid;
-    }
-    __syncthreads();
-    const int cnt = s_cnt[0] + s_cnt[1];
+    const int cnt = s_cnt;
     if (cnt == 0)
         return;
-    const int grp = tid >> 3, k = tid & 7;
-    u64 best = ~0ull;
-    for (int c0 = 0; c0 < cnt; c0 += 32) {
-        const int c = c0 + grp;
-        const int node = s_list[c < cnt ? c : cnt - 1];
-        const float *mrow = a.d.ma + (size_t)node * a.d.ldm;
-        const float d = onl_dist_all<MAXI>(s_x, mrow, a.d.L, k);
-        if (c < cnt) {
-            const u64 key = vsom_key(d, (uint32_t)node);
-            best = key < best ? key : best;
-            if (node == 0 && k == 0)
-                a.state[ONL_FLAG + a.par] = (d != d) ? 1ull : 0ull;
+    if (tid == 0) {          // diagnostics (vsom_get_online_search_stats): a few workgroups per sample get here
+        atomicAdd(&o.stats[1], (u64)cnt);
+        atomicAdd(&o.stats[2], 1ull);
+        if (blockIdx.x == 0) {
+            atomicAdd(&o.stats[0], 1ull);                // (node 0 is always a candidate of workgroup 0)
+            ONL_STAMP(2);
         }
     }
-    for (int off = 32; off >= 8; off >>= 1) {
-        const u64 ob = __shfl_xor(best, off);
-        best = ob < best ? ob : best;
+    u64 best = ~0ull;
+    for (int c = wave; c < cnt; c += 4) {                // one wavefront per candidate
+        const int node = s_list[c];
+        const float d = onl_wave_dist(a.d.ma + (size_t)node * a.d.ldm, s_x, s_p[wave], a.d.L, lane);
+        const u64 key = vsom_key(d, (uint32_t)node);
+        best = key < best ? key : best;
+        if (node == 0 && lane == 0)
+            a.state[ONL_FLAG + a.par] = (d != d) ? 1ull : 0ull;
     }
+    if (tid == 0 && blockIdx.x == 0)
+        ONL_STAMP(3);
     if (lane == 0)
         skey[wave] = best;
     __syncthreads();
@@ -938,7 +1060,32 @@ __global__ __launch_bounds__(256) void onl_refine_kernel(OnlineArgs a, OnlI8 o, 
             m = skey[i] < m ? skey[i] : m;
         if (m != ~0ull)
             atomicMin(online_slot(a.state, a.par, (int)(blockIdx.x % ONL_SLOTS)), m);
+        if (blockIdx.x == 0)
+            ONL_STAMP(4);
     }
+}
+
+// End of a chunk: sigmaMap rows of the nodes its windows rewrote.  Som.cpp:942 writes sqrt(|S / w|) at every update of a
+// node; nothing of the training reads sigmaMap, and S and weightMap change at the node's updates only, so the value after the
+// node's LAST update -- computed here from the final S and weight with :939's and :942's operations -- is the same bits,
+// for a fifth fewer bytes per window (5 of the 25 N_w D per sample).  Nodes no window touched keep what they had.
+__global__ __launch_bounds__(256) void onl_sigma_kernel(const float *__restrict__ Smap, float *__restrict__ sigmap,
+                                                        const float *__restrict__ weight, unsigned char *__restrict__ dirty, int D,
+                                                        int pitch, int N)
+{
+    const int n = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N || !dirty[n])
+        return;
+    const float wnew = weight[n];
+    const double tw2 = wnew == 0 ? 0.000001 : (double)wnew;   // :939
+    const float twf = (float)tw2;
+    const float *S = Smap + (size_t)n * pitch;
+    float *sg = sigmap + (size_t)n * pitch;
+    for (int d = lane; d < D; d += 64)
+        sg[d] = sqrtf(fabsf(S[d] / twf));                // :942
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0)
+        dirty[n] = 0;
 }
 
 __global__ void onl_uslots_init_kernel(unsigned *uslots)
@@ -1158,26 +1305,38 @@ __global__ __launch_bounds__(64) void single_local_kernel(DistArgs d, u64 W, u64
 
 // ---- host side of the image-bounded search ------------------------------------------------------------------------
 // Does the chunk loop of this context search through the image?  VSOM_BMU_EXACT: never; VSOM_BMU_SHORTLIST: whenever the
-// kernels apply (Standard / Median, rows of at most 1024 values, sigma > 1); VSOM_BMU_AUTO: where it pays -- a map of at
-// least 8 MiB (below that the exact scan is a few microseconds of launch latency either way) and a chunk long enough to
-// repay the per-chunk digit pass over the whole map.
+// kernels apply (Standard / Median, rows of at most 1024 values, sigma > 1); VSOM_BMU_AUTO: where it pays.  Measured on
+// MI355X (tools/online_sweep.py, profiles/r6_online_sweep.jsonl; microseconds per sample, image minus exact):
+//     +3.3 (the refinement launch and its boundary)  - 0.43e-6 N D (three of the scan's four bytes per value saved)
+//     + 0.55e-3 k (re-digiting and scoring each of the k window nodes)
+// e.g. 128 x 128 x 784: -2.2 at sigma 2, -1.0 at sigma 8, +1.3 at sigma 16, +6.6 at sigma 32; 192 x 192 x 784: -9.0 ... -1.1;
+// 64 x 64 x 784 and below: 0 ... +5; rows of 256 values or fewer lose 2-5 us everywhere (the per-node costs of the refinement
+// and of the slots outweigh the bytes).  AUTO takes the image where that estimate gains at least 0.3 us, for rows of at
+// least 512 values and chunks long enough to repay the per-chunk passes over the map (digit pass in, sigmaMap pass out).
 static bool onl_i8_applies(const vsom_ctx *c, double sigma)
 {
     if (c->transform == VSOM_CLR || c->part_len > 1024 || !(sigma > 1) || c->bmu_mode == VSOM_BMU_EXACT || c->B == 0)
         return false;
     if (c->bmu_mode == VSOM_BMU_SHORTLIST)
         return true;
-    return (size_t)c->N * c->pitch * 4 >= ((size_t)8 << 20) && c->B >= 16;
+    if (c->part_len < 512 || c->B < 64)
+        return false;
+    const double ext = std::floor(5.0 * sigma) + 2.0;
+    const double k = std::min<double>((double)c->W, ext) * std::min<double>((double)c->H, ext);
+    return 0.43e-6 * (double)c->N * (double)c->part_len - 0.55e-3 * k > 3.6;
 }
 
 static int onl_i8_ensure(vsom_ctx *c, OnlI8 *o)
 {
-    const uint32_t ipitch = (c->part_len + 127) / 128 * 128;
+    const uint32_t ipitch = (c->part_len + 15) / 16 * 16;    // rows of 16-byte pieces
     if (!c->onl_img) {
         VSOM_HIP_CHECK(hipMalloc(&c->onl_img, (size_t)c->N * ipitch));
         VSOM_HIP_CHECK(hipMalloc(&c->onl_nsc, (size_t)c->N * sizeof(float4)));
         VSOM_HIP_CHECK(hipMalloc(&c->onl_lb, (size_t)c->N * sizeof(float)));
-        VSOM_HIP_CHECK(hipMalloc(&c->onl_u, ONL_U_BYTES));
+        VSOM_HIP_CHECK(hipMalloc(&c->onl_u, ONL_U_BYTES + 64));
+        VSOM_HIP_CHECK(hipMemsetAsync((char *)c->onl_u + ONL_U_BYTES, 0, 64, c->stream));
+        VSOM_HIP_CHECK(hipMalloc(&c->onl_dirty, (size_t)c->N));
+        VSOM_HIP_CHECK(hipMemsetAsync(c->onl_dirty, 0, (size_t)c->N, c->stream));
     }
     if (c->onl_xsc_cap < c->B) {
         VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1193,9 +1352,11 @@ static int onl_i8_ensure(vsom_ctx *c, OnlI8 *o)
     o->nsc = (float4 *)c->onl_nsc;
     o->lb = c->onl_lb;
     o->uslots = c->onl_u;
+    o->stats = reinterpret_cast<u64 *>((char *)c->onl_u + ONL_U_BYTES);
     o->xsc = (const float4 *)c->onl_xsc;
+    o->dirty = c->onl_dirty;
     o->ipitch = (int)ipitch;
-    o->ni = (int)(ipitch / 128);
+    o->ni = (int)((ipitch + 127) / 128);
     o->cT = (float)((2.0 * 35000.0 + 256.0) * u);
     o->g2c = (float)(1.05 * ((double)c->part_len / 8.0 + 16.0) * u);
     return VSOM_OK;
@@ -1228,7 +1389,22 @@ static int enqueue_chunk_i8(vsom_ctx *c, double eta, double sigma, int decay_fn,
     const float fB = (float)B;
     double ext = std::floor(5.0 * sigma) + 2.0;          // maximal window extents (enqueue_single)
     const int gx = (int)std::min<double>((double)c->W, ext), gy = (int)std::min<double>((double)c->H, ext);
-    const unsigned nscan = (unsigned)((N + 31) / 32), nref = (unsigned)((N + ONL_REF_NODES - 1) / ONL_REF_NODES);
+    // scan workgroups: the window launch of sigma = 8 on a 128 x 128 map is 1764 workgroups and the chip holds 2048 of
+    // them; two groups of 32 nodes per scan workgroup keep the launch one round (256 + 1764)
+    // One group of 32 nodes per scan workgroup (64 VGPRs: eight workgroups per CU; at sigma = 8 on a 128 x 128 map 512 +
+    // 1764 workgroups, 2048 resident: the last window workgroups take the scan workgroups' places -- 14.75 us per sample;
+    // two groups per workgroup, one round but 86 VGPRs = five per CU: 15.2) and write-through (sc1) stores of the window's
+    // rows (nothing re-reads them from this XCD's L2 before the next launch, and dirty lines are written back at the
+    // kernel's end: plain 16.05 us per sample, nontemporal 15.7, write-through 15.3 -- profiles/EXPERIMENTS.md).
+#ifdef VSOM_DEVELOPMENT
+    static const int passes_env = std::getenv("VSOM_ONL_PASSES") ? std::atoi(std::getenv("VSOM_ONL_PASSES")) : 0;
+    static const int store_env = std::getenv("VSOM_ONL_STORE") ? std::atoi(std::getenv("VSOM_ONL_STORE")) : 2;
+    const int passes = passes_env == 2 ? 2 : 1, store_kind = store_env;
+#else
+    const int passes = 1, store_kind = 2;
+#endif
+    const unsigned nscan = (unsigned)((N + 32 * passes - 1) / (32 * passes)),
+                   nref = (unsigned)((N + ONL_REF_NODES - 1) / ONL_REF_NODES);
     const bool med = c->transform == VSOM_MEDIAN;
     auto fused = [&](const float *xs_j, int par_j, const float *xs_next, size_t jnext, bool win, bool scan) {
         OnlFusedArgs f;
@@ -1241,13 +1417,20 @@ static int enqueue_chunk_i8(vsom_ctx *c, double eta, double sigma, int decay_fn,
         f.do_scan = scan ? 1 : 0;
         f.nwin_x = gx > 0 ? gx : 1;
         f.nwin_y = gy > 0 ? gy : 1;
+        f.nscan = (int)nscan;
+        f.passes = passes;
         const unsigned grid = (win ? (unsigned)(f.nwin_x * f.nwin_y) : 0u) + (scan ? nscan : 0u);
-        if (med)
-            hipLaunchKernelGGL(onl_fused_kernel<VSOM_MEDIAN>, dim3(grid), dim3(256), 0, c->stream, f, o, lutd, lutw, D, (int)c->pitch,
-                               eta, sigma, decay_fn, c->map, c->S, c->sigma, c->weight);
-        else
-            hipLaunchKernelGGL(onl_fused_kernel<VSOM_STANDARD>, dim3(grid), dim3(256), 0, c->stream, f, o, lutd, lutw, D, (int)c->pitch,
-                               eta, sigma, decay_fn, c->map, c->S, c->sigma, c->weight);
+#define ONL_FUSED2(KIND, ST, P)                                                                                            \
+    hipLaunchKernelGGL((onl_fused_kernel<KIND, ST, P>), dim3(grid), dim3(256), 0, c->stream, f, o, lutd, lutw, D, (int)c->pitch, eta, \
+                       sigma, decay_fn, c->map, c->S, c->sigma, c->weight)
+#define ONL_FUSED(KIND, ST) do { if (passes == 2) ONL_FUSED2(KIND, ST, 2); else ONL_FUSED2(KIND, ST, 1); } while (0)
+        if (med) {
+            if (store_kind == 2) ONL_FUSED(VSOM_MEDIAN, 2); else if (store_kind == 1) ONL_FUSED(VSOM_MEDIAN, 1); else ONL_FUSED(VSOM_MEDIAN, 0);
+        } else {
+            if (store_kind == 2) ONL_FUSED(VSOM_STANDARD, 2); else if (store_kind == 1) ONL_FUSED(VSOM_STANDARD, 1); else ONL_FUSED(VSOM_STANDARD, 0);
+        }
+#undef ONL_FUSED2
+#undef ONL_FUSED
     };
     auto refine = [&](const float *xs_j, int par_j, const float *xs_prev, u64 *lb_prev, bool do_refine) {
         OnlineArgs r = a;
@@ -1256,13 +1439,7 @@ static int enqueue_chunk_i8(vsom_ctx *c, double eta, double sigma, int decay_fn,
         r.pxa = r.pxb = xs_prev;
         r.do_post = xs_prev != nullptr;
         const dim3 grid((do_refine ? nref : 0u) + 1u);
-        const int dr = do_refine ? 1 : 0;
-        if (D <= 128)
-            hipLaunchKernelGGL(onl_refine_kernel<16>, grid, dim3(256), 0, c->stream, r, o, dr, c->hits, lb_prev, fB, 1);
-        else if (D <= 512)
-            hipLaunchKernelGGL(onl_refine_kernel<64>, grid, dim3(256), 0, c->stream, r, o, dr, c->hits, lb_prev, fB, 1);
-        else
-            hipLaunchKernelGGL(onl_refine_kernel<128>, grid, dim3(256), 0, c->stream, r, o, dr, c->hits, lb_prev, fB, 1);
+        hipLaunchKernelGGL(onl_refine_kernel, grid, dim3(256), 0, c->stream, r, o, do_refine ? 1 : 0, c->hits, lb_prev, fB, 1);
     };
     // scores of sample 0 (no window yet): the launch works on "sample -1" of parity 1
     fused(c->Xs, 1, c->Xs, 0, false, true);
@@ -1276,6 +1453,8 @@ static int enqueue_chunk_i8(vsom_ctx *c, double eta, double sigma, int decay_fn,
     }
     // finish the last sample: its post step runs as the "previous sample" of a launch of the other parity
     refine(prev, (int)(B & 1), prev, c->lastbmu + (B - 1), false);
+    hipLaunchKernelGGL(onl_sigma_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, c->stream, c->S, c->sigma, c->weight,
+                       c->onl_dirty, D, (int)c->pitch, N);
     return VSOM_OK;
 }
 
@@ -1457,6 +1636,22 @@ int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay
         VSOM_HIP_CHECK(hipMemcpyAsync(mse_out, c->onl_f + 1, 4, hipMemcpyDeviceToHost, c->stream));
         VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
+    return VSOM_OK;
+}
+
+int vsom_get_online_search_stats(vsom_ctx *c, uint64_t *out, int reset)
+{
+    if (!c || !out)
+        return vsom_fail(VSOM_ERR_INVALID, "null argument");
+    VSOM_HIP_CHECK(hipSetDevice(c->device));
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!c->onl_u)
+        return VSOM_OK;
+    u64 *st = reinterpret_cast<u64 *>((char *)c->onl_u + ONL_U_BYTES);
+    VSOM_HIP_CHECK(hipMemcpyAsync(out, st, 32, hipMemcpyDeviceToHost, c->stream));
+    if (reset)
+        VSOM_HIP_CHECK(hipMemsetAsync(st, 0, 32, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
     return VSOM_OK;
 }
 
