@@ -83,9 +83,9 @@ def test_online_chunk_through_the_image(name, W, H, J, tr, fn, B, sigma):
 
 @pytest.mark.parametrize("kind", ["uint8", "unit_floats", "signed_dense", "tiny_values", "huge_values"])
 def test_online_image_search_on_a_big_map(kind):
-    """A map large enough for VSOM_BMU_AUTO to pick the image-bounded search by itself (>= 8 MiB), rows of MNIST-like
-    pixels / the same over 255 / signed dense values / values near the bottom and the top of fp32's useful range: the
-    bound has to hold for every scale, and whatever it prunes, indices and distances are the exact-order evaluation's."""
+    """A 10 MB map, rows of MNIST-like pixels / the same over 255 / signed dense values / values near the bottom and the
+    top of fp32's useful range, through the image-bounded search: the bound has to hold for every scale, and whatever it
+    prunes, indices and distances are the exact-order evaluation's."""
     W, H, J, B = 72, 64, 520, 40
     if kind in ("uint8", "unit_floats"):
         X = gen.mnist_like(B, 11, J)
@@ -99,7 +99,35 @@ def test_online_image_search_on_a_big_map(kind):
         scale = {"signed_dense": 1.0, "tiny_values": 1e-17, "huge_values": 3e15}[kind]
         X = (X * np.float32(scale)).astype(np.float32)
         init = (init * np.float32(scale)).astype(np.float32)
-    _run_online_case(W, H, J, po.STANDARD, capi.EXPONENTIAL, B, 4.0, X, init, 0.08)
+    _run_online_case(W, H, J, po.STANDARD, capi.EXPONENTIAL, B, 4.0, X, init, 0.08, mode=capi.BMU_SHORTLIST)
+
+
+def test_online_auto_mode_picks_the_image_at_baseline_size():
+    """VSOM_BMU_AUTO on BASELINE's 128 x 128 x 784 map: sigma = 4 goes through the image (vsom_get_online_search_stats counts
+    its samples), sigma = 32 -- a window as large as the map -- through the exact scan; both are the oracle's bits, and the
+    sigmaMap rows owed at the end of an image chunk are there before vsom_get_state reads them."""
+    W = H = 128
+    J, B = 784, 64
+    X = gen.mnist_like(B, 5, J)
+    init = (gen.random_map(W * H, J, seed=42) * np.float32(100) + np.float32(100)).astype(np.float32)
+    o = po.OracleSom(W, H, J, po.STANDARD)
+    o.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, po.STANDARD)
+    ctx.set_state(map=init)
+    for sigma, through_image in ((4.0, True), (32.0, False), (4.0, True)):
+        lb = np.zeros(B, np.uint64)
+        mse_o = o.train_online_chunk(X, lb, 0.1, sigma, po.EXPONENTIAL)
+        ctx.upload_chunk(X)
+        ctx.online_search_stats(reset=True)
+        mse_g = ctx.train_online_chunk(0.1, sigma, capi.EXPONENTIAL)
+        st = ctx.online_search_stats()
+        assert (st["samples"] == B) == through_image, (sigma, st)
+        assert beq(ctx.get_last_bmu(), lb), sigma
+        state = ctx.get_state()
+        for k in ("map", "S", "sigma", "weight", "hits"):
+            assert beq(state[k], getattr(o, k)), (sigma, k)
+        assert beq(np.float32(mse_g), np.float32(mse_o)), sigma
+    ctx.close()
 
 
 def test_online_image_search_with_nan_inf_rows_and_samples():

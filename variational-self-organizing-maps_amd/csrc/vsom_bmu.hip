@@ -215,9 +215,25 @@ __device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1,
                                               u64 *__restrict__ partial, int pstride,
                                               unsigned char *__restrict__ nan0,
                                               const int *__restrict__ slist,
-                                              const u64 *__restrict__ hits, u64 min_hits, int by)
+                                              const u64 *__restrict__ hits, u64 min_hits, int by,
+                                              const int *__restrict__ nlist, const unsigned *__restrict__ ncount)
 {
     constexpr int TS = 16 * TI;                 // samples per tile
+    // nlist / ncount: search the listed nodes only -- the lowest-index representative of every class of bit-identical
+    // model rows (bmu_dedupe_*: equal rows give equal distances and the strict `<` keeps the lowest index, Som.cpp:299).
+    // Positions past the count are not evaluated; a tile wholly past it only reports "nothing here".
+    if (ncount) {
+        const int cnt = (int)*ncount;
+        N = cnt < N ? cnt : N;
+        if ((int)blockIdx.x * TILE >= N) {      // workgroup-uniform
+            if ((int)threadIdx.x < TS) {
+                const int s = s0 + by * TS + (int)threadIdx.x;
+                if (s < s1)
+                    partial[(size_t)blockIdx.x * pstride + (slist ? slist[s - s0] : s)] = ~0ull;
+            }
+            return;
+        }
+    }
     constexpr int NX = TS * 8 / 256;            // float4 of a sample operand per thread and K-chunk (1 or 2)
     __shared__ __attribute__((aligned(16))) float sx[TILE * LDT];   // TS rows used (also the key scratch: 64 x 16 u64 max)
     __shared__ __attribute__((aligned(16))) float sm[TILE * LDT];
@@ -243,6 +259,12 @@ __device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1,
     // consumed (register prefetch: the loads used to be issued and waited for between the two barriers, with
     // only two wavefronts per SIMD to cover them)
     float4 gx[NX], gm[2], gy[NX], gb[2];
+    size_t mrow[2];                             // the model rows this thread stages (through the node list, if any)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = nbase + ((tid + 256 * i) >> 3);
+        mrow[i] = n < N ? (size_t)(nlist ? nlist[n] : n) : 0;
+    }
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -266,9 +288,9 @@ __device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1,
             gm[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             gb[i] = gm[i];
             if (n < N) {
-                gm[i] = *reinterpret_cast<const float4 *>(a.ma + (size_t)n * a.ldm + k0 + c4);
+                gm[i] = *reinterpret_cast<const float4 *>(a.ma + mrow[i] * a.ldm + k0 + c4);
                 if (CLR)
-                    gb[i] = *reinterpret_cast<const float4 *>(a.mb + (size_t)n * a.ldm + k0 + c4);
+                    gb[i] = *reinterpret_cast<const float4 *>(a.mb + mrow[i] * a.ldm + k0 + c4);
             }
         }
     };
@@ -388,9 +410,10 @@ __device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int n = nbase + tx + 16 * j;
+            const int node = (nlist && n < N) ? nlist[n] : n;
             // findRestrictedBmu (Som.cpp:316-322): node 0 seeds unconditionally, others need the hits
-            const bool allowed = n < N && (hits == nullptr || n == 0 || hits[n] >= min_hits);
-            u64 k = allowed ? vsom_key(dist[i][j], (uint32_t)n) : ~0ull;
+            const bool allowed = n < N && (hits == nullptr || node == 0 || hits[node] >= min_hits);
+            u64 k = allowed ? vsom_key(dist[i][j], (uint32_t)node) : ~0ull;
             kmin = k < kmin ? k : kmin;
         }
         keys[(ty + 16 * i) * 16 + tx] = kmin;
@@ -421,13 +444,14 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
                                                           unsigned char *__restrict__ nan0,
                                                           const int *__restrict__ slist,
                                                           const unsigned *__restrict__ scount,
-                                                          const u64 *__restrict__ hits, u64 min_hits, SlFeedback fb)
+                                                          const u64 *__restrict__ hits, u64 min_hits, SlFeedback fb,
+                                                          const int *__restrict__ nlist, const unsigned *__restrict__ ncount)
 {
     constexpr int TS = 16 * TI;
     if (LIST && fb.scal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64)
         sl_feedback_write(fb);               // (vsom_digits.hpp: the search's statistics for the host)
     if (!LIST) {
-        bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, nullptr, hits, min_hits, (int)blockIdx.y);
+        bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, nullptr, hits, min_hits, (int)blockIdx.y, nlist, ncount);
         return;
     }
     const int cnt = (int)*scount;
@@ -435,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
     for (int by = blockIdx.y; s0 + by * TS < s1; by += gridDim.y) {
         if (by != (int)blockIdx.y)
             __syncthreads();                    // the key scratch of the previous tile has been read
-        bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, slist, hits, min_hits, by);
+        bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, slist, hits, min_hits, by, nlist, ncount);
     }
 }
 
@@ -467,6 +491,136 @@ __global__ void bmu_reduce_kernel(const u64 *__restrict__ partial, int pstride, 
     }
 }
 
+// ---- duplicate model rows: the exact search evaluates one representative per class -------------------------------------
+// Batch training on chunks whose samples lie on (nearly) one line leaves maps with few DISTINCT rows (C5's CLR maps after
+// every other chunk: 426 of 1024; an empty chunk leaves one: Som.cpp:840-875) and the exact kernel paid for every copy.
+// Equal rows give equal distances and the reference's strict `<` from node 0 keeps the lowest index (Som.cpp:293-304), so
+// searching the lowest-index member of every class of BIT-IDENTICAL rows returns the same index and distance.
+//   bmu_row_hash_kernel   64-bit hash of every row's bits (order-independent sum of mixed (position, bits) words)
+//   bmu_row_twin_kernel   rep[n] = the lowest m < n with the same hash AND the same bits, else n
+//   bmu_unique_kernel     the representatives in index order + their count
+// `scount` (the redo list's device-side length) below `min_list`: the passes leave at once and the list is the identity.
+__device__ __forceinline__ u64 bmu_mix64(u64 z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void bmu_row_hash_kernel(const float *__restrict__ map, int ldm, int N, u64 *__restrict__ hash,
+                                                           const unsigned *__restrict__ scount, unsigned min_list)
+{
+    __shared__ u64 sh[4];
+    if (scount && *scount < min_list)
+        return;
+    const int n = blockIdx.x;
+    const unsigned *row = reinterpret_cast<const unsigned *>(map + (size_t)n * ldm);
+    u64 h = 0;
+    for (int d = threadIdx.x * 4; d < ldm; d += 1024) {      // pitches are multiples of 32 floats
+        const uint4 v = *reinterpret_cast<const uint4 *>(row + d);
+        h += bmu_mix64(((u64)(d + 0) << 32) | v.x) + bmu_mix64(((u64)(d + 1) << 32) | v.y) +
+             bmu_mix64(((u64)(d + 2) << 32) | v.z) + bmu_mix64(((u64)(d + 3) << 32) | v.w);
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        h += __shfl_xor(h, off);
+    if ((threadIdx.x & 63) == 0)
+        sh[threadIdx.x >> 6] = h;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        hash[n] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void bmu_row_twin_kernel(const float *__restrict__ map, int ldm, int N, const u64 *__restrict__ hash,
+                                                           int *__restrict__ rep, const unsigned *__restrict__ scount,
+                                                           unsigned min_list)
+{
+    const int n = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N)
+        return;
+    if (scount && *scount < min_list) {
+        if (lane == 0)
+            rep[n] = n;
+        return;
+    }
+    const u64 hn = hash[n];
+    const unsigned *rn = reinterpret_cast<const unsigned *>(map + (size_t)n * ldm);
+    int found = n;
+    for (int m0 = 0; m0 < n && found == n; m0 += 64) {
+        const int m = m0 + lane;
+        u64 mask = __ballot(m < n && hash[m] == hn);
+        while (mask) {                                       // (wavefront-uniform) candidates in ascending order
+            const int mc = m0 + __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            const unsigned *rm = reinterpret_cast<const unsigned *>(map + (size_t)mc * ldm);
+            bool differ = false;
+            for (int d = lane * 4; d < ldm && !__ballot(differ); d += 256) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(rn + d), b = *reinterpret_cast<const uint4 *>(rm + d);
+                differ = a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w;
+            }
+            if (!__ballot(differ)) {
+                found = mc;                                  // the first match is the class's lowest index (equality is transitive)
+                break;
+            }
+        }
+    }
+    if (lane == 0)
+        rep[n] = found;
+}
+
+__global__ __launch_bounds__(1024) void bmu_unique_kernel(const int *__restrict__ rep, int N, int *__restrict__ ulist,
+                                                          unsigned *__restrict__ ucount)
+{
+    __shared__ int swave[16];
+    __shared__ int sbase;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0)
+        sbase = 0;
+    __syncthreads();
+    for (int n0 = 0; n0 < N; n0 += 1024) {
+        const int n = n0 + tid;
+        const bool uniq = n < N && rep[n] == n;
+        const u64 bm = __ballot(uniq);
+        if (lane == 0)
+            swave[wave] = __popcll(bm);
+        __syncthreads();
+        int off = sbase;
+        for (int w = 0; w < wave; ++w)
+            off += swave[w];
+        if (uniq)
+            ulist[off + __popcll(bm & ((1ull << lane) - 1ull))] = n;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; ++w)
+                tot += swave[w];
+            sbase += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0)
+        *ucount = (unsigned)sbase;
+}
+
+// enqueue the three passes; *nlist / *ncount = what bmu_tile_kernel takes (buffers kept with the context)
+static int launch_bmu_dedupe(vsom_ctx *c, const unsigned *scount, unsigned min_list, const int **nlist, const unsigned **ncount)
+{
+    if (!c->dd_hash) {
+        VSOM_HIP_CHECK(hipMalloc(&c->dd_hash, (size_t)c->N * sizeof(u64)));
+        VSOM_HIP_CHECK(hipMalloc(&c->dd_rep, (size_t)c->N * sizeof(int)));
+        VSOM_HIP_CHECK(hipMalloc(&c->dd_list, (size_t)c->N * sizeof(int) + 64));
+    }
+    u64 *hash = reinterpret_cast<u64 *>(c->dd_hash);
+    unsigned *cnt = reinterpret_cast<unsigned *>(c->dd_list + c->N);
+    hipLaunchKernelGGL(bmu_row_hash_kernel, dim3((unsigned)c->N), dim3(256), 0, c->stream, c->map, (int)c->pitch, (int)c->N, hash, scount,
+                       min_list);
+    hipLaunchKernelGGL(bmu_row_twin_kernel, dim3((unsigned)((c->N + 3) / 4)), dim3(256), 0, c->stream, c->map, (int)c->pitch, (int)c->N,
+                       hash, c->dd_rep, scount, min_list);
+    hipLaunchKernelGGL(bmu_unique_kernel, dim3(1), dim3(1024), 0, c->stream, c->dd_rep, (int)c->N, c->dd_list, cnt);
+    *nlist = c->dd_list;
+    *ncount = cnt;
+    return VSOM_OK;
+}
+
 int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *slist, const unsigned *scount,
                                  const u64 *hits, u64 min_hits, const SlFeedback *fbp = nullptr)
 {
@@ -492,9 +646,19 @@ int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *s
     const bool list = slist != nullptr && scount != nullptr;
     const int gy = list ? std::min(nts, std::max(1, 512 / ntn)) : nts;
     dim3 grid((unsigned)ntn, (unsigned)gy);
+    // Representatives of the duplicate rows only -- where the search is large enough to repay three small passes over the
+    // map (~20 us at C5's size): 2e9 (sample, node, value) triples = ~50 us of this kernel.  With a redo list the passes
+    // look at its device-side length first and leave when it is short (the usual case).  Not for restricted searches:
+    // bit-identical rows may differ in their hit counts.
+    const int *nlist = nullptr;
+    const unsigned *ncount = nullptr;
+    if (!hits && c->N >= 256 && c->dedupe && (double)(s1 - s0) * (double)c->N * (double)c->D >= 2.0e9) {
+        if (int rc = launch_bmu_dedupe(c, list ? scount : nullptr, 256u, &nlist, &ncount))
+            return rc;
+    }
 #define VSOM_TILE_LAUNCH(K)                                                                                             \
     hipLaunchKernelGGL(K, grid, dim3(256), 0, c->stream, a, (int)s0, (int)s1, (int)c->N, c->partial, (int)c->Bcap, c->nan0, \
-                       slist, scount, hits, min_hits, fb)
+                       slist, scount, hits, min_hits, fb, nlist, ncount)
     if (c->transform == VSOM_CLR) {
         if (list)
             VSOM_TILE_LAUNCH((bmu_tile_kernel<true, 2, true>));

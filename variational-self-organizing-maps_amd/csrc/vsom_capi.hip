@@ -160,7 +160,7 @@ static int free_all(vsom_ctx *c)
                     c->cw, c->lut, c->lutd, c->sl_G, c->sl_nrm, c->sl_scal, c->sl_list, c->sl_tmin, c->sl_fs, c->sl_fm, c->v_dev, c->res_dev, c->onl_state, c->onl_f,
                     c->cc_flags, c->cc_idx, c->cc_inv, c->cc_meta, c->Xc, c->Mc, c->Uc_map, c->Uc_S, c->Xq, c->zq, c->sl_xi, c->sl_l1, c->sl_q, c->sl_qscale, c->sl_qcorr,
                     c->lastbmu_alt, c->cc_idx_alt, c->cc_inv_alt, c->cc_meta_alt, c->sl_a2, c->sl_qfast,
-                    c->onl_img, c->onl_nsc, c->onl_lb, c->onl_u, c->onl_xsc, c->q_scratch, c->onl_dirty};
+                    c->onl_img, c->onl_nsc, c->onl_lb, c->onl_u, c->onl_xsc, c->q_scratch, c->onl_dirty, c->dd_hash, c->dd_rep, c->dd_list};
     for (void *p : ptrs)
         if (p)
             (void)hipFree(p);
@@ -261,6 +261,8 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
         c->use_tiny = !(e[0] == '1');
     if (const char *e = std::getenv("VSOM_COMPACT_MIN_ROWS"))     // development: initial vsom_set_column_compaction
         c->cc_min_rows = std::atol(e);
+    if (const char *e = std::getenv("VSOM_NO_DEDUPE"))
+        c->dedupe = !(e[0] == '1');     // A/B measurements of the duplicate-row pass of the exact search
     if (const char *e = std::getenv("VSOM_NO_CHAIN"))
         c->use_chain = !(e[0] == '1');  // debugging aid: lane = node update kernel on small maps too
 

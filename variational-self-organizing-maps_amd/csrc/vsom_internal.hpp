@@ -100,6 +100,10 @@ struct vsom_ctx {
     u64 *partial = nullptr; size_t partial_cap = 0;
     unsigned char *nan0 = nullptr;
 
+    // duplicate-row representatives of the exact search (vsom_bmu.hip, bmu_dedupe_*)
+    void *dd_hash = nullptr; int *dd_rep = nullptr, *dd_list = nullptr;
+    bool dedupe = true;             // VSOM_NO_DEDUPE=1 switches it off (A/B measurements)
+
     // MFMA shortlist scratch
     float *sl_G = nullptr; size_t sl_cap = 0; float *sl_nrm = nullptr; unsigned *sl_scal = nullptr;
     float *sl_a2 = nullptr;         // CLR shortlist: per-node max A^2 (the select kernel's per-node bounds)
