@@ -201,6 +201,11 @@ int vsom_find_bmu(vsom_ctx *ctx, const float *v_host, uint64_t *bmu_out, float *
  * one synchronisation, no allocation.  Neither touches the staged chunk. */
 int vsom_dist_single(vsom_ctx *ctx, const float *v_host, uint64_t node, float *dist_out);
 int vsom_find_local_bmu(vsom_ctx *ctx, const float *v_host, uint64_t last_bmu, uint64_t *bmu_out, float *dist_out);
+/* Som::findRestrictedBmu(v, ..., minBmuHits, ...) (Som.cpp:313-332: node 0 seeds the search whatever its hits) and the
+ * distances Som::findRestrictedBmd walks (Som.cpp:457-487: dist_out_host[N] = euclidianWeightedDist(i, v)) for ONE host
+ * vector, the same way: one copy, one scan launch, one synchronisation; the staged chunk is not touched. */
+int vsom_find_restricted_bmu(vsom_ctx *ctx, const float *v_host, uint64_t min_hits, uint64_t *bmu_out, float *dist_out);
+int vsom_distances_single(vsom_ctx *ctx, const float *v_host, float *dist_out_host);
 /* Som::findLocalBmu from the current lastBMU of every sample (Som.cpp:335-454) */
 int vsom_bmu_local_batch(vsom_ctx *ctx, uint64_t *idx_out_host, float *dist_out_host);
 /* Som::euclidianWeightedDist(pos, v, ...) for `count` (node, sample-row) pairs of the chunk */

@@ -65,27 +65,31 @@ def test_exact_search_on_a_map_with_duplicate_rows(tr, W, H, J, B):
         ctx.close()
 
 
-def test_collapsed_clr_map_goes_through_the_redo_list_with_representatives():
-    """C5's situation: a CLR map whose nodes (nearly) coincide -- the shortlist recognises it on the device, every sample
-    lands on the redo list, and the exact kernel then searches the distinct rows only."""
+def test_redo_list_of_a_shortlist_search_uses_the_representatives():
+    """The shortlist hands the samples it cannot bound (here: 300 rows holding a NaN or an inf) to the exact kernel as a
+    device-side redo list; with at least 256 entries the list form, too, searches the distinct rows only.  (C5's situation
+    is the same path with every sample on the list: a collapsed CLR map.)"""
     W = H = 32
-    J, B = 20, 8192
-    D = po.length(po.CLR, J)
-    X = gen.correlated(B, J, seed=9)
-    rs = np.random.RandomState(3)
-    base = gen.random_map(40, D, seed=11)               # 40 distinct rows spread over 1024 nodes
-    init = base[rs.randint(0, 40, size=W * H)].copy()
-    init += np.float32(0)                                # (same bits)
-    orc = po.OracleSom(W, H, J, po.CLR)
+    J, B = 128, 16384
+    X = gen.blobs(B, J, 6, 1, 2, sigma=0.4)
+    rs = np.random.RandomState(4)
+    rows = rs.choice(B, size=300, replace=False)
+    X[rows[:200], rs.randint(0, J, size=200)] = np.nan
+    X[rows[200:], rs.randint(0, J, size=100)] = np.inf
+    init = map_with_copies(W * H, J, seed=12)
+    orc = po.OracleSom(W, H, J, po.STANDARD)
     orc.set_state(map=init)
     lb = np.zeros(B, np.uint64)
     sq = np.zeros(B, np.float32)
     orc.batch_phase1_range(X, 0, B, lb, sq, True, nthreads=16)
-    ctx = vsom_amd.Context(W, H, J, po.CLR)
+    ctx = vsom_amd.Context(W, H, J, po.STANDARD)
+    ctx.set_bmu_mode(capi.BMU_SHORTLIST)
     ctx.set_state(map=init)
     ctx.upload_chunk(X)
-    for rep in range(2):                                 # (the second search has the first one's feedback)
+    for rep in range(2):
         idx, dist = ctx.bmu_batch()
         assert (idx == lb).all(), (rep, np.nonzero(idx != lb)[0][:8])
         assert bits_eq(dist, sq), rep
+    st = ctx.shortlist_stats()
     ctx.close()
+    assert st["redo_samples"] >= 300, st

@@ -185,6 +185,25 @@ def test_single_vector_distance_and_local_search(tr, W, H, J):
     assert ctx.chunk_size == 5
     with pytest.raises(capi.VsomError):
         ctx.dist_single(X[0], W * H)
+    # the restricted search (Som.cpp:313-332: node 0 seeds whatever its hits) and the all-node distances of findRestrictedBmd
+    hits = rs.randint(0, 4, size=W * H).astype(np.uint64)
+    ctx.set_state(hits=hits)
+    orc.set_state(hits=hits)
+    for i in range(12):
+        for min_hits in (0, 1, 3, 9):
+            idx, dist = ctx.find_restricted_bmu(X[i], min_hits)
+            want = orc.find_restricted_bmu(X[i], min_hits)
+            assert idx == want, (i, min_hits)
+            assert beq(dist, np.float32(orc.dist(want, X[i]))), (i, min_hits)
+    all_d = ctx.distances_single(X[3])
+    assert beq(all_d, np.array([orc.dist(n, X[3]) for n in range(W * H)], np.float32))
+    bad = init.copy()
+    bad[0, 0] = np.nan
+    ctx.set_state(map=bad)
+    orc.set_state(map=bad)
+    idx, dist = ctx.find_restricted_bmu(X[0], 2)
+    assert idx == orc.find_restricted_bmu(X[0], 2) == 0 and np.isnan(dist)
+    assert ctx.chunk_size == 5
     ctx.close()
 
 

@@ -28,4 +28,6 @@ for mode in strict sigma; do
     VSOM_UPDATE_MODE=$mode $T perf_e2e array "$D/rows.f32" 16384 784 4096 | grep '^{' >> "$OUT"
     VSOM_UPDATE_MODE=$mode $T perf_e2e mnist "$D" 4096 | grep '^{' >> "$OUT"
 done
+# the online drivers (Som::train(Exponential | InverseProportional): one trainSingle per sample, Som.cpp:1135-1187)
+$T perf_e2e_online "$D/rows.f32" 16384 784 4096 | grep '^{' >> "$OUT"
 cat "$OUT"

@@ -30,7 +30,7 @@ SYMBOLS = [
     "vsom_synchronize", "vsom_set_bmu_mode", "vsom_set_update_mode", "vsom_set_column_compaction", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
     "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_host_alloc", "vsom_host_free",
     "vsom_prefetch_chunk", "vsom_prefetch_wait", "vsom_commit_chunk", "vsom_stage_next_device", "vsom_get_last_bmu",
-    "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_find_bmu", "vsom_dist_single", "vsom_find_local_bmu", "vsom_bmu_local_batch",
+    "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_find_bmu", "vsom_dist_single", "vsom_find_local_bmu", "vsom_find_restricted_bmu", "vsom_distances_single", "vsom_bmu_local_batch",
     "vsom_distances", "vsom_bmu_restricted_batch", "vsom_distances_row", "vsom_distances_raw", "vsom_batch_phase1_async", "vsom_batch_finish_async",
     "vsom_batch_phase2_async", "vsom_batch_epoch_async", "vsom_batch_epoch", "vsom_get_mse",
     "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk", "vsom_train_online_chunk_acc", "vsom_get_online_search_stats",
@@ -154,6 +154,8 @@ def lib():
     L.vsom_get_online_search_stats.argtypes = [vp, u64p, C.c_int]
     L.vsom_dist_single.argtypes = [vp, fp, C.c_uint64, fp]
     L.vsom_find_local_bmu.argtypes = [vp, fp, C.c_uint64, u64p, fp]
+    L.vsom_find_restricted_bmu.argtypes = [vp, fp, C.c_uint64, u64p, fp]
+    L.vsom_distances_single.argtypes = [vp, fp, fp]
     L.vsom_train_online_chunk.argtypes = [vp, C.c_double, C.c_double, C.c_int, fp]
     L.vsom_train_online_chunk_acc.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int, fp]
     L.vsom_neighbourhood_weight.argtypes = [C.c_size_t] * 4 + [C.c_double]
@@ -387,6 +389,22 @@ class Context:
         idx, d = C.c_uint64(), C.c_float()
         check(lib().vsom_find_local_bmu(self._h, _f(v), int(last_bmu), C.byref(idx), C.byref(d)))
         return int(idx.value), np.float32(d.value)
+
+    def find_restricted_bmu(self, v, min_hits):
+        """Som::findRestrictedBmu of one host vector: (index, distance)."""
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        assert v.shape == (self.in_len,)
+        idx, d = C.c_uint64(), C.c_float()
+        check(lib().vsom_find_restricted_bmu(self._h, _f(v), int(min_hits), C.byref(idx), C.byref(d)))
+        return int(idx.value), np.float32(d.value)
+
+    def distances_single(self, v):
+        """euclidianWeightedDist(i, v) of one host vector to every node."""
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        assert v.shape == (self.in_len,)
+        out = np.empty(self.n_nodes, np.float32)
+        check(lib().vsom_distances_single(self._h, _f(v), _f(out)))
+        return out
 
     def find_bmu(self, v):
         """Som::findBmu of one host vector (does not disturb the staged chunk)."""

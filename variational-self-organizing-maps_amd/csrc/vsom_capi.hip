@@ -171,6 +171,8 @@ static int free_all(vsom_ctx *c)
             (void)hipEventDestroy(c->lut_ev[i]);
     if (c->v_pinned)
         (void)hipHostFree(c->v_pinned);
+    if (c->st_pinned)
+        (void)hipHostFree(c->st_pinned);
     if (c->sl_fb)
         (void)hipHostFree(c->sl_fb);
     if (c->cc_fb)
@@ -404,9 +406,47 @@ uint32_t vsom_nodes(const vsom_ctx *c) { return c ? c->N : 0; }
 uint32_t vsom_residual_len(const vsom_ctx *c) { return c ? c->part_len : 0; }
 size_t vsom_chunk_size(const vsom_ctx *c) { return c ? c->B : 0; }
 
-// host [N][D] <-> device [N][pitch] (each part separately for CLR)
+static bool all_zero_bits(const void *p, size_t bytes)
+{
+    const uint64_t *w = static_cast<const uint64_t *>(p);
+    size_t i = 0;
+    for (; i + 8 <= bytes / 8; i += 8)
+        if (w[i] | w[i + 1] | w[i + 2] | w[i + 3] | w[i + 4] | w[i + 5] | w[i + 6] | w[i + 7])
+            return false;
+    for (size_t b = i * 8; b < bytes; ++b)
+        if (static_cast<const unsigned char *>(p)[b])
+            return false;
+    return true;
+}
+
+// host [N][D] <-> device [N][pitch] (each part separately for CLR).  Host -> device: an all-zero array (what
+// Som::randomInitialize hands over for sigmaMap / SMap, Som.cpp:977-997) is a device fill; anything else travels through a
+// pinned staging buffer -- a strided copy out of pageable memory took 5 ms per 4 MB array (tests/perf/ref_harness.py).
 static int copy_rows(vsom_ctx *c, float *dev, const float *host_in, float *host_out)
 {
+    const size_t bytes = (size_t)c->N * c->D * 4;
+    if (host_in && all_zero_bits(host_in, bytes)) {
+        VSOM_HIP_CHECK(hipMemsetAsync(dev, 0, (size_t)c->N * c->pitch * 4, c->stream));   // (pad columns are zero anyway)
+        return VSOM_OK;
+    }
+    if (host_in && bytes <= ((size_t)256 << 20)) {
+        if (bytes > c->st_pinned_cap) {
+            VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (c->st_pinned)
+                (void)hipHostFree(c->st_pinned);
+            c->st_pinned = nullptr;
+            c->st_pinned_cap = 0;
+            if (hipHostMalloc(&c->st_pinned, bytes) == hipSuccess)
+                c->st_pinned_cap = bytes;
+            else
+                (void)hipGetLastError();
+        }
+        if (c->st_pinned_cap >= bytes) {
+            VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));       // the previous array's copy out of the buffer
+            std::memcpy(c->st_pinned, host_in, bytes);
+            host_in = static_cast<const float *>(c->st_pinned);
+        }
+    }
     for (uint32_t part = 0; part < c->nparts; ++part) {
         float *d = dev + (size_t)part * c->part_pitch;
         if (host_in) {
@@ -435,10 +475,18 @@ int vsom_set_state(vsom_ctx *c, const float *map, const float *sigma, const floa
         return rc;
     if (S && (rc = copy_rows(c, c->S, S, nullptr)))
         return rc;
-    if (weight)
-        VSOM_HIP_CHECK(hipMemcpyAsync(c->weight, weight, (size_t)c->N * 4, hipMemcpyHostToDevice, c->stream));
-    if (bmu_hits)
-        VSOM_HIP_CHECK(hipMemcpyAsync(c->hits, bmu_hits, (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
+    if (weight) {
+        if (all_zero_bits(weight, (size_t)c->N * 4))
+            VSOM_HIP_CHECK(hipMemsetAsync(c->weight, 0, (size_t)c->N * 4, c->stream));
+        else
+            VSOM_HIP_CHECK(hipMemcpyAsync(c->weight, weight, (size_t)c->N * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    if (bmu_hits) {
+        if (all_zero_bits(bmu_hits, (size_t)c->N * 8))
+            VSOM_HIP_CHECK(hipMemsetAsync(c->hits, 0, (size_t)c->N * 8, c->stream));
+        else
+            VSOM_HIP_CHECK(hipMemcpyAsync(c->hits, bmu_hits, (size_t)c->N * 8, hipMemcpyHostToDevice, c->stream));
+    }
     VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
     return VSOM_OK;
 }

@@ -168,6 +168,8 @@ struct vsom_ctx {
     void *onl_xsc = nullptr; size_t onl_xsc_cap = 0;
     unsigned char *onl_dirty = nullptr;      // [N] nodes whose sigmaMap row is written at the end of the chunk
 
+    // pinned staging of vsom_set_state's host arrays
+    void *st_pinned = nullptr; size_t st_pinned_cap = 0;
     // device scratch of the distance queries (vsom_distances / _row / _raw): grow-only
     void *q_scratch = nullptr; size_t q_scratch_cap = 0;
 

@@ -1303,6 +1303,41 @@ __global__ __launch_bounds__(64) void single_local_kernel(DistArgs d, u64 W, u64
     }
 }
 
+// Som::findRestrictedBmu / the distances of Som::findRestrictedBmd for ONE vector: online_scan_kernel's evaluation (8 lanes
+// per node, the (distance, index) key, the node-0-NaN flag) with the hit-count filter of Som.cpp:316-322 -- node 0 seeds
+// the search whatever its hits, any other node needs bmuHits >= min_hits -- and, optionally, every node's distance kept.
+template <bool CLR>
+__global__ __launch_bounds__(256) void single_scan_kernel(OnlineArgs a, const u64 *__restrict__ hits, u64 min_hits, int use_hits,
+                                                          float *__restrict__ all_dist)
+{
+    __shared__ u64 skey[4];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int node = gid >> 3, k = threadIdx.x & 7;
+    const int nc = node < a.N ? node : a.N - 1;
+    const float d = vsom_group_dist<CLR, VSOM_SCAN_UNR>(a.d.xa, a.d.xb, a.d.ma + (size_t)nc * a.d.ldm, a.d.mb + (size_t)nc * a.d.ldm,
+                                                        a.d.L, k);
+    if (all_dist && node < a.N && k == 0)
+        all_dist[node] = d;
+    const bool allowed = node < a.N && (!use_hits || node == 0 || hits[nc] >= min_hits);
+    u64 key = allowed ? vsom_key(d, (uint32_t)node) : ~0ull;
+    if (node == 0 && k == 0)
+        a.state[ONL_FLAG + a.par] = (d != d) ? 1ull : 0ull;
+    for (int off = 32; off >= 8; off >>= 1) {
+        const u64 o = __shfl_xor(key, off);
+        key = o < key ? o : key;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0)
+        skey[wave] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 m = skey[0];
+        for (int i = 1; i < 4; ++i)
+            m = skey[i] < m ? skey[i] : m;
+        atomicMin(online_slot(a.state, a.par, (int)(blockIdx.x % ONL_SLOTS)), m);
+    }
+}
+
 // ---- host side of the image-bounded search ------------------------------------------------------------------------
 // Does the chunk loop of this context search through the image?  VSOM_BMU_EXACT: never; VSOM_BMU_SHORTLIST: whenever the
 // kernels apply (Standard / Median, rows of at most 1024 values, sigma > 1); VSOM_BMU_AUTO: where it pays.  Measured on
@@ -1567,6 +1602,93 @@ static int single_query(vsom_ctx *c, const float *v_host, uint64_t node, int whi
     if (dist_out)
         *dist_out = pout[2];
     return VSOM_OK;
+}
+
+// one host vector against every node: restricted (or plain) BMU through the key slots, optionally all N distances
+static int single_scan(vsom_ctx *c, const float *v_host, int use_hits, uint64_t min_hits, uint64_t *bmu_out, float *dist_out,
+                       float *all_out_host)
+{
+    if (!c)
+        return vsom_fail(VSOM_ERR_INVALID, "null context");
+    VSOM_HIP_CHECK(hipSetDevice(c->device));
+    if (int jrc = vsom_join_aux(c))
+        return jrc;
+    if (!v_host)
+        return vsom_fail(VSOM_ERR_INVALID, "null argument");
+    int rc = stage_single(c, v_host);
+    if (rc)
+        return rc;
+    float *all_dev = nullptr;
+    if (all_out_host) {
+        if ((size_t)c->N * 4 > c->q_scratch_cap) {
+            VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+            if (c->q_scratch)
+                (void)hipFree(c->q_scratch);
+            c->q_scratch = nullptr;
+            c->q_scratch_cap = 0;
+            const size_t cap = ((size_t)c->N * 4 + 4095) / 4096 * 4096;
+            VSOM_HIP_CHECK(hipMalloc(&c->q_scratch, cap));
+            c->q_scratch_cap = cap;
+        }
+        all_dev = reinterpret_cast<float *>(c->q_scratch);
+    }
+    const bool clr = c->transform == VSOM_CLR;
+    const size_t xs_n = c->xpitch, pp = c->part_pitch;
+    float *xs = c->v_dev, *xp = c->v_dev + xs_n, *yp = xp + pp;
+    OnlineArgs a;
+    a.par = 0;
+    a.d.xa = clr ? xp : xs;
+    a.d.xb = clr ? yp : xs;
+    a.d.ldx = 0;
+    a.d.ma = c->map;
+    a.d.mb = clr ? c->map + c->part_pitch : c->map;
+    a.d.ldm = (int)c->pitch;
+    a.d.L = (int)c->part_len;
+    a.state = c->onl_state;
+    a.fstate = c->onl_f;
+    a.N = (int)c->N;
+    a.W = (int)c->W;
+    a.H = (int)c->H;
+    a.pxa = a.pxb = nullptr;
+    a.do_scan = 1;
+    a.do_post = 0;
+    VSOM_HIP_CHECK(hipMemsetAsync(c->onl_state, 0xFF, ONL_SLOTS * 16 * sizeof(u64), c->stream));   // arm the keys of parity 0
+    dim3 grid((unsigned)(((size_t)c->N * 8 + 255) / 256));
+    if (clr)
+        hipLaunchKernelGGL(single_scan_kernel<true>, grid, dim3(256), 0, c->stream, a, c->hits, (u64)min_hits, use_hits, all_dev);
+    else
+        hipLaunchKernelGGL(single_scan_kernel<false>, grid, dim3(256), 0, c->stream, a, c->hits, (u64)min_hits, use_hits, all_dev);
+    VSOM_HIP_CHECK(hipGetLastError());
+    u64 *st = reinterpret_cast<u64 *>(c->v_pinned + xs_n + 3 * pp + 32);   // image of onl_state (vsom_find_bmu)
+    VSOM_HIP_CHECK(hipMemcpyAsync(st, c->onl_state, ONL_STATE_BYTES, hipMemcpyDeviceToHost, c->stream));
+    if (all_out_host)
+        VSOM_HIP_CHECK(hipMemcpyAsync(all_out_host, all_dev, (size_t)c->N * 4, hipMemcpyDeviceToHost, c->stream));
+    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+    uint64_t key = ~0ull;
+    for (int sl = 0; sl < ONL_SLOTS; ++sl)
+        key = std::min<uint64_t>(key, st[sl * 16]);
+    const bool nan0 = st[ONL_FLAG] != 0;          // a NaN distance at node 0 pins the BMU to 0 (Som.cpp:316-322: `cur < NaN` never holds)
+    if (bmu_out)
+        *bmu_out = nan0 ? 0ull : (key & 0xFFFFFFFFull);
+    if (dist_out) {
+        const uint32_t bits = nan0 ? 0x7FC00000u : (uint32_t)(key >> 32);
+        std::memcpy(dist_out, &bits, 4);
+    }
+    return VSOM_OK;
+}
+
+// Som::findRestrictedBmu(v, ..., minBmuHits, ...) for ONE host vector (Som.cpp:313-332)
+int vsom_find_restricted_bmu(vsom_ctx *c, const float *v_host, uint64_t min_hits, uint64_t *bmu_out, float *dist_out)
+{
+    return single_scan(c, v_host, 1, min_hits, bmu_out, dist_out, nullptr);
+}
+
+// euclidianWeightedDist(i, v) of ONE host vector to every node i (what Som::findRestrictedBmd walks, Som.cpp:457-487)
+int vsom_distances_single(vsom_ctx *c, const float *v_host, float *dist_out_host)
+{
+    if (!dist_out_host)
+        return vsom_fail(VSOM_ERR_INVALID, "null output");
+    return single_scan(c, v_host, 0, 0, nullptr, nullptr, dist_out_host);
 }
 
 // Som::euclidianWeightedDist(pos, v, ...) for ONE host vector (Som.cpp:124-141)

@@ -1246,9 +1246,10 @@ SomIndex Som::findRestrictedBmu(const Eigen::VectorXf &v, const Eigen::VectorXf 
         const size_t idx = hostFindRestrictedBmu(v, valid, minBmuHits, weights);
         return SomIndex(idx % width, idx / width);
     }
-    stageOne(v);
+    if ((size_t)v.size() != inLen)
+        throw std::invalid_argument("sample length does not match the map");
     uint64_t idx = 0;
-    check(vsom_bmu_restricted_batch(ctx, minBmuHits, &idx, nullptr), "vsom_bmu_restricted_batch");
+    check(vsom_find_restricted_bmu(ctx, v.data(), minBmuHits, &idx, nullptr), "vsom_find_restricted_bmu");
     return SomIndex((size_t)idx % width, (size_t)idx / width);
 }
 
@@ -1263,9 +1264,10 @@ std::vector<double> Som::findRestrictedBmd(const Eigen::VectorXf &v, const Eigen
         for (size_t i = 0; i < N; ++i)
             d[i] = hHits[i] >= minBmuHits ? (float)hostDist(i, v, valid, weights) : 0.f;
     } else {
-        stageOne(v);
+        if ((size_t)v.size() != inLen)
+            throw std::invalid_argument("sample length does not match the map");
         refreshHost();
-        check(vsom_distances_row(ctx, 0, d.data()), "vsom_distances_row");
+        check(vsom_distances_single(ctx, v.data(), d.data()), "vsom_distances_single");
     }
     std::vector<double> dist(N, -1);
     double C = 0;

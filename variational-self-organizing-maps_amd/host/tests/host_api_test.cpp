@@ -432,6 +432,70 @@ static int threads_mode(const std::string &out)
     return 0;
 }
 
+// `host_api_test perf_e2e_online <rows.f32> <nrows> <depth> <chunk>`: Som::train(..., Exponential | InverseProportional)
+// (Som.cpp:1135-1187: trainBasicSom, one trainSingle per sample) through the reference API on a 128x128 map at sigma 8,
+// one JSON line per run: wall time of the call, device time of the same epochs (the library's HIP-event span around the
+// chunk's kernels) and their ratio.
+static int perf_e2e_online(int argc, char **argv)
+{
+    if (argc < 6) {
+        std::fprintf(stderr, "usage: perf_e2e_online <rows.f32> <nrows> <depth> <chunk>\n");
+        return 2;
+    }
+    const size_t nrows = std::stoul(argv[3]), depth = std::stoul(argv[4]), chunk = std::stoul(argv[5]);
+    std::vector<float> rows(nrows * depth);
+    {
+        std::ifstream f(argv[2], std::ios::binary);
+        f.read((char *)rows.data(), (std::streamsize)(rows.size() * 4));
+        if (!f) {
+            std::fprintf(stderr, "cannot read %s\n", argv[2]);
+            return 2;
+        }
+    }
+    ArrayDataLoader loader(rows.data(), nrows, depth, chunk);
+    DataSet ds(loader);
+    Som som{128, 128, ds, Transformation::Standard(loader.getNames())};
+    som.randomInitialize(42, 1);
+    std::cout.setstate(std::ios_base::failbit);
+    static const char *const names[VSOM_T_COUNT] = {"stage", "bmu", "finish", "cw", "update", "online", "sigma"};
+    auto run = [&](const char *what, Som::WeigthDecayFunction fn, size_t epochs) {
+        float ms[VSOM_T_COUNT];
+        uint32_t cnt[VSOM_T_COUNT];
+        vsom_get_timing(som.context(), ms, cnt, 1);
+        vsom_enable_timing(som.context(), 1);
+        const auto t0 = std::chrono::steady_clock::now();
+        som.train(ds, epochs, 0.1, 0.0, 8.0, 0.0, fn);               // eta 0.1, sigma 8 throughout
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        vsom_get_timing(som.context(), ms, cnt, 1);
+        vsom_enable_timing(som.context(), 0);
+        double dev = 0;
+        for (int i = 0; i < VSOM_T_COUNT; ++i)
+            dev += ms[i];
+        uint64_t st[4] = {0, 0, 0, 0};
+        vsom_get_online_search_stats(som.context(), st, 1);
+        std::cout.clear();
+        std::printf("{\"e2e\": \"%s\", \"loader\": \"array\", \"rows\": %zu, \"depth\": %zu, \"chunk\": %zu, \"epochs\": %zu, "
+                    "\"wall_ms_per_epoch\": %.3f, \"device_ms_per_epoch\": %.3f, \"device_over_wall\": %.4f, \"samples_per_s\": %.0f, "
+                    "\"device_only_samples_per_s\": %.0f, \"wall_us_per_sample\": %.3f, \"searched_through_the_image\": %s",
+                    what, nrows, som.getDepth(), chunk, epochs, wall / epochs, dev / epochs, dev / wall, nrows * epochs / wall * 1e3,
+                    nrows * epochs / dev * 1e3, wall / epochs / nrows * 1e3, st[0] ? "true" : "false");
+        for (int i = 0; i < VSOM_T_COUNT; ++i)
+            if (cnt[i])
+                std::printf(", \"%s_ms\": %.3f", names[i], ms[i] / epochs);
+        std::printf("}\n");
+        std::fflush(stdout);
+        std::cout.setstate(std::ios_base::failbit);
+    };
+    som.train(ds, 1, 0.1, 0.0, 8.0, 0.0, Som::WeigthDecayFunction::Exponential);      // warm-up: allocations, tables
+    for (int r = 0; r < 2; ++r)
+        run("Som::train(Exponential), sigma 8, one epoch per call", Som::WeigthDecayFunction::Exponential, 1);
+    run("Som::train(Exponential), sigma 8, three epochs", Som::WeigthDecayFunction::Exponential, 3);
+    run("Som::train(InverseProportional), sigma 8, one epoch per call", Som::WeigthDecayFunction::InverseProportional, 1);
+    run("Som::train(InverseProportional), sigma 8, three epochs", Som::WeigthDecayFunction::InverseProportional, 3);
+    std::cout.clear();
+    return 0;
+}
+
 // `host_api_test mnist <folder> <outdir>`: BASELINE configuration 2's plumbing at test size -- IDX files
 // -> MnistDataLoader (chunked) -> DataSet -> Som::train(BatchMap); the dump is compared with the oracle
 // run on the same rows and chunk boundaries (tests/test_gpu_host_cpp.py)
@@ -461,6 +525,8 @@ int main(int argc, char **argv)
         return perf_mnist(argv[2]);
     if (argc > 2 && std::string(argv[1]) == "perf_e2e")
         return perf_e2e(argc, argv);
+    if (argc > 2 && std::string(argv[1]) == "perf_e2e_online")
+        return perf_e2e_online(argc, argv);
     if (argc > 3 && std::string(argv[1]) == "mnist")
         return mnist(argv[2], argv[3]);
     const std::string out = argc > 1 ? argv[1] : ".";
