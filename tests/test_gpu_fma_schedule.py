@@ -10,7 +10,7 @@ more epochs -- each run on ITS OWN map against the strict oracle on its own.
     include/vsom_hip.h); asserted here up to BASELINE config 3's size (10 epochs x 2 chunks of 4096).
   * VSOM_UPDATE_FMA: holds its tolerance for ONE epoch from a given map (tests/test_gpu_fma_mode.py) and no
     longer: the next search runs on a map perturbed by ~3e-7, near-ties flip, and the run leaves the
-    reference's trajectory.  That is measured here (tools/fma_schedule_report.py, profiles/r3_fma_schedule.jsonl:
+    reference's trajectory.  That is measured here (tests/perf/fma_schedule_report.py, profiles/r3_fma_schedule.jsonl:
     C3 with 2 chunks: 5 of 8192 BMUs differ in epoch 0, 24 % by epoch 9), not asserted away: the test records
     the first epoch whose BMUs differ and only requires that strict on the same inputs does not.
 bench.py therefore quotes `value` on strict."""

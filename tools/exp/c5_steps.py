@@ -27,5 +27,6 @@ for i in range(int(os.environ.get("STEPS", "24"))):
     extra = {"A2max_pct": [float(np.percentile(A2, q)) for q in (50, 90, 99, 100)],
              "nB_pct": [float(np.percentile(nB, q)) for q in (50, 90, 99, 100)]}
     print(json.dumps({"step": i, **extra, "bmu_ms": round(tm["bmu"][0], 3), "update_ms": round(tm["update"][0], 3), "stats": st,
-                      "nan_rows": int(np.isnan(m).any(axis=1).sum()), "distinct_rows": int(len(np.unique(m.round(4), axis=0)))}))
+                      "nan_rows": int(np.isnan(m).any(axis=1).sum()), "distinct_rows": int(len(np.unique(m.round(4), axis=0))),
+                      "bit_distinct_rows": int(len(np.unique(np.ascontiguousarray(m).view(np.uint32), axis=0)))}))
 ctx.close()

@@ -215,7 +215,7 @@ __device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1,
                                               u64 *__restrict__ partial, int pstride,
                                               unsigned char *__restrict__ nan0,
                                               const int *__restrict__ slist,
-                                              const u64 *__restrict__ hits, u64 min_hits, int by,
+                                              const u64 *__restrict__ hits, u64 min_hits, int by, int bx,
                                               const int *__restrict__ nlist, const unsigned *__restrict__ ncount)
 {
     constexpr int TS = 16 * TI;                 // samples per tile
@@ -225,11 +225,11 @@ __device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1,
     if (ncount) {
         const int cnt = (int)*ncount;
         N = cnt < N ? cnt : N;
-        if ((int)blockIdx.x * TILE >= N) {      // workgroup-uniform
+        if (bx * TILE >= N) {                   // workgroup-uniform
             if ((int)threadIdx.x < TS) {
                 const int s = s0 + by * TS + (int)threadIdx.x;
                 if (s < s1)
-                    partial[(size_t)blockIdx.x * pstride + (slist ? slist[s - s0] : s)] = ~0ull;
+                    partial[(size_t)bx * pstride + (slist ? slist[s - s0] : s)] = ~0ull;
             }
             return;
         }
@@ -241,7 +241,7 @@ __device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1,
     __shared__ __attribute__((aligned(16))) float sb[CLR ? TILE * LDT : 4];
 
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int nbase = blockIdx.x * TILE;
+    const int nbase = bx * TILE;
     const int sbase = s0 + by * TS;
     const int L = a.L, L8 = L & ~7;
     const int nchunks = (L + VSOM_TK - 1) / VSOM_TK;
@@ -393,7 +393,7 @@ __device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1,
         }
 
     // node 0's NaN flag: `cur < NaN` is never true, so a NaN at node 0 pins the BMU to 0 (Som.cpp:293-299)
-    if (blockIdx.x == 0 && tx == 0) {
+    if (bx == 0 && tx == 0) {
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             int s = sbase + ty + 16 * i;
@@ -428,7 +428,7 @@ __device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1,
                 u64 k = keys[tid * 16 + t];
                 kmin = k < kmin ? k : kmin;
             }
-            partial[(size_t)blockIdx.x * pstride + (slist ? slist[s - s0] : s)] = kmin;
+            partial[(size_t)bx * pstride + (slist ? slist[s - s0] : s)] = kmin;
         }
     }
 }
@@ -451,23 +451,41 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
     if (LIST && fb.scal && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64)
         sl_feedback_write(fb);               // (vsom_digits.hpp: the search's statistics for the host)
     if (!LIST) {
-        bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, nullptr, hits, min_hits, (int)blockIdx.y, nlist, ncount);
+        bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, nullptr, hits, min_hits, (int)blockIdx.y, (int)blockIdx.x, nlist,
+                               ncount);
         return;
     }
     const int cnt = (int)*scount;
     s1 = s0 + cnt < s1 ? s0 + cnt : s1;
-    for (int by = blockIdx.y; s0 + by * TS < s1; by += gridDim.y) {
-        if (by != (int)blockIdx.y)
+    // The workgroups of the (node tile, walker) grid share out the (node tile, sample tile) pairs that EXIST: with a node
+    // list the live node tiles are a device-side count -- were the walk tied to blockIdx.x, the workgroups of dead node tiles
+    // would leave and the others keep their full share (C5's collapsed maps: 7 of 16 node tiles live, the search 9 % shorter
+    // instead of 55 %).
+    const int nts = (s1 - s0 + TS - 1) / TS;
+    int neff = N;
+    if (ncount) {
+        const int nc = (int)*ncount;
+        neff = nc < N ? nc : N;
+    }
+    const int ntn = (neff + TILE - 1) / TILE;
+    const int G = (int)(gridDim.x * gridDim.y), f0 = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+    for (int w = f0; w < ntn * nts; w += G) {
+        if (w != f0)
             __syncthreads();                    // the key scratch of the previous tile has been read
-        bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, slist, hits, min_hits, by, nlist, ncount);
+        bmu_tile_body<CLR, TI>(a, s0, s1, N, partial, pstride, nan0, slist, hits, min_hits, w / ntn, w % ntn, nlist, ncount);
     }
 }
 
 __global__ void bmu_reduce_kernel(const u64 *__restrict__ partial, int pstride, int ntiles,
                                   const unsigned char *__restrict__ nan0, int s0, int s1,
                                   u64 *__restrict__ lastbmu, float *__restrict__ sqres,
-                                  const int *__restrict__ slist, const unsigned *__restrict__ scount)
+                                  const int *__restrict__ slist, const unsigned *__restrict__ scount,
+                                  const unsigned *__restrict__ ncount)
 {
+    if (ncount) {                               // node list: only its tiles were searched (and written)
+        const int live = ((int)*ncount + TILE - 1) / TILE;
+        ntiles = live < ntiles ? live : ntiles;
+    }
     int s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (scount) {
         const int cnt = (int)*scount;
@@ -673,7 +691,7 @@ int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *s
 #undef VSOM_TILE_LAUNCH
     hipLaunchKernelGGL(bmu_reduce_kernel, dim3((unsigned)((s1 - s0 + 255) / 256)), dim3(256), 0,
                        c->stream, c->partial, (int)c->Bcap, ntn, c->nan0, (int)s0, (int)s1, c->lastbmu,
-                       c->sqres, slist, scount);
+                       c->sqres, slist, scount, ncount);
     VSOM_HIP_CHECK(hipGetLastError());
     return VSOM_OK;
 }
