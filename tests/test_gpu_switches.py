@@ -4,6 +4,7 @@ that no kernel in libvsom_hip.so is reachable only by hand:
   VSOM_NO_CHAIN=1           small maps through the lane = node quad kernels instead of update_chain3_kernel
   VSOM_NO_COMPACT=1         no column compaction at all (the quad kernels on the full-width transposed chunk)
   VSOM_COMPACT_MIN_ROWS=1   every chunk compacted, however short
+  VSOM_NO_DEDUPE=1          the exact search over every node, duplicate rows included (no representatives pass)
 Each switch is read once per process, hence a fresh child interpreter per setting (a child process, never a re-exec),
 running parity tests that compare the HIP path with the oracle bit for bit."""
 import os
@@ -46,3 +47,7 @@ def test_without_column_compaction():
 def test_every_chunk_compacted():
     _child({"VSOM_COMPACT_MIN_ROWS": "1", "VSOM_ASM_SWEEP_N": "12"},
            ["test_gpu_random_shapes.py", "test_gpu_batch_parity.py", "test_gpu_shortlist.py", "test_gpu_group.py"])
+
+
+def test_exact_search_without_the_duplicate_row_pass():
+    _child({"VSOM_NO_DEDUPE": "1"}, ["test_gpu_dedupe.py", "test_gpu_shortlist.py"], kexpr="duplicate or redo or ties")

@@ -1,15 +1,15 @@
 #!/bin/bash
-# Development: copy what tools/exp/final_artefacts.sh left under gpurun_out/ into profiles/ (run here, after the GPU call)
+# Development: copy what the round's GPU calls (tools/prof_all.sh, tools/exp/final_artefacts.sh) left under gpurun_out/ into
+# profiles/ (run here, after the GPU calls).  ROUND=r6 by default.
 cd "$(dirname "$0")/../.."
-for c in c3 c3_sigma c3_contracted c2 c4 c5 online; do
+R=${ROUND:-r6}
+for c in c3 c3_sigma c3_contracted c2 c4 c5 online online_exact; do
   for f in bench_default.json bench_under_rocprof.json kernel_stats.txt pmc.txt bench_under_rocprof_headline.json kernel_stats_headline.txt; do
-    [ -s gpurun_out/r5_$c/summary/$f ] && cp gpurun_out/r5_$c/summary/$f profiles/r5_${c}_$f
+    [ -s gpurun_out/${R}_$c/summary/$f ] && cp gpurun_out/${R}_$c/summary/$f profiles/${R}_${c}_$f
   done
 done
-cp gpurun_out/r5_records/ab_stage.jsonl profiles/r5_ab_stage.jsonl
-cp gpurun_out/r5_records/ab_cwl2.jsonl profiles/r5_ab_cwl2.jsonl
-cp gpurun_out/r5_records/step_timeline.txt profiles/r5_step_timeline.txt
-cp gpurun_out/r5_rank_sim_strong.jsonl profiles/r5_rank_sim_strong.jsonl
-cp gpurun_out/r5_e2e_final.jsonl profiles/r5_e2e.jsonl
-cp gpurun_out/r5_bench_default_final.json profiles/r5_c3_bench_data_variants.json
-python3 tools/traffic_from_pmc.py r5 > /dev/null
+for f in rank_sim_strong.jsonl e2e.jsonl ref_harness.jsonl online_sweep.jsonl; do
+  [ -s gpurun_out/${R}_final/$f ] && cp gpurun_out/${R}_final/$f profiles/${R}_$f
+done
+[ -s gpurun_out/${R}_final/bench_default.json ] && cp gpurun_out/${R}_final/bench_default.json profiles/${R}_c3_bench_data_variants.json
+python3 tools/traffic_from_pmc.py $R > /dev/null

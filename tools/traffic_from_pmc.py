@@ -20,7 +20,7 @@ ROUND = sys.argv[1] if len(sys.argv) > 1 else "r4"
 KERNEL = {"c3_strict": ("c3", r"vsom_update_std_nt4_gfx950"), "c3_sigma": ("c3_sigma", r"vsom_update_sfma_nt4_gfx950"),
           "c3_contracted": ("c3_contracted", r"vsom_update_fma_nt4_gfx950"),
           "c2_strict": ("c2", r"vsom_update_std_nt4_gfx950"), "c4_strict": ("c4", r"update_chain3_kernel"),
-          "c5_strict": ("c5", r"vsom_update_clr_rp8_gfx950"), "online_strict": ("online", r"online_window_kernel")}
+          "c5_strict": ("c5", r"vsom_update_clr_rp8_gfx950"), "online_strict": ("online", r"onl_fused_kernel")}
 
 
 def counters(path, kernel):
