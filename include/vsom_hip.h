@@ -138,6 +138,12 @@ int vsom_set_update_mode(vsom_ctx *ctx, int mode);
  * Chunks of at least min_rows rows use it (default 1024: below that the passes cost more than they save);
  * min_rows < 0 switches it off. */
 int vsom_set_column_compaction(vsom_ctx *ctx, long min_rows);
+/* [MI355X build] The exact search (small problems, the shortlist's redo list, VSOM_BMU_EXACT) evaluates ONE representative
+ * per class of bit-identical model rows (csrc/vsom_bmu.hip: equal rows give equal distances and the reference's strict `<`
+ * keeps the lowest index, Som.cpp:293-304) -- batch training on degenerate chunks leaves such maps (an empty chunk: one
+ * class).  Results are bit-identical with it on or off.  Searches of at least min_work (sample, node, value) triples use
+ * it (default 2e10; a redo list also only while a recent search reported a long one); 0: always; < 0: never. */
+int vsom_set_row_dedupe(vsom_ctx *ctx, double min_work);
 /* diagnostics of the last MFMA-shortlist search (synchronises): out[0] = samples that had to be
  * redone by the exact-order kernel, out[1] = shortlisted candidates in total, out[2] = samples
  * searched, out[3] = number of shortlist searches so far */

@@ -42,7 +42,6 @@ def test_exact_search_on_a_map_with_duplicate_rows(tr, W, H, J, B):
     D = po.length(tr, J)
     X = gen.correlated(B, J, seed=5) if tr == po.CLR else gen.blobs(B, J, 6, 1, 2, sigma=0.4)
     init = map_with_copies(W * H, D, seed=7)
-    assert B * W * H * D >= 2.0e9                       # the size from which the representatives are used
     orc = po.OracleSom(W, H, J, tr)
     orc.set_state(map=init)
     lb = np.zeros(B, np.uint64)
@@ -51,6 +50,7 @@ def test_exact_search_on_a_map_with_duplicate_rows(tr, W, H, J, B):
     for mode in (capi.BMU_EXACT, capi.BMU_AUTO):
         ctx = vsom_amd.Context(W, H, J, tr)
         ctx.set_bmu_mode(mode)
+        ctx.set_row_dedupe(0)                           # always (the default waits for searches of 2e10 triples)
         ctx.set_state(map=init)
         ctx.upload_chunk(X)
         idx, dist = ctx.bmu_batch()
@@ -84,9 +84,10 @@ def test_redo_list_of_a_shortlist_search_uses_the_representatives():
     orc.batch_phase1_range(X, 0, B, lb, sq, True, nthreads=16)
     ctx = vsom_amd.Context(W, H, J, po.STANDARD)
     ctx.set_bmu_mode(capi.BMU_SHORTLIST)
+    ctx.set_row_dedupe(1.0)                              # any size, but a redo list only after a recent long one
     ctx.set_state(map=init)
     ctx.upload_chunk(X)
-    for rep in range(2):
+    for rep in range(3):                                 # (default threshold: the second search knows the first one's long list)
         idx, dist = ctx.bmu_batch()
         assert (idx == lb).all(), (rep, np.nonzero(idx != lb)[0][:8])
         assert bits_eq(dist, sq), rep

@@ -27,7 +27,7 @@ TIMER_NAMES = ["stage", "bmu", "finish", "cw", "update", "online", "sigma"]
 # every symbol include/vsom_hip.h declares (tests/test_capi_symbols.py checks the header too)
 SYMBOLS = [
     "vsom_last_error", "vsom_device_count", "vsom_create", "vsom_destroy", "vsom_set_stream",
-    "vsom_synchronize", "vsom_set_bmu_mode", "vsom_set_update_mode", "vsom_set_column_compaction", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
+    "vsom_synchronize", "vsom_set_bmu_mode", "vsom_set_update_mode", "vsom_set_column_compaction", "vsom_set_row_dedupe", "vsom_get_shortlist_stats", "vsom_depth", "vsom_nodes", "vsom_set_state",
     "vsom_get_state", "vsom_upload_chunk", "vsom_set_chunk_device", "vsom_host_alloc", "vsom_host_free",
     "vsom_prefetch_chunk", "vsom_prefetch_wait", "vsom_commit_chunk", "vsom_stage_next_device", "vsom_get_last_bmu",
     "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_find_bmu", "vsom_dist_single", "vsom_find_local_bmu", "vsom_find_restricted_bmu", "vsom_distances_single", "vsom_bmu_local_batch",
@@ -115,6 +115,7 @@ def lib():
     L.vsom_set_bmu_mode.argtypes = [vp, C.c_int]
     L.vsom_set_update_mode.argtypes = [vp, C.c_int]
     L.vsom_set_column_compaction.argtypes = [vp, C.c_long]
+    L.vsom_set_row_dedupe.argtypes = [vp, C.c_double]
     L.vsom_get_shortlist_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
     for name in ("vsom_depth", "vsom_nodes", "vsom_residual_len", "vsom_pitch", "vsom_chunk_pitch"):
         getattr(L, name).argtypes = [vp]
@@ -283,6 +284,11 @@ class Context:
 
     def set_update_mode(self, mode):
         check(lib().vsom_set_update_mode(self._h, int(mode)))
+
+    def set_row_dedupe(self, min_work):
+        """exact searches of at least min_work (sample, node, value) triples evaluate one representative per class of
+        bit-identical model rows (default 2e10; 0: always; < 0: never)"""
+        check(lib().vsom_set_row_dedupe(self._h, float(min_work)))
 
     def set_column_compaction(self, min_rows):
         """chunks of at least min_rows rows retire their all-zero columns (default 1024; < 0: off)"""

@@ -222,6 +222,10 @@ __device__ __forceinline__ void bmu_tile_body(const DistArgs &a, int s0, int s1,
     // nlist / ncount: search the listed nodes only -- the lowest-index representative of every class of bit-identical
     // model rows (bmu_dedupe_*: equal rows give equal distances and the strict `<` keeps the lowest index, Som.cpp:299).
     // Positions past the count are not evaluated; a tile wholly past it only reports "nothing here".
+    if (ncount && *ncount == 0xFFFFFFFFu) {     // the passes left without a list (short redo list): every node, no indirection
+        ncount = nullptr;
+        nlist = nullptr;
+    }
     if (ncount) {
         const int cnt = (int)*ncount;
         N = cnt < N ? cnt : N;
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void bmu_tile_kernel(DistArgs a, int s0, in
     // instead of 55 %).
     const int nts = (s1 - s0 + TS - 1) / TS;
     int neff = N;
-    if (ncount) {
+    if (ncount && *ncount != 0xFFFFFFFFu) {
         const int nc = (int)*ncount;
         neff = nc < N ? nc : N;
     }
@@ -482,7 +486,7 @@ __global__ void bmu_reduce_kernel(const u64 *__restrict__ partial, int pstride, 
                                   const int *__restrict__ slist, const unsigned *__restrict__ scount,
                                   const unsigned *__restrict__ ncount)
 {
-    if (ncount) {                               // node list: only its tiles were searched (and written)
+    if (ncount && *ncount != 0xFFFFFFFFu) {     // node list: only its tiles were searched (and written)
         const int live = ((int)*ncount + TILE - 1) / TILE;
         ntiles = live < ntiles ? live : ntiles;
     }
@@ -531,35 +535,33 @@ __global__ __launch_bounds__(256) void bmu_row_hash_kernel(const float *__restri
     __shared__ u64 sh[4];
     if (scount && *scount < min_list)
         return;
-    const int n = blockIdx.x;
-    const unsigned *row = reinterpret_cast<const unsigned *>(map + (size_t)n * ldm);
-    u64 h = 0;
-    for (int d = threadIdx.x * 4; d < ldm; d += 1024) {      // pitches are multiples of 32 floats
-        const uint4 v = *reinterpret_cast<const uint4 *>(row + d);
-        h += bmu_mix64(((u64)(d + 0) << 32) | v.x) + bmu_mix64(((u64)(d + 1) << 32) | v.y) +
-             bmu_mix64(((u64)(d + 2) << 32) | v.z) + bmu_mix64(((u64)(d + 3) << 32) | v.w);
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {        // (a bounded grid: leaving early is then a 2 us launch)
+        const unsigned *row = reinterpret_cast<const unsigned *>(map + (size_t)n * ldm);
+        u64 h = 0;
+        for (int d = threadIdx.x * 4; d < ldm; d += 1024) {  // pitches are multiples of 32 floats
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + d);
+            h += bmu_mix64(((u64)(d + 0) << 32) | v.x) + bmu_mix64(((u64)(d + 1) << 32) | v.y) +
+                 bmu_mix64(((u64)(d + 2) << 32) | v.z) + bmu_mix64(((u64)(d + 3) << 32) | v.w);
+        }
+        for (int off = 32; off > 0; off >>= 1)
+            h += __shfl_xor(h, off);
+        if ((threadIdx.x & 63) == 0)
+            sh[threadIdx.x >> 6] = h;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            hash[n] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        __syncthreads();
     }
-    for (int off = 32; off > 0; off >>= 1)
-        h += __shfl_xor(h, off);
-    if ((threadIdx.x & 63) == 0)
-        sh[threadIdx.x >> 6] = h;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        hash[n] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 __global__ __launch_bounds__(256) void bmu_row_twin_kernel(const float *__restrict__ map, int ldm, int N, const u64 *__restrict__ hash,
                                                            int *__restrict__ rep, const unsigned *__restrict__ scount,
                                                            unsigned min_list)
 {
-    const int n = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (n >= N)
-        return;
-    if (scount && *scount < min_list) {
-        if (lane == 0)
-            rep[n] = n;
-        return;
-    }
+    const int lane = threadIdx.x & 63;
+    if (scount && *scount < min_list)
+        return;                                              // (bmu_unique_kernel then marks "no list": rep is not read)
+    for (int n = blockIdx.x * 4 + ((int)threadIdx.x >> 6); n < N; n += 4 * (int)gridDim.x) {
     const u64 hn = hash[n];
     const unsigned *rn = reinterpret_cast<const unsigned *>(map + (size_t)n * ldm);
     int found = n;
@@ -583,14 +585,21 @@ __global__ __launch_bounds__(256) void bmu_row_twin_kernel(const float *__restri
     }
     if (lane == 0)
         rep[n] = found;
+    }
 }
 
 __global__ __launch_bounds__(1024) void bmu_unique_kernel(const int *__restrict__ rep, int N, int *__restrict__ ulist,
-                                                          unsigned *__restrict__ ucount)
+                                                          unsigned *__restrict__ ucount, const unsigned *__restrict__ scount,
+                                                          unsigned min_list)
 {
     __shared__ int swave[16];
     __shared__ int sbase;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (scount && *scount < min_list) {                      // short redo list: no representatives pass, no list
+        if (tid == 0)
+            *ucount = 0xFFFFFFFFu;
+        return;
+    }
     if (tid == 0)
         sbase = 0;
     __syncthreads();
@@ -629,11 +638,11 @@ static int launch_bmu_dedupe(vsom_ctx *c, const unsigned *scount, unsigned min_l
     }
     u64 *hash = reinterpret_cast<u64 *>(c->dd_hash);
     unsigned *cnt = reinterpret_cast<unsigned *>(c->dd_list + c->N);
-    hipLaunchKernelGGL(bmu_row_hash_kernel, dim3((unsigned)c->N), dim3(256), 0, c->stream, c->map, (int)c->pitch, (int)c->N, hash, scount,
-                       min_list);
-    hipLaunchKernelGGL(bmu_row_twin_kernel, dim3((unsigned)((c->N + 3) / 4)), dim3(256), 0, c->stream, c->map, (int)c->pitch, (int)c->N,
-                       hash, c->dd_rep, scount, min_list);
-    hipLaunchKernelGGL(bmu_unique_kernel, dim3(1), dim3(1024), 0, c->stream, c->dd_rep, (int)c->N, c->dd_list, cnt);
+    hipLaunchKernelGGL(bmu_row_hash_kernel, dim3(std::min<unsigned>((unsigned)c->N, 2048u)), dim3(256), 0, c->stream, c->map,
+                       (int)c->pitch, (int)c->N, hash, scount, min_list);
+    hipLaunchKernelGGL(bmu_row_twin_kernel, dim3(std::min<unsigned>((unsigned)((c->N + 3) / 4), 1024u)), dim3(256), 0, c->stream,
+                       c->map, (int)c->pitch, (int)c->N, hash, c->dd_rep, scount, min_list);
+    hipLaunchKernelGGL(bmu_unique_kernel, dim3(1), dim3(1024), 0, c->stream, c->dd_rep, (int)c->N, c->dd_list, cnt, scount, min_list);
     *nlist = c->dd_list;
     *ncount = cnt;
     return VSOM_OK;
@@ -664,13 +673,27 @@ int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *s
     const bool list = slist != nullptr && scount != nullptr;
     const int gy = list ? std::min(nts, std::max(1, 512 / ntn)) : nts;
     dim3 grid((unsigned)ntn, (unsigned)gy);
-    // Representatives of the duplicate rows only -- where the search is large enough to repay three small passes over the
-    // map (~20 us at C5's size): 2e9 (sample, node, value) triples = ~50 us of this kernel.  With a redo list the passes
-    // look at its device-side length first and leave when it is short (the usual case).  Not for restricted searches:
-    // bit-identical rows may differ in their hit counts.
+    // Representatives of the duplicate rows only -- where the search is large enough to repay three passes over the map
+    // (C3's size: hash 15 + twins 5 + list 17 us): 2e10 (sample, node, value) triples = ~0.5 ms of this kernel
+    // (vsom_set_row_dedupe moves the threshold; 0 = always).  With a redo list the passes look at its device-side length
+    // first and leave when it is short.  Not for restricted searches: bit-identical rows may differ in their hit counts.
     const int *nlist = nullptr;
     const unsigned *ncount = nullptr;
-    if (!hits && c->N >= 256 && c->dedupe && (double)(s1 - s0) * (double)c->N * (double)c->D >= 2.0e9) {
+    const double work = (double)(s1 - s0) * (double)c->N * (double)c->D;
+    bool dd = !hits && c->N >= 256 && c->dedupe && c->dd_min_work >= 0 && work >= c->dd_min_work;
+    if (dd && list && c->dd_min_work > 0) {
+        // A redo list is usually empty (C3: always), and then even three launches that look at its length and leave are
+        // ~8 us of a step for nothing: the passes are enqueued only while a recent search of this context reported a long
+        // list (the shortlist's pinned feedback words, possibly one call stale; C5 alternates collapsed and healthy maps, so
+        // "recent" spans eight searches)
+        volatile unsigned *fbw = c->sl_fb;
+        if (fbw && fbw[0] >= 256u)
+            c->dd_recent = 8;
+        else if (c->dd_recent > 0)
+            --c->dd_recent;
+        dd = c->dd_recent > 0;
+    }
+    if (dd) {
         if (int rc = launch_bmu_dedupe(c, list ? scount : nullptr, 256u, &nlist, &ncount))
             return rc;
     }

@@ -393,6 +393,15 @@ int vsom_set_column_compaction(vsom_ctx *c, long min_rows)
     return VSOM_OK;
 }
 
+int vsom_set_row_dedupe(vsom_ctx *c, double min_work)
+{
+    if (!c)
+        return vsom_fail(VSOM_ERR_INVALID, "null context");
+    c->dd_min_work = min_work;
+    c->dd_recent = 0;
+    return VSOM_OK;
+}
+
 int vsom_set_update_mode(vsom_ctx *c, int mode)
 {
     if (!c || (mode != VSOM_UPDATE_STRICT && mode != VSOM_UPDATE_FMA && mode != VSOM_UPDATE_FMA_SIGMA))
