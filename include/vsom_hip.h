@@ -142,7 +142,8 @@ int vsom_set_column_compaction(vsom_ctx *ctx, long min_rows);
  * per class of bit-identical model rows (csrc/vsom_bmu.hip: equal rows give equal distances and the reference's strict `<`
  * keeps the lowest index, Som.cpp:293-304) -- batch training on degenerate chunks leaves such maps (an empty chunk: one
  * class).  Results are bit-identical with it on or off.  Searches of at least min_work (sample, node, value) triples use
- * it (default 2e10; a redo list also only while a recent search reported a long one); 0: always; < 0: never. */
+ * it (default 2e10; behind a shortlist search -- its redo list -- only for the CLR comparer, whose collapsed maps put whole
+ * chunks on that list); 0: always; < 0: never. */
 int vsom_set_row_dedupe(vsom_ctx *ctx, double min_work);
 /* diagnostics of the last MFMA-shortlist search (synchronises): out[0] = samples that had to be
  * redone by the exact-order kernel, out[1] = shortlisted candidates in total, out[2] = samples

@@ -84,13 +84,43 @@ def test_redo_list_of_a_shortlist_search_uses_the_representatives():
     orc.batch_phase1_range(X, 0, B, lb, sq, True, nthreads=16)
     ctx = vsom_amd.Context(W, H, J, po.STANDARD)
     ctx.set_bmu_mode(capi.BMU_SHORTLIST)
-    ctx.set_row_dedupe(1.0)                              # any size, but a redo list only after a recent long one
+    ctx.set_row_dedupe(0)                                # always (by default only CLR's redo lists get the passes)
     ctx.set_state(map=init)
     ctx.upload_chunk(X)
-    for rep in range(3):                                 # (default threshold: the second search knows the first one's long list)
+    for rep in range(2):
         idx, dist = ctx.bmu_batch()
         assert (idx == lb).all(), (rep, np.nonzero(idx != lb)[0][:8])
         assert bits_eq(dist, sq), rep
     st = ctx.shortlist_stats()
     ctx.close()
     assert st["redo_samples"] >= 300, st
+
+
+def test_collapsed_clr_map_goes_through_the_redo_list_with_representatives():
+    """C5's situation: a CLR map whose nodes nearly coincide (40 distinct rows that differ in the sixth digit, spread over
+    1024 nodes).  The shortlist recognises the collapse on the device, every sample lands on the redo list, and -- by
+    default, for the CLR comparer -- the exact kernel then searches the 40 representatives."""
+    W = H = 32
+    J, B = 20, 4096
+    D = po.length(po.CLR, J)
+    X = gen.correlated(B, J, seed=9)
+    rs = np.random.RandomState(3)
+    row = gen.random_map(1, D, seed=11)[0]
+    base = np.stack([(row * np.float32(1.0 + 1e-6 * k)).astype(np.float32) for k in range(40)])
+    init = base[rs.randint(0, 40, size=W * H)].copy()
+    assert len(np.unique(init.view(np.uint32), axis=0)) == 40
+    orc = po.OracleSom(W, H, J, po.CLR)
+    orc.set_state(map=init)
+    lb = np.zeros(B, np.uint64)
+    sq = np.zeros(B, np.float32)
+    orc.batch_phase1_range(X, 0, B, lb, sq, True, nthreads=16)
+    ctx = vsom_amd.Context(W, H, J, po.CLR)
+    ctx.set_state(map=init)
+    ctx.upload_chunk(X)
+    for rep in range(2):
+        idx, dist = ctx.bmu_batch()
+        assert (idx == lb).all(), (rep, np.nonzero(idx != lb)[0][:8])
+        assert bits_eq(dist, sq), rep
+    st = ctx.shortlist_stats()
+    ctx.close()
+    assert st["redo_samples"] == B, st                   # the collapse was recognised: everything went to the exact kernel

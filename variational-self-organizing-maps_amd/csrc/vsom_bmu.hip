@@ -681,17 +681,14 @@ int launch_bmu_full_exact_masked(vsom_ctx *c, size_t s0, size_t s1, const int *s
     const unsigned *ncount = nullptr;
     const double work = (double)(s1 - s0) * (double)c->N * (double)c->D;
     bool dd = !hits && c->N >= 256 && c->dedupe && c->dd_min_work >= 0 && work >= c->dd_min_work;
-    if (dd && list && c->dd_min_work > 0) {
-        // A redo list is usually empty (C3: always), and then even three launches that look at its length and leave are
-        // ~8 us of a step for nothing: the passes are enqueued only while a recent search of this context reported a long
-        // list (the shortlist's pinned feedback words, possibly one call stale; C5 alternates collapsed and healthy maps, so
-        // "recent" spans eight searches)
-        volatile unsigned *fbw = c->sl_fb;
-        if (fbw && fbw[0] >= 256u)
-            c->dd_recent = 8;
-        else if (c->dd_recent > 0)
-            --c->dd_recent;
-        dd = c->dd_recent > 0;
+    if (dd && list && c->dd_min_work > 0 && c->transform != VSOM_CLR) {
+        // A redo list is usually empty or a handful of non-finite samples (C3: always empty), and then even three launches
+        // that look at its length and leave are ~8 us of a step for nothing.  Whole-chunk redo lists are what the CLR
+        // shortlist produces when it recognises a collapsed map on the device (vsom_shortlist.hip, sl_clr_degenerate): the
+        // passes are enqueued behind CLR searches (8 us of a 5.4 ms step when the list is short) and, for the other
+        // transformations, only when vsom_set_row_dedupe(ctx, 0) asks for them always.  (A hint from the previous search's
+        // feedback words was tried: the host enqueues whole steps ahead of the device, the words are stale when it matters.)
+        dd = false;
     }
     if (dd) {
         if (int rc = launch_bmu_dedupe(c, list ? scount : nullptr, 256u, &nlist, &ncount))

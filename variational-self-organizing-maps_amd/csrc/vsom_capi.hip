@@ -398,7 +398,6 @@ int vsom_set_row_dedupe(vsom_ctx *c, double min_work)
     if (!c)
         return vsom_fail(VSOM_ERR_INVALID, "null context");
     c->dd_min_work = min_work;
-    c->dd_recent = 0;
     return VSOM_OK;
 }
 
