@@ -51,7 +51,7 @@ def main():
     for ln in cpu.stdout.splitlines():
         if ln.startswith("{"):
             d = json.loads(ln)
-            cpu_by[d["scenario"]] = d
+            cpu_by.setdefault(d["scenario"], {}).update(d)
     for ln in gpu.stdout.splitlines():
         if not ln.startswith("{"):
             continue
@@ -62,6 +62,8 @@ def main():
         if c:
             d["cpu_oracle_" + unit] = c["cpu_oracle_" + unit]
             d["mirror_over_cpu_time"] = round(d["mirror_" + unit] / max(c["cpu_oracle_" + unit], 1e-9), 3)
+            if "cpu_oracle_faithful_" + unit in c:
+                d["cpu_oracle_faithful_" + unit] = c["cpu_oracle_faithful_" + unit]
         print(json.dumps(d), flush=True)
 
 

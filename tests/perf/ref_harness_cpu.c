@@ -12,6 +12,7 @@
 #define _POSIX_C_SOURCE 199309L
 #include "../../oracle/vsom_oracle.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -80,6 +81,26 @@ int main(int argc, char **argv)
             else
                 vso_train_online(s, fx, off, 1, 300, 0.001, 0.01, 10.0, 0.01, fns[m], mse);
             line(names[m], 300, now_us() - t0, "us_per_epoch");
+            vso_free(s);
+        }
+        {   /* the batch epochs again in the oracle's `faithful` mode: the reference's per-call temporaries (a heap vector per
+             * Comparer / Stepper call, a neuron copy per distance) -- closer to what libsom itself spends per epoch */
+            vso_som *s = vso_create(10, 10, FJ, VSO_STANDARD);
+            uint64_t lbf[FR];
+            vso_random_initialize(s, 7, 1.f);
+            size_t done = 0;
+            t0 = now_us();
+            for (size_t e = 0; e < 300; ++e) {
+                const double sigma = 10.0 * exp(-0.01 * (double)e);
+                if (sigma < 1.0)
+                    break;
+                memset(lbf, 0, sizeof(lbf));
+                sink += vso_batch_epoch_faithful(s, fx, FR, lbf, sigma, e == 0);
+                ++done;
+            }
+            printf("{\"scenario\": \"%s\", \"calls\": %zu, \"cpu_oracle_faithful_us_per_epoch\": %.3f}\n", names[1], done,
+                   (now_us() - t0) / (double)done);
+            fflush(stdout);
             vso_free(s);
         }
     }
