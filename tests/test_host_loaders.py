@@ -93,6 +93,23 @@ def test_mnist_loader_chunks(exe, tmp_path, chunk):
     assert len(passes) == 2
 
 
+def test_mnist_loader_with_images_that_are_not_28x28(exe, tmp_path):
+    """An IDX pair whose images are 30 x 30: a row holds 900 pixels + 10 label columns but the loader's depth is the
+    reference's fixed 794 names.  The flat path (rows straight into a buffer sized with getDepth()) must not be taken --
+    it would write 910 values per row; load() clips every row to the depth, as loadNextDataFromStream always did."""
+    rs = np.random.RandomState(11)
+    n = 9
+    images = rs.randint(0, 256, size=(n, 30, 30))
+    labels = rs.randint(0, 10, size=n)
+    write_idx(str(tmp_path), images, labels)
+    passes, other = parse(run(exe, "mnist", tmp_path, 4))
+    assert other[0].startswith("DEPTH 794 ")
+    want = np.concatenate([images.reshape(n, 900), np.eye(10)[labels]], axis=1).astype(np.float32)[:, :794]
+    for chunks in passes:
+        got = np.concatenate([c for c in chunks if c.shape[0]], axis=0)
+        assert got.shape == want.shape and (got == want).all()
+
+
 def make_db(path, rows, names):
     con = sqlite3.connect(path)
     con.execute("CREATE TABLE ican (Id INTEGER PRIMARY KEY, %s)" % ", ".join(f"{c} REAL" for c in names))

@@ -499,8 +499,9 @@ extern "C" int vsom_dev_onl_trace(unsigned long long *out)
 #define ONL_STAMP(i) ((void)0)
 #define ONL_TRACE(slot) ((void)0)
 #endif
-constexpr int ONL_USLOTS = 64;                           // min U: 64 line-sized slots per parity (one lane of a wavefront each)
+constexpr int ONL_USLOTS = 32;                           // min U: 32 line-sized slots per parity
 constexpr size_t ONL_U_BYTES = 2 * ONL_USLOTS * 128;
+constexpr int ONL_KSLOTS = 2;                            // exact keys of a refinement: ~40 workgroups have one, two slots do
 constexpr int ONL_REF_NODES = 32;                        // nodes per refinement workgroup (one wavefront per candidate)
 
 struct OnlI8 {
@@ -510,6 +511,7 @@ struct OnlI8 {
     unsigned *uslots;        // [2][ONL_USLOTS][32]
     const float4 *xsc;       // [B] {l1, nx, sx, -}
     int ipitch, ni;          // ni = ipitch / 128: 16-byte pieces per lane
+    int nref;                // refinement workgroups = ceil(N / 32): the layout of lb
     float cT, g2c;           // (2 * 35000 + 256) u ; 1.05 (K / 8 + 16) u
     u64 *stats;              // [0] samples searched, [1] nodes evaluated exactly, [2] refinement workgroups with work
     unsigned char *dirty;    // [N] the node's sigmaMap row is owed
@@ -653,11 +655,26 @@ __global__ __launch_bounds__(256) void onl_prep_kernel(const float *__restrict__
         xsc[s] = make_float4(l1 * 1.0001f, nx, (float)sx, 0.f);   // (a NaN / inf in the row makes l1 / nx non-finite: every interval opens)
 }
 
+// BMU of the sample of parity `par` from the refinement's key slots (whole wavefronts call this)
+__device__ __forceinline__ u64 onl_resolve_i8(const u64 *state, int par)
+{
+    u64 key = state[(par * ONL_SLOTS + ((int)threadIdx.x & (ONL_KSLOTS - 1))) * 16];
+    for (int off = ONL_KSLOTS / 2; off >= 1; off >>= 1) {
+        const u64 o = __shfl_xor(key, off);
+        key = o < key ? o : key;
+    }
+    return state[ONL_FLAG + par] ? 0ull : (key & 0xFFFFFFFFull);
+}
+
+// onl_lb is stored in the REFINEMENT's order: workgroup b of nref owns the nodes b + t nref (t < 32), and its 32 bounds sit
+// side by side (one 128-byte line per workgroup instead of 32 lines 4 nref bytes apart)
+__device__ __forceinline__ int onl_lb_index(int n, int nref) { return (n % nref) * ONL_REF_NODES + n / nref; }
+
 // min U of the sample of parity `par` (whole wavefronts call this: one slot per lane)
 __device__ __forceinline__ float onl_umin(const unsigned *uslots, int par)
 {
-    unsigned k = uslots[(par * ONL_USLOTS + ((int)threadIdx.x & 63)) * 32];
-    for (int off = 32; off > 0; off >>= 1) {
+    unsigned k = uslots[(par * ONL_USLOTS + ((int)threadIdx.x & (ONL_USLOTS - 1))) * 32];
+    for (int off = ONL_USLOTS / 2; off > 0; off >>= 1) {
         const unsigned o = (unsigned)__shfl_xor((int)k, off);
         k = o < k ? o : k;
     }
@@ -706,7 +723,7 @@ __global__ __launch_bounds__(256, PASSES == 1 ? 8 : 1) void onl_fused_kernel(
             const int d = tid + u * 256;
             xn[u] = (f.do_scan && d < D) ? f.xnext[d] : 0.f;
         }
-        const u64 bmu = online_resolve(a.state, a.par);
+        const u64 bmu = onl_resolve_i8(a.state, a.par);
         if (st_)
             ONL_STAMP(9);
         int bx, by;
@@ -799,7 +816,7 @@ __global__ __launch_bounds__(256, PASSES == 1 ? 8 : 1) void onl_fused_kernel(
             const float A = fmaf(-2.f * sn, dot, nm);
             float L, U;
             onl_interval(A, sn, nm, eps, rho, xs, o.cT, o.g2c, L, U);
-            o.lb[n] = L;
+            o.lb[onl_lb_index((int)n, o.nref)] = L;
             if (U < inf)
                 atomicMin(&o.uslots[(parn * ONL_USLOTS + (wb & (ONL_USLOTS - 1))) * 32], onl_fkey(U));
             if (st_)
@@ -828,8 +845,20 @@ __global__ __launch_bounds__(256, PASSES == 1 ? 8 : 1) void onl_fused_kernel(
     const float4 xs = o.xsc[f.jnext];
     u64 startX = 0, startY = 0, endX = 0, endY = 0;       // (no window: empty)
     uint4 pc[8];
-    if (f.do_window) {                                   // nodes of the window are scored by their own workgroups: not even loaded
-        const u64 bmu = online_resolve(a.state, a.par);
+    // The first group's rows are requested BEFORE the window is known (the rows of nodes that turn out to lie in the window
+    // are read for nothing -- a tenth of them at sigma = 8 -- but the scan workgroup is through one round trip earlier and
+    // hands its place to a window workgroup that much sooner); later groups skip the window's nodes.
+    auto issue = [&](int n_, bool live) {
+        const unsigned char *irow = o.img + (size_t)(n_ < a.N ? n_ : a.N - 1) * o.ipitch + 16 * k;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < o.ni)                                // (the last round of a row is ragged: 16-byte pieces past it are not read)
+                pc[i] = (live && 128 * i + 16 * k < o.ipitch) ? *reinterpret_cast<const uint4 *>(irow + 128 * i) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    int node = sb * 32 * PASSES + (tid >> 3);
+    issue(node, node < a.N);
+    if (f.do_window) {                                   // nodes of the window are scored by their own workgroups
+        const u64 bmu = onl_resolve_i8(a.state, a.par);
         int bx, by;
         online_window(bmu, a.W, a.H, sigma, bx, by, startX, startY, endX, endY);
     }
@@ -838,16 +867,6 @@ __global__ __launch_bounds__(256, PASSES == 1 ? 8 : 1) void onl_fused_kernel(
         const unsigned ny_ = (unsigned)nc / mapw, nx_ = (unsigned)nc - ny_ * mapw;
         return nx_ >= wx0 && nx_ < wx1 && ny_ >= wy0 && ny_ < wy1;
     };
-    auto issue = [&](int n_) {
-        const bool live = n_ < a.N && !in_window(n_);
-        const unsigned char *irow = o.img + (size_t)(n_ < a.N ? n_ : a.N - 1) * o.ipitch + 16 * k;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (i < o.ni)                                // (the last round of a row is ragged: 16-byte pieces past it are not read)
-                pc[i] = (live && 128 * i + 16 * k < o.ipitch) ? *reinterpret_cast<const uint4 *>(irow + 128 * i) : make_uint4(0u, 0u, 0u, 0u);
-    };
-    int node = sb * 32 * PASSES + (tid >> 3);
-    issue(node);
     __syncthreads();
     if (st_)
         ONL_STAMP(17);
@@ -874,7 +893,7 @@ __global__ __launch_bounds__(256, PASSES == 1 ? 8 : 1) void onl_fused_kernel(
             }
         }
         if (pass + 1 < PASSES)                           // the next group's rows travel while this one's interval is formed
-            issue(node + 32);
+            issue(node + 32, node + 32 < a.N && !in_window(node + 32));
         float T = t0 + t1;
         T += __shfl_xor(T, 1);
         T += __shfl_xor(T, 2);
@@ -885,7 +904,7 @@ __global__ __launch_bounds__(256, PASSES == 1 ? 8 : 1) void onl_fused_kernel(
         onl_interval(A, nsc.x, nsc.y, nsc.z, nsc.w, xs, o.cT, o.g2c, L, U);
         const bool mine = node < a.N && !in_window(nc);
         if (mine && k == 0)
-            o.lb[node] = L;
+            o.lb[onl_lb_index(node, o.nref)] = L;
         const unsigned uk = (mine && U < inf) ? onl_fkey(U) : 0xFFFFFFFFu;
         ukmin = uk < ukmin ? uk : ukmin;
     }
@@ -975,7 +994,7 @@ __global__ __launch_bounds__(256) void onl_refine_kernel(OnlineArgs a, OnlI8 o, 
         if (a.do_post && tid < 64) {
             if (tid == 0)
                 ONL_STAMP(5);
-            const u64 bmu = online_resolve(a.state, a.par ^ 1);
+            const u64 bmu = onl_resolve_i8(a.state, a.par ^ 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {                // the row of the sample being finished (this wavefront only uses it)
                 const int d = (i * 64 + tid) * 4;
@@ -1019,7 +1038,7 @@ __global__ __launch_bounds__(256) void onl_refine_kernel(OnlineArgs a, OnlI8 o, 
         bool cand = false;
         const int n = (int)blockIdx.x + lane * nref;
         if (lane < ONL_REF_NODES && n < a.N) {
-            const float L = o.lb[n];
+            const float L = o.lb[(int)blockIdx.x * ONL_REF_NODES + lane];
             cand = !(L > umin) || n == 0;                // (node 0 seeds the reference's search, Som.cpp:293-299)
         }
         const u64 bm = __ballot(cand);
@@ -1059,7 +1078,7 @@ __global__ __launch_bounds__(256) void onl_refine_kernel(OnlineArgs a, OnlI8 o, 
         for (int i = 1; i < 4; ++i)
             m = skey[i] < m ? skey[i] : m;
         if (m != ~0ull)
-            atomicMin(online_slot(a.state, a.par, (int)(blockIdx.x % ONL_SLOTS)), m);
+            atomicMin(online_slot(a.state, a.par, (int)(blockIdx.x % ONL_KSLOTS)), m);
         if (blockIdx.x == 0)
             ONL_STAMP(4);
     }
@@ -1367,7 +1386,7 @@ static int onl_i8_ensure(vsom_ctx *c, OnlI8 *o)
     if (!c->onl_img) {
         VSOM_HIP_CHECK(hipMalloc(&c->onl_img, (size_t)c->N * ipitch));
         VSOM_HIP_CHECK(hipMalloc(&c->onl_nsc, (size_t)c->N * sizeof(float4)));
-        VSOM_HIP_CHECK(hipMalloc(&c->onl_lb, (size_t)c->N * sizeof(float)));
+        VSOM_HIP_CHECK(hipMalloc(&c->onl_lb, (((size_t)c->N + ONL_REF_NODES - 1) / ONL_REF_NODES) * ONL_REF_NODES * sizeof(float)));
         VSOM_HIP_CHECK(hipMalloc(&c->onl_u, ONL_U_BYTES + 64));
         VSOM_HIP_CHECK(hipMemsetAsync((char *)c->onl_u + ONL_U_BYTES, 0, 64, c->stream));
         VSOM_HIP_CHECK(hipMalloc(&c->onl_dirty, (size_t)c->N));
@@ -1392,6 +1411,7 @@ static int onl_i8_ensure(vsom_ctx *c, OnlI8 *o)
     o->dirty = c->onl_dirty;
     o->ipitch = (int)ipitch;
     o->ni = (int)((ipitch + 127) / 128);
+    o->nref = (int)((c->N + ONL_REF_NODES - 1) / ONL_REF_NODES);
     o->cT = (float)((2.0 * 35000.0 + 256.0) * u);
     o->g2c = (float)(1.05 * ((double)c->part_len / 8.0 + 16.0) * u);
     return VSOM_OK;

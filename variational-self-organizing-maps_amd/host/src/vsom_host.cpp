@@ -340,11 +340,13 @@ Eigen::VectorXf DataSet::getData(size_t i) const
 const Eigen::VectorXi DataSet::getValidity(size_t i) const
 {
     ensureRows();
-    Eigen::VectorXi v = Eigen::VectorXi::Zero((Eigen::Index)_loader.getDepth());
-    if (n > i && valid.size() > i)
+    if (n > i && valid.size() > i) {      // a view of the row's own flags, whatever their count (DataSet.cpp:44-45): a loader may
+        Eigen::VectorXi v((Eigen::Index)valid[i].size());   // hand over rows longer than its depth (IDX images that are not 28 x 28)
         for (size_t d = 0; d < valid[i].size(); ++d)
             v[(Eigen::Index)d] = valid[i][d];
-    return v;
+        return v;
+    }
+    return Eigen::VectorXi::Zero((Eigen::Index)_loader.getDepth());
 }
 
 static Eigen::ArrayXi to_arrayxi(const std::vector<int> &src)
