@@ -88,6 +88,21 @@ def test_random_shape(name, tr, W, H, J, B, sigma, seed):
         st = ctx.get_state()
         for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("S", orc.S), ("weight", orc.weight), ("hits", orc.hits)):
             assert _same(st[k], ref), (name, sg, "online " + k)
+    # and the same chunk once more through the image-bounded search of the chunk loop (csrc/vsom_online.hip; forced: these
+    # maps are far below the size VSOM_BMU_AUTO takes it for): random shapes, scales 0.1 / 1 / 50, exact zeros
+    if tr != capi.CLR and D <= 1024:
+        ctx.set_bmu_mode(capi.BMU_SHORTLIST)
+        sg = max(sigma, 1.2)
+        lb = np.zeros(nb, np.uint64)
+        mse_o = orc.train_online_chunk(X[:nb], lb, 0.05, sg, capi.EXPONENTIAL)
+        ctx.upload_chunk(X[:nb])
+        mse_g = ctx.train_online_chunk(0.05, sg, capi.EXPONENTIAL)
+        assert ctx.online_search_stats(reset=True)["samples"] == nb, name
+        assert _same(ctx.get_last_bmu(), lb), (name, sg, "image-bounded online lastBMU")
+        assert _same(np.float32(mse_g), np.float32(mse_o)), (name, sg, "image-bounded online mse")
+        st = ctx.get_state()
+        for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("S", orc.S), ("weight", orc.weight), ("hits", orc.hits)):
+            assert _same(st[k], ref), (name, sg, "image-bounded online " + k)
     ctx.close()
 
 
