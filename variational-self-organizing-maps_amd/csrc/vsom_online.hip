@@ -1833,16 +1833,16 @@ int vsom_train_single(vsom_ctx *c, const float *v_host, double eta, double sigma
     rc = ensure_lutd(c, sigma, &lutd, &lutw);
     if (rc)
         return rc;
-    float *xs = c->v_dev, *xp = c->v_dev + xs_n, *yp = xp + pp, *res = yp + pp, *tail = res + pp;
+    // The sample's rows are copied into HBM (thousands of wavefronts read them); lastBMU in, residual + {bmu, distance, mse}
+    // out go straight through the pinned buffer, which the device addresses: written / read by single wavefronts of the
+    // step's kernels -- one copy and one synchronisation per call (three copies before: 36 us per call)
+    float *xs = c->v_dev, *xp = c->v_dev + xs_n, *yp = xp + pp;
+    float *res = c->v_pinned + xs_n + 2 * pp, *tail = res + pp;
     u64 *lb = reinterpret_cast<u64 *>(tail);
-    // inputs and outputs travel through the pinned buffer: rows (stage_single), a 16-byte tail in,
-    // residual + tail out -- three small asynchronous copies and one synchronisation per call
-    float *ptail_in = c->v_pinned + xs_n + 3 * pp + 16;      // host image of the tail going in
-    float *pout = c->v_pinned + xs_n + 2 * pp;               // host image of [residual | tail] coming out
-    std::memcpy(ptail_in, last_bmu, 8);
-    ptail_in[2] = 0.f;
-    ptail_in[3] = 0.f;
-    VSOM_HIP_CHECK(hipMemcpyAsync(tail, ptail_in, 16, hipMemcpyHostToDevice, c->stream));
+    float *pout = res;
+    std::memcpy(tail, last_bmu, 8);
+    tail[2] = 0.f;
+    tail[3] = 0.f;
     {
         TimerScope ts(c, VSOM_T_ONLINE);
         hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f, 1);
@@ -1851,7 +1851,6 @@ int vsom_train_single(vsom_ctx *c, const float *v_host, double eta, double sigma
             return rc;
         VSOM_HIP_CHECK(hipGetLastError());
     }
-    VSOM_HIP_CHECK(hipMemcpyAsync(pout, res, (pp + 4) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
     uint64_t bmu = 0;
     std::memcpy(&bmu, pout + pp, 8);
