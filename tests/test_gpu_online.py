@@ -262,6 +262,52 @@ def test_online_chunk_with_nan_rows_and_duplicates():
         ctx.close()
 
 
+@pytest.mark.parametrize("tr", [po.STANDARD, po.MEDIAN])
+def test_tiny_map_chunk_in_one_launch_with_nan_rows_and_duplicates(tr):
+    """Maps of at most 4096 values train a whole chunk in ONE single-workgroup launch (online_tiny_chunk_kernel: model
+    values in registers, three barriers per sample, four when sigma <= 1 walks from the sample's last BMU).  The argmin rules on it: NaN rows never win, equal rows resolve to the
+    lowest index, a NaN at node 0 pins every BMU to node 0 (Som.cpp:293-304); depths with every remainder class of Eigen's
+    reduction; chunks continued with the running MSE; the per-sample forms (fp32 scan, image-bounded search) beside it."""
+    for W, H, J, B in ((12, 10, 9, 61), (16, 16, 13, 40), (31, 33, 4, 50), (8, 8, 24, 33), (20, 10, 20, 17)):
+        X = gen.blobs(B, J, 5, 1, 2, sigma=0.4)
+        init = gen.random_map(W * H, J, seed=21)
+        init[50:60] = init[10:20]                # duplicates at higher indices
+        init[7, J // 2] = np.nan
+        init[33:60:9] = np.nan
+        for nan0 in (False, True):
+            m = init.copy()
+            if nan0:
+                m[0, 1] = np.nan
+            # VSOM_BMU_AUTO: the one-launch chunk; EXACT / SHORTLIST: the per-sample kernels (fp32 scan / image-bounded search)
+            for mode in (capi.BMU_AUTO, capi.BMU_EXACT, capi.BMU_SHORTLIST):
+                o = po.OracleSom(W, H, J, tr)
+                o.set_state(map=m)
+                ctx = vsom_amd.Context(W, H, J, tr)
+                ctx.set_bmu_mode(mode)
+                ctx.set_state(map=m)
+                run_o = np.float32(0)
+                # three chunks of full searches, then three of local walks (sigma <= 1, Som.cpp:891) that start from the BMUs
+                # the chunk before left in lastBMU; the last one's window is empty (2.5 sigma < 1)
+                sched = ((capi.EXPONENTIAL, 2.2), (capi.INVERSE_PROPORTIONAL, 6.0), (capi.EXPONENTIAL, 1.3),
+                         (capi.EXPONENTIAL, 1.0), (capi.INVERSE_PROPORTIONAL, 0.8), (capi.EXPONENTIAL, 0.3))
+                lb = np.zeros(B, np.uint64)
+                for ci, (fn, sigma) in enumerate(sched):
+                    lb = lb.copy() if sigma <= 1 else np.zeros(B, np.uint64)
+                    start = lb.copy()
+                    run_o = o.train_online_chunk(X, lb, 0.05, sigma, fn, mse_start=0.0 if ci == 0 else float(run_o))
+                    ctx.upload_chunk(X)
+                    ctx.set_last_bmu(start)
+                    run_g = ctx.train_online_chunk(0.05, sigma, fn, first_chunk=(ci == 0))
+                    assert beq(ctx.get_last_bmu(), lb), (W, H, J, nan0, mode, ci)
+                    if sigma > 1:
+                        assert nan0 == bool((lb == 0).all())
+                    st = ctx.get_state()
+                    for k in ("map", "S", "sigma", "weight", "hits"):
+                        assert beq(st[k], getattr(o, k)), (W, H, J, nan0, mode, ci, k)
+                    assert beq(np.float32(run_g), np.float32(run_o)), (W, H, J, nan0, mode, ci)
+                ctx.close()
+
+
 @pytest.mark.parametrize("tr,fn,sigma", [(0, 0, 3.0), (1, 1, 2.0), (2, 0, 1.5), (0, 1, 1.0)])
 def test_train_single_api(tr, fn, sigma):
     W, H, J = 11, 9, 6

@@ -93,7 +93,7 @@ struct vsom_ctx {
     const float *next_dev = nullptr;   // vsom_stage_next_device: rows in HBM waiting for vsom_commit_chunk
     size_t next_dev_B = 0;
     bool next_dev_pending = false;
-    float *mse = nullptr;           // [1]
+    float *mse = nullptr;           // [1]  pinned HOST memory (device-visible): kernels store, vsom_get_mse reads after a stream wait
     int *pair_i = nullptr, *pair_j = nullptr;   // CLR pair tables [P]
 
     // BMU tile-search scratch
@@ -104,6 +104,7 @@ struct vsom_ctx {
     void *dd_hash = nullptr; int *dd_rep = nullptr, *dd_list = nullptr;
     bool dedupe = true;             // VSOM_NO_DEDUPE=1 switches it off (A/B measurements)
     double dd_min_work = 2.0e10;    // exact searches of at least this many (sample, node, value) triples (vsom_set_row_dedupe)
+    bool tiny_lds_attr = false;     // online_tiny_chunk_kernel's dynamic LDS limit raised on this context's device
 
     // MFMA shortlist scratch
     float *sl_G = nullptr; size_t sl_cap = 0; float *sl_nrm = nullptr; unsigned *sl_scal = nullptr;
@@ -171,6 +172,7 @@ struct vsom_ctx {
 
     // pinned staging of vsom_set_state's host arrays
     void *st_pinned = nullptr; size_t st_pinned_cap = 0;
+    void *out_pinned = nullptr;     // [8192] u64: vsom_get_last_bmu of short chunks
     // device scratch of the distance queries (vsom_distances / _row / _raw): grow-only
     void *q_scratch = nullptr; size_t q_scratch_cap = 0;
 

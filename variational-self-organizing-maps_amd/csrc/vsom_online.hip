@@ -1299,6 +1299,413 @@ static int stage_single(vsom_ctx *c, const float *v_host, bool copy = true)
     return VSOM_OK;
 }
 
+// =====================================================================================================================
+// Tiny maps: the whole chunk loop of Som::trainBasicSom (Som.cpp:1159-1171) in ONE launch of ONE workgroup.
+//
+// The reference's own performance scenario trains a 10 x 10 map on 20 nine-dimensional rows (tests/performance/
+// perf_tests.cpp:74-112): two dependent launches per sample were 220-260 us per epoch there against 50 us of one CPU thread.
+// For maps of at most 4096 values (N D) and 1024 nodes, Standard / Median, sigma > 1: every thread owns up to four model
+// values (M, S) IN REGISTERS for the whole chunk, plus a copy of its node's weight -- the window update of Som.cpp:911-943 is
+// elementwise, so nothing of it crosses threads -- and per sample the workgroup meets at four barriers:
+//   A  squares p = fl(fl(m - x)^2) of every value into LDS
+//   B  one thread per node adds its row's squares in Eigen's order (the eight accumulator classes, the tree, the tail:
+//      vsom_group_dist's arithmetic) and folds the (distance, index) key into an LDS atomic minimum
+//   C  every thread reads the BMU, applies online_window / the neighbourhood table and updates its values with
+//      online_node_update's operations (same expressions, same order: same bits)
+//   D  the BMU's threads publish their new squares; thread 0 adds them (the distance after the update, :946), the MSE
+//      running sum (:1167), addBmu, lastBMU
+// sigmaMap is written once at the end, from the final S and weight, for the nodes some window touched (the value of the
+// node's last update: onl_sigma_kernel's argument).  Results are bit-identical to the per-sample kernels and the oracle.
+struct OnlTinyArgs {
+    const float *X;          // staged rows
+    int ldx, B, N, W, H, D, pitch;
+    float *map, *Smap, *sigmap, *weight;
+    u64 *hits, *lastbmu;
+    float *fstate;           // [0] distance of the last sample's BMU, [1] MSE running sum (in/out)
+    const double *lutd;
+    int lutw;
+    double eta, sigma;
+    int decay_fn;
+    float fB;
+    int keep_mse;            // 0: first chunk of an epoch, the running MSE starts at 0 (online_init_kernel's argument)
+    float *mse_out;          // vsom_get_mse's value
+};
+
+constexpr int TINY_XBLOCK = 2048;      // values of staged rows held in LDS at a time (TINY_XBLOCK / D samples)
+
+// minimum of a u64 over the wavefront, in lane 63: four row shifts, two row broadcasts (DPP moves of both halves; the
+// cross-lane LDS permutes of a shuffle ladder were a third of a tiny-map sample)
+__device__ __forceinline__ u64 onl_wave_min_u64(u64 v)
+{
+#define ONL_DPP_STEP(CTRL, ROWS)                                                                                         \
+    {                                                                                                                    \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)v, CTRL, ROWS, 0xF, false);         \
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)(unsigned)(v >> 32), CTRL, ROWS, 0xF, false); \
+        const u64 o = (u64)hi << 32 | lo;                                                                                \
+        v = o < v ? o : v;                                                                                               \
+    }
+    ONL_DPP_STEP(0x111, 0xF)   // row_shr:1
+    ONL_DPP_STEP(0x112, 0xF)   // row_shr:2
+    ONL_DPP_STEP(0x114, 0xF)   // row_shr:4
+    ONL_DPP_STEP(0x118, 0xF)   // row_shr:8   (lane 15 of every row: the row's minimum)
+    ONL_DPP_STEP(0x142, 0xA)   // row_bcast:15 into rows 1 and 3
+    ONL_DPP_STEP(0x143, 0xC)   // row_bcast:31 into rows 2 and 3
+#undef ONL_DPP_STEP
+    return v;
+}
+
+struct OnlTinyNode {           // what a thread needs to know about the sample's BMU: its coordinates and window (Som.cpp:899-907)
+    unsigned short bx, by, startX, endX, startY, endY, pad0, pad1;
+};
+
+// Som::findLocalBmu (Som.cpp:335-454) over a table of the sample's distances to every node, by one thread: vsom_local_walk's
+// steps and comparisons in its order (the 8 neighbours of the first try, then 3 nodes ahead while moving in X; the size_t
+// wrap-then-clamp of :362-385 in 32 bits -- a wrapped coordinate is far above width - 1 either way)
+__device__ __forceinline__ int onl_tiny_walk(const float *s_d, const OnlTinyNode *s_win, unsigned W, unsigned H, unsigned start)
+{
+    unsigned lastBMU = start, minIndex = start, lastMeasured = start;
+    float minDist = s_d[start];
+    for (;;) {
+        const unsigned lmX = s_win[lastMeasured].bx, lmY = s_win[lastMeasured].by, lbX = s_win[lastBMU].bx;
+        if (lastMeasured == lastBMU) {
+            for (int g = 0; g < 8; ++g) {
+                const unsigned fsx = (g == 0 || g >= 6) ? ~0u : ((g == 1 || g == 5) ? 0u : 1u);   // firstSearchX / Y (:341-342)
+                const unsigned fsy = g <= 2 ? 1u : ((g == 3 || g == 7) ? 0u : ~0u);
+                unsigned cx = lmX + fsx, cy = lmY + fsy;
+                cx = cx < W - 1 ? cx : W - 1;
+                cy = cy < H - 1 ? cy : H - 1;
+                const unsigned node = cy * W + cx;
+                const float di = s_d[node];
+                if (di < minDist) {
+                    minDist = di;
+                    minIndex = node;
+                }
+            }
+            if (minIndex == lastBMU)
+                break;
+            lastMeasured = minIndex;
+        } else {
+            if (lmX - lbX) {                                     // moving in X: 3 nodes ahead (:390-403)
+                unsigned cx = lmX + lmX - lbX;
+                cx = cx < W - 1 ? cx : W - 1;
+                for (int i = 0; i < 3; ++i) {
+                    unsigned cy = lmY + (unsigned)(i - 1);
+                    cy = cy < H - 1 ? cy : H - 1;
+                    const unsigned node = cy * W + cx;
+                    const float di = s_d[node];
+                    if (di < minDist) {
+                        minDist = di;
+                        minIndex = node;
+                    }
+                }
+            }
+            // (moving in Y evaluates nothing: :406-437, vsom_local_walk)
+            if (minIndex == lastMeasured)
+                break;
+            lastBMU = lastMeasured;
+            lastMeasured = minIndex;
+        }
+    }
+    return (int)minIndex;
+}
+
+template <int KIND, bool LOCAL>
+__global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char tiny_onl_smem[];
+    const int N = a.N, D = a.D, ND = N * D, tid = threadIdx.x, Dp = D | 1;      // (odd row pitch: phase B's rows hit distinct banks)
+    // LDS: per-BMU window table, the neighbourhood table (double for :933's division; its two float images for :924-925),
+    // the squares, a block of staged rows, the chunk's addBmu counts and lastBMU
+    OnlTinyNode *s_win = reinterpret_cast<OnlTinyNode *>(tiny_onl_smem);        // [N]
+    double *s_lut = reinterpret_cast<double *>(s_win + N);                      // [W * H]
+    float2 *s_lf = reinterpret_cast<float2 *>(s_lut + N);                       // [W * H]  {(float)(h eta), (float)h}
+    float *s_p = reinterpret_cast<float *>(s_lf + N);                           // [N Dp] squares of the sample against every node
+    float *s_p2 = s_p + N * Dp;                                                 // [2][D]  squares of the BMU's row after its update
+    float *s_x = s_p2 + 2 * ((D + 3) & ~3);                                     // [TINY_XBLOCK] staged rows of this block
+    unsigned *s_hits = reinterpret_cast<unsigned *>(s_x + TINY_XBLOCK);         // [N]  addBmu counts of this chunk
+    float *s_d = reinterpret_cast<float *>(s_hits + N);                         // [N]  LOCAL: the sample's distances
+    unsigned short *s_last = reinterpret_cast<unsigned short *>(s_d + N);       // [B]  lastBMU of every sample (a global store
+                                                                                //      per sample made its wavefront wait for it)
+    __shared__ u64 s_key[2];
+    if (LOCAL)                                               // findLocalBmu starts from the sample's BMU of the last epoch (:891)
+        for (int i = tid; i < a.B; i += 1024)
+            s_last[i] = (unsigned short)a.lastbmu[i];
+    for (int i = tid; i < N; i += 1024) {
+        const double h = a.lutd[(size_t)(i / a.W) * a.lutw + (i % a.W)];
+        s_lut[i] = h;
+        s_lf[i] = make_float2((float)(h * a.eta), (float)h);
+        s_hits[i] = 0u;
+        int bx, by;
+        u64 startX, startY, endX, endY;
+        online_window((u64)i, a.W, a.H, a.sigma, bx, by, startX, startY, endX, endY);   // (ends <= W, H <= 1024)
+        OnlTinyNode t;
+        t.bx = (unsigned short)bx;
+        t.by = (unsigned short)by;
+        t.startX = (unsigned short)startX;
+        t.endX = (unsigned short)endX;
+        t.startY = (unsigned short)startY;
+        t.endY = (unsigned short)endY;
+        t.pad0 = t.pad1 = 0;
+        s_win[i] = t;
+    }
+    // this thread's values: flattened (node, dim) indices tid + 1024 u
+    float m[4], sv[4], w[4];
+    int node[4], dim[4], nx[4], ny[4];
+    bool own[4], touched[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + 1024 * u;
+        own[u] = e < ND;
+        node[u] = own[u] ? e / D : 0;
+        dim[u] = own[u] ? e - node[u] * D : 0;
+        nx[u] = node[u] % a.W;
+        ny[u] = node[u] / a.W;
+        m[u] = own[u] ? a.map[(size_t)node[u] * a.pitch + dim[u]] : 0.f;
+        sv[u] = own[u] ? a.Smap[(size_t)node[u] * a.pitch + dim[u]] : 0.f;
+        w[u] = own[u] ? a.weight[node[u]] : 0.f;
+        touched[u] = false;
+    }
+    float mse = a.keep_mse ? a.fstate[1] : 0.f, lastdist = 0.f;
+    if (tid < 2)
+        s_key[tid] = ~0ull;
+    const int L8 = D & ~7, rem = D - L8, KB = TINY_XBLOCK / D;
+    const bool exp_decay = a.decay_fn == VSOM_EXPONENTIAL;
+    for (int j0 = 0; j0 < a.B; j0 += KB) {
+        const int kb = min(KB, a.B - j0);
+        __syncthreads();                                     // (the previous block's rows are no longer read; first: the tables)
+        for (int i = tid; i < kb * D; i += 1024)
+            s_x[i] = a.X[(size_t)(j0 + i / D) * a.ldx + (i % D)];
+        __syncthreads();
+        for (int jj = 0; jj < kb; ++jj) {
+            const int j = j0 + jj, par = j & 1;
+            float x[4];
+            // A: squares
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (own[u]) {
+                    x[u] = s_x[jj * D + dim[u]];
+                    const float r = m[u] - x[u];
+                    s_p[node[u] * Dp + dim[u]] = r * r;
+                }
+            __syncthreads();
+            // B: distances in Eigen's order, argmin with the reference's rules (strict <, lowest index, NaN never wins,
+            //    a NaN at node 0 pins the BMU: Som.cpp:293-304 -- key 0 is below every other key and names node 0)
+            if (tid < ((N + 63) & ~63)) {                        // whole wavefronts
+                u64 mykey = ~0ull;
+                if (tid < N) {
+                    const float *p = s_p + tid * Dp;
+                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int d = 0; d < L8; d += 8) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            acc[k] = acc[k] + p[d + k];
+                    }
+                    float q0 = acc[0] + acc[4], q1 = acc[1] + acc[5], q2 = acc[2] + acc[6], q3 = acc[3] + acc[7];
+                    int t = 0;
+                    if (rem >= 4) {
+                        q0 = q0 + p[L8];
+                        q1 = q1 + p[L8 + 1];
+                        q2 = q2 + p[L8 + 2];
+                        q3 = q3 + p[L8 + 3];
+                        t = 4;
+                    }
+                    const float t02 = q0 + q2, t13 = q1 + q3;
+                    float res = t02 + t13;
+                    for (; t < rem; ++t)
+                        res = res + p[L8 + t];
+                    mykey = (tid == 0 && res != res) ? 0ull : vsom_key(res, (uint32_t)tid);
+                    if (LOCAL)
+                        s_d[tid] = res;
+                }
+                if (!LOCAL) {
+                    mykey = onl_wave_min_u64(mykey);             // one LDS atomic per wavefront (N same-address atomics
+                    if ((tid & 63) == 63)                        // serialise: 100 of them were 2 us of a sample)
+                        atomicMin(&s_key[par], mykey);
+                }
+            }
+            __syncthreads();
+            if (LOCAL) {                                         // sigma <= 1: the walk from the sample's last BMU (Som.cpp:891)
+                if (tid == 1023)
+                    s_key[par] = (u64)onl_tiny_walk(s_d, s_win, (unsigned)a.W, (unsigned)a.H, (unsigned)s_last[j]);
+                __syncthreads();
+            }
+            const int bmu = (int)(s_key[par] & 0xFFFFFFFFull);
+            // C: the window of Som.cpp:899-944 around the BMU (online_window's bounds, from the table)
+            const OnlTinyNode bn = s_win[bmu];
+            const int bx = bn.bx, by = bn.by;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!own[u])
+                    continue;
+                if (nx[u] < (int)bn.startX || nx[u] >= (int)bn.endX || ny[u] < (int)bn.startY || ny[u] >= (int)bn.endY)
+                    continue;
+                int dx = nx[u] - bx, dy = ny[u] - by;
+                dx = dx < 0 ? -dx : dx;
+                dy = dy < 0 ? -dy : dy;
+                const int at = dy * a.W + dx;                    // calculateNeighbourhoodWeight(i,j,bx,by,sigma) :915
+                const float wold = w[u];
+                const float2 lf = s_lf[at];
+                const float hf = lf.y;
+                float wnew, scM;
+                if (exp_decay) {
+                    scM = lf.x;                                  // (float)(h eta) :925
+                    wnew = wold + scM;                           // :924
+                } else {
+                    wnew = wold + hf;                            // :930
+                    const double tw = wnew == 0 ? 1.0 : s_lut[at] / (double)wnew;   // :933
+                    scM = (float)tw;
+                }
+                float dl = x[u] - m[u];                          // Stepper :912
+                if (KIND == VSOM_MEDIAN)
+                    dl = onl_sign(dl);
+                const float tt = scM * dl;
+                const float mn = m[u] + tt;                      // :925 / :935
+                float dl2 = x[u] - mn;                           // Stepper(v, map_new) :941
+                if (KIND == VSOM_MEDIAN)
+                    dl2 = onl_sign(dl2);
+                const float pr = dl * dl2;
+                const float uu = hf * pr;
+                sv[u] = sv[u] + uu;                              // :941
+                m[u] = mn;
+                w[u] = wnew;
+                touched[u] = true;
+            }
+            // D: distance of the BMU after the update (:946), MSE (:1167), addBmu (:1165), lastBMU (:895)
+            float *p2 = s_p2 + par * ((D + 3) & ~3);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (own[u] && node[u] == bmu) {
+                    const float r = m[u] - x[u];
+                    p2[dim[u]] = r * r;
+                }
+            __syncthreads();
+            // (the last thread -- its wavefront has the least to do in A and B -- works on this parity's squares and key while
+            //  the others go on to the next sample, whose phases use the other parity; it re-arms this parity for sample j + 2,
+            //  which nobody touches before two more barriers)
+            if (tid == 1023) {
+                const float *p = p2;
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int d = 0; d < L8; d += 8) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        acc[k] = acc[k] + p[d + k];
+                }
+                float q0 = acc[0] + acc[4], q1 = acc[1] + acc[5], q2 = acc[2] + acc[6], q3 = acc[3] + acc[7];
+                int t = 0;
+                if (rem >= 4) {
+                    q0 = q0 + p[L8];
+                    q1 = q1 + p[L8 + 1];
+                    q2 = q2 + p[L8 + 2];
+                    q3 = q3 + p[L8 + 3];
+                    t = 4;
+                }
+                const float t02 = q0 + q2, t13 = q1 + q3;
+                float res = t02 + t13;
+                for (; t < rem; ++t)
+                    res = res + p[L8 + t];
+                lastdist = res;
+                const float q = res / a.fB;                      // residual.squaredNorm() / epochSize  (:1167)
+                mse = mse + q;
+                s_hits[bmu] += 1u;
+                s_last[j] = (unsigned short)bmu;
+                s_key[par] = ~0ull;
+            }
+        }
+    }
+    __syncthreads();
+    // state back: M and S of every value, weight by the node's first value, sigmaMap = sqrt(|S / w|) (:939-942) where a
+    // window touched the node during this chunk
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (!own[u])
+            continue;
+        const size_t at = (size_t)node[u] * a.pitch + dim[u];
+        a.map[at] = m[u];
+        a.Smap[at] = sv[u];
+        if (touched[u]) {
+            const double tw2 = w[u] == 0 ? 0.000001 : (double)w[u];   // :939
+            const float twf = (float)tw2;
+            a.sigmap[at] = sqrtf(fabsf(sv[u] / twf));                 // :942
+        }
+        if (dim[u] == 0)
+            a.weight[node[u]] = w[u];
+    }
+    for (int i = tid; i < N; i += 1024)
+        if (s_hits[i])
+            a.hits[i] += (u64)s_hits[i];
+    for (int i = tid; i < a.B; i += 1024)
+        a.lastbmu[i] = (u64)s_last[i];
+    if (tid == 1023) {
+        a.fstate[0] = lastdist;
+        a.fstate[1] = mse;
+        *a.mse_out = mse;
+    }
+}
+
+static size_t online_tiny_lds_bytes(const vsom_ctx *c)
+{
+    const size_t N = c->N, D = c->part_len;
+    return N * (16 + 8 + 8) + (N * (D | 1) + 2 * ((D + 3) & ~(size_t)3) + TINY_XBLOCK) * sizeof(float) + N * 8 +
+           (c->B + 8) * sizeof(unsigned short);
+}
+
+static bool online_tiny_applies(const vsom_ctx *c, double sigma)
+{
+    return c->use_tiny && c->transform != VSOM_CLR && sigma == sigma && c->B > 0 && c->N <= 1024 &&
+           (size_t)c->N * c->part_len <= 4096 && c->part_len <= 512 && c->B <= 4096 && c->bmu_mode == VSOM_BMU_AUTO;   // (EXACT / SHORTLIST name the per-sample forms)
+}
+
+static int enqueue_chunk_tiny(vsom_ctx *c, double eta, double sigma, int decay_fn, const double *lutd, int lutw, int first_chunk)
+{
+    OnlTinyArgs a;
+    a.X = c->Xs;
+    a.ldx = (int)c->xpitch;
+    a.B = (int)c->B;
+    a.N = (int)c->N;
+    a.W = (int)c->W;
+    a.H = (int)c->H;
+    a.D = (int)c->part_len;
+    a.pitch = (int)c->pitch;
+    a.map = c->map;
+    a.Smap = c->S;
+    a.sigmap = c->sigma;
+    a.weight = c->weight;
+    a.hits = c->hits;
+    a.lastbmu = c->lastbmu;
+    a.fstate = c->onl_f;
+    a.lutd = lutd;
+    a.lutw = lutw;
+    a.eta = eta;
+    a.sigma = sigma;
+    a.decay_fn = decay_fn;
+    a.fB = (float)c->B;
+    a.keep_mse = first_chunk ? 0 : 1;
+    a.mse_out = c->mse;
+    const size_t smem = online_tiny_lds_bytes(c);
+    const bool local = !(sigma > 1);                  // SIGMA_SWITCH_TO_LOCAL (SOM.hpp:37, Som.cpp:891)
+    if (!c->tiny_lds_attr) {                          // (more than the 64 KiB a launch may ask for by default; 160 KiB per CU)
+        const void *fns[4] = {reinterpret_cast<const void *>(online_tiny_chunk_kernel<VSOM_MEDIAN, false>),
+                              reinterpret_cast<const void *>(online_tiny_chunk_kernel<VSOM_MEDIAN, true>),
+                              reinterpret_cast<const void *>(online_tiny_chunk_kernel<VSOM_STANDARD, false>),
+                              reinterpret_cast<const void *>(online_tiny_chunk_kernel<VSOM_STANDARD, true>)};
+        for (const void *fn : fns)
+            VSOM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10));
+        c->tiny_lds_attr = true;
+    }
+    if (c->transform == VSOM_MEDIAN) {
+        if (local)
+            hipLaunchKernelGGL((online_tiny_chunk_kernel<VSOM_MEDIAN, true>), dim3(1), dim3(1024), smem, c->stream, a);
+        else
+            hipLaunchKernelGGL((online_tiny_chunk_kernel<VSOM_MEDIAN, false>), dim3(1), dim3(1024), smem, c->stream, a);
+    } else {
+        if (local)
+            hipLaunchKernelGGL((online_tiny_chunk_kernel<VSOM_STANDARD, true>), dim3(1), dim3(1024), smem, c->stream, a);
+        else
+            hipLaunchKernelGGL((online_tiny_chunk_kernel<VSOM_STANDARD, false>), dim3(1), dim3(1024), smem, c->stream, a);
+    }
+    return VSOM_OK;
+}
+
 // ---- single-vector queries (Som::euclidianWeightedDist / Som::findLocalBmu of ONE host vector) ----------------------
 // one wavefront; results into the 16-byte tail behind the single-sample rows: {u64 index, float distance}
 template <bool CLR>
@@ -1751,11 +2158,17 @@ int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay
     int rc = ensure_lutd(c, sigma, &lutd, &lutw);
     if (rc)
         return rc;
+    bool tiny = false;
     {
         TimerScope ts(c, VSOM_T_ONLINE);
-        hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f,
-                           first_chunk ? 0 : 1);
-        if (onl_i8_applies(c, sigma)) {
+        tiny = online_tiny_applies(c, sigma);
+        if (!tiny)                            // (the one-launch chunk starts the running MSE itself and uses no key slots)
+            hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f,
+                               first_chunk ? 0 : 1);
+        if (tiny) {
+            if ((rc = enqueue_chunk_tiny(c, eta, sigma, decay_fn, lutd, lutw, first_chunk)))
+                return rc;
+        } else if (onl_i8_applies(c, sigma)) {
             if ((rc = enqueue_chunk_i8(c, eta, sigma, decay_fn, lutd, lutw)))
                 return rc;
         } else {
@@ -1781,7 +2194,8 @@ int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay
         VSOM_HIP_CHECK(hipGetLastError());
     }
     // vsom_get_mse reports the chunk's MSE for callers that passed mse_out = NULL (asynchronous use)
-    VSOM_HIP_CHECK(hipMemcpyAsync(c->mse, c->onl_f + 1, 4, hipMemcpyDeviceToDevice, c->stream));
+    if (!tiny)
+        VSOM_HIP_CHECK(hipMemcpyAsync(c->mse, c->onl_f + 1, 4, hipMemcpyDefault, c->stream));   // (c->mse: pinned host memory)
     if (mse_out) {
         VSOM_HIP_CHECK(hipMemcpyAsync(mse_out, c->onl_f + 1, 4, hipMemcpyDeviceToHost, c->stream));
         VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
