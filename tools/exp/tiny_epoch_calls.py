@@ -19,9 +19,10 @@ lb = np.zeros(B, np.uint64)
 lbp = lb.ctypes.data_as(C.POINTER(C.c_uint64))
 mse = C.c_float()
 names = ("prefetch_chunk", "commit_chunk", "train_online_chunk_acc", "get_last_bmu", "get_mse")
-for sigma in (8.0, 1.0):
+for sigma0 in (8.0, 1.0, -8.0):          # negative: a new sigma every epoch, as the schedule of Som.cpp:1146 has it
     tot = np.zeros(5)
     for e in range(330):
+        sigma = sigma0 if sigma0 > 0 else -sigma0 - 0.001 * e
         t = [time.perf_counter()]
         assert L.vsom_prefetch_chunk(h, fp, C.c_size_t(B)) == 0; t.append(time.perf_counter())
         assert L.vsom_commit_chunk(h) == 0; t.append(time.perf_counter())
@@ -31,5 +32,5 @@ for sigma in (8.0, 1.0):
         if e >= 30:
             tot += np.diff(t)
     tot *= 1e6 / 300
-    print(f"sigma {sigma}: " + ", ".join(f"{n} {v:.1f}" for n, v in zip(names, tot)) + f"  | sum {tot.sum():.1f} us per epoch", flush=True)
+    print(f"sigma {sigma0}: " + ", ".join(f"{n} {v:.1f}" for n, v in zip(names, tot)) + f"  | sum {tot.sum():.1f} us per epoch", flush=True)
 ctx.close()

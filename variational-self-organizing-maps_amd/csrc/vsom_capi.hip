@@ -175,6 +175,11 @@ static int free_all(vsom_ctx *c)
         (void)hipHostFree(c->st_pinned);
     if (c->mse)
         (void)hipHostFree(c->mse);
+    if (c->lutd_host)
+        (void)hipHostFree(c->lutd_host);
+    for (int i = 0; i < 2; ++i)
+        if (c->lutd_ev[i])
+            (void)hipEventDestroy(c->lutd_ev[i]);
     if (c->out_pinned)
         (void)hipHostFree(c->out_pinned);
     if (c->sl_fb)

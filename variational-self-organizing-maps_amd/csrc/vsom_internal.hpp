@@ -131,6 +131,10 @@ struct vsom_ctx {
     hipEvent_t lut_ev[2] = {nullptr, nullptr}; bool lut_ev_valid[2] = {false, false}; int lut_slot = 0;
     double lut_sigma = -1.0; uint32_t lut_w = 0, lut_h = 0;
     double *lutd = nullptr; size_t lutd_cap = 0; double lutd_sigma = -1.0;   // online path (double)
+    // the table's host image: two pinned slots used alternately (the device copy is enqueued on the stream, one-launch
+    // chunks of tiny maps read the slot itself), each guarded by an event recorded behind its last reader
+    double *lutd_host = nullptr; size_t lutd_host_cap = 0; double lutd_host_sigma[2] = {-1.0, -1.0};
+    hipEvent_t lutd_ev[2] = {nullptr, nullptr}; bool lutd_ev_valid[2] = {false, false}; int lutd_slot = 0;
 
     // hand-scheduled update kernel (code object loaded with hipModuleLoadData)
     void *upd_module = nullptr, *upd_clr8 = nullptr, *upd_nt[4] = {nullptr, nullptr, nullptr, nullptr};   // nt: std, fma, sfma, med

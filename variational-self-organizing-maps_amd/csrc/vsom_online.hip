@@ -1114,15 +1114,63 @@ __global__ void onl_uslots_init_kernel(unsigned *uslots)
         uslots[t * 32] = 0xFFFFFFFFu;
 }
 
-// double-precision table of calculateNeighbourhoodWeight for the online path (the batch path
-// uses its float cast); cached per sigma
+// double-precision table of calculateNeighbourhoodWeight for the online path (the batch path uses its float cast), cached per
+// sigma.  The schedule changes sigma every epoch (Som.cpp:1146), so a training run builds one table per epoch: the host image
+// goes into one of two pinned slots and from there to the device by a copy ENQUEUED on the stream -- ordered behind the
+// kernels that still read the previous table, no stream wait, no pageable staging (a synchronous copy was ~20 us of the
+// 10 x 10 x 9 scenario's epoch).
+static int ensure_lutd_host(vsom_ctx *c, double sigma, const double **out, int *slot_out)
+{
+    const uint32_t lw = c->W, lh = c->H;
+    const size_t need = (size_t)lw * lh;
+    if (need > c->lutd_host_cap) {
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->lutd_host)
+            VSOM_HIP_CHECK(hipHostFree(c->lutd_host));
+        c->lutd_host = nullptr;
+        c->lutd_host_cap = 0;
+        VSOM_HIP_CHECK(hipHostMalloc(&c->lutd_host, 2 * need * sizeof(double)));
+        c->lutd_host_cap = need;
+        c->lutd_host_sigma[0] = c->lutd_host_sigma[1] = -1.0;
+        c->lutd_ev_valid[0] = c->lutd_ev_valid[1] = false;
+    }
+    for (int k = 0; k < 2; ++k)
+        if (c->lutd_host_sigma[k] == sigma) {
+            *out = c->lutd_host + (size_t)k * c->lutd_host_cap;
+            *slot_out = k;
+            return VSOM_OK;
+        }
+    const int k = c->lutd_slot ^= 1;
+    if (!c->lutd_ev[k])
+        VSOM_HIP_CHECK(hipEventCreateWithFlags(&c->lutd_ev[k], hipEventDisableTiming));
+    if (c->lutd_ev_valid[k])
+        VSOM_HIP_CHECK(hipEventSynchronize(c->lutd_ev[k]));      // its last reader (two tables ago): long done
+    double *host = c->lutd_host + (size_t)k * c->lutd_host_cap;
+    c->lutd_host_sigma[k] = -1.0;
+    for (uint32_t dy = 0; dy < lh; ++dy)
+        for (uint32_t dx = 0; dx < lw; ++dx)
+            host[(size_t)dy * lw + dx] = vsom_neighbourhood_weight(dx, dy, 0, 0, sigma);
+    c->lutd_host_sigma[k] = sigma;
+    *out = host;
+    *slot_out = k;
+    return VSOM_OK;
+}
+
+// (behind the last enqueued reader of host slot k)
+static int lutd_host_used(vsom_ctx *c, int k)
+{
+    VSOM_HIP_CHECK(hipEventRecord(c->lutd_ev[k], c->stream));
+    c->lutd_ev_valid[k] = true;
+    return VSOM_OK;
+}
+
 static int ensure_lutd(vsom_ctx *c, double sigma, const double **out, int *lutw)
 {
     const uint32_t lw = c->W, lh = c->H;
     const size_t need = (size_t)lw * lh;
+    *lutw = (int)lw;
     if (c->lutd && c->lutd_sigma == sigma) {
         *out = c->lutd;
-        *lutw = (int)lw;
         return VSOM_OK;
     }
     if (need > c->lutd_cap) {
@@ -1130,19 +1178,20 @@ static int ensure_lutd(vsom_ctx *c, double sigma, const double **out, int *lutw)
         if (c->lutd)
             VSOM_HIP_CHECK(hipFree(c->lutd));
         c->lutd = nullptr;
+        c->lutd_cap = 0;
         VSOM_HIP_CHECK(hipMalloc(&c->lutd, need * sizeof(double)));
         c->lutd_cap = need;
     }
-    std::vector<double> host(need);
-    for (uint32_t dy = 0; dy < lh; ++dy)
-        for (uint32_t dx = 0; dx < lw; ++dx)
-            host[(size_t)dy * lw + dx] = vsom_neighbourhood_weight(dx, dy, 0, 0, sigma);
-    // the previous table may still be in use by enqueued kernels
-    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
-    VSOM_HIP_CHECK(hipMemcpy(c->lutd, host.data(), need * sizeof(double), hipMemcpyHostToDevice));
+    const double *host = nullptr;
+    int k = 0;
+    if (int rc = ensure_lutd_host(c, sigma, &host, &k))
+        return rc;
+    c->lutd_sigma = -1.0;
+    VSOM_HIP_CHECK(hipMemcpyAsync(c->lutd, host, need * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (int rc = lutd_host_used(c, k))
+        return rc;
     c->lutd_sigma = sigma;
     *out = c->lutd;
-    *lutw = (int)lw;
     return VSOM_OK;
 }
 
@@ -2154,19 +2203,21 @@ int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay
         return vsom_fail(VSOM_ERR_INVALID,
                          "the next chunk is staged ahead over the current chunk's rows: vsom_commit_chunk first");
     const double *lutd = nullptr;
-    int lutw = 0;
-    int rc = ensure_lutd(c, sigma, &lutd, &lutw);
+    int lutw = (int)c->W, lslot = 0, rc;
+    bool tiny = online_tiny_applies(c, sigma);
+    if (tiny)                                 // one launch reads the table once, into LDS: straight from the pinned slot
+        rc = ensure_lutd_host(c, sigma, &lutd, &lslot);
+    else
+        rc = ensure_lutd(c, sigma, &lutd, &lutw);
     if (rc)
         return rc;
-    bool tiny = false;
     {
         TimerScope ts(c, VSOM_T_ONLINE);
-        tiny = online_tiny_applies(c, sigma);
         if (!tiny)                            // (the one-launch chunk starts the running MSE itself and uses no key slots)
             hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f,
                                first_chunk ? 0 : 1);
         if (tiny) {
-            if ((rc = enqueue_chunk_tiny(c, eta, sigma, decay_fn, lutd, lutw, first_chunk)))
+            if ((rc = enqueue_chunk_tiny(c, eta, sigma, decay_fn, lutd, lutw, first_chunk)) || (rc = lutd_host_used(c, lslot)))
                 return rc;
         } else if (onl_i8_applies(c, sigma)) {
             if ((rc = enqueue_chunk_i8(c, eta, sigma, decay_fn, lutd, lutw)))

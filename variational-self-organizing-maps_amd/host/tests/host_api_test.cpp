@@ -263,6 +263,9 @@ static int ref_harness(const char *fixture, size_t scale)
         Som sut{10, 10, ds, Transformation::Standard(loader.getNames())};
         sut.randomInitialize(7, 1);
         sut.train(ds, 3, 0.001, 0.01, 10.0, 0.01, fns[m]);          // warm-up: allocations, code objects
+        sut.train(ds, 1, 0.001, 0.01, 1.0, 0.01, fns[m]);           // ... and those of the sigma <= 1 epochs (a kernel's first
+                                                                    //     launch loads its code: ~15 ms, once per process)
+        (void)sut.getNeuron(size_t{0});                             // ... and the state download's
         sut.randomInitialize(7, 1);
         const auto t0 = clk::now();
         sut.train(ds, 300, 0.001, 0.01, 10.0, 0.01, fns[m]);
