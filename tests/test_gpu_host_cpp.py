@@ -137,6 +137,22 @@ def test_online_training_through_cpp_api(dumps):
     assert beq(dump["mse"], mse)
 
 
+def test_online_schedule_down_to_local_walks_through_cpp_api(dumps):
+    """twelve online epochs on the reference's scenario shape (10 x 10 x 9, chunks of 20 / 20 / 10): sigma 3 -> 1.1 over five
+    epochs, then clamped at 1 (Som.cpp:1148-1149) where trainSingle walks from lastBMU (:891) -- every chunk of every epoch
+    one launch (online_tiny_chunk_kernel), the running MSE carried across the chunks of an epoch"""
+    d, _, _ = dumps
+    rows = make_rows(50, 9, 12345)
+    for name, tr, fn in (("online_to_local_std.bin", po.STANDARD, po.INVERSE_PROPORTIONAL),
+                         ("online_to_local_median.bin", po.MEDIAN, po.EXPONENTIAL)):
+        o = po.OracleSom(10, 10, 9, tr)
+        o.random_initialize(11, 1.0)
+        mse = o.train_online(rows, [0, 20, 40, 50], 12, 0.05, 0.1, 3.0, 0.25, fn)
+        dump = read_dump(os.path.join(d, name))
+        check_state(dump, o, with_S=True)
+        assert beq(dump["mse"], mse), name
+
+
 def test_search_single_copy_and_checkpoint(dumps):
     d, _, _ = dumps
     rows = make_rows(50, 9, 12345)

@@ -78,16 +78,22 @@ def test_random_shape(name, tr, W, H, J, B, sigma, seed):
     orc.set_state(map=clean, sigma=np.zeros_like(clean), S=np.zeros_like(clean), weight=np.zeros(W * H, np.float32),
                   hits=np.zeros(W * H, np.uint64))
     nb = min(B, 12)
-    for sg, fn in ((max(sigma, 1.2), capi.EXPONENTIAL), (1.0, capi.INVERSE_PROPORTIONAL)):
-        lb = np.zeros(nb, np.uint64)
-        mse_o = orc.train_online_chunk(X[:nb], lb, 0.05, sg, fn)
-        ctx.upload_chunk(X[:nb])
-        mse_g = ctx.train_online_chunk(0.05, sg, fn)
-        assert _same(ctx.get_last_bmu(), lb), (name, sg, "online lastBMU")
-        assert _same(np.float32(mse_g), np.float32(mse_o)), (name, sg, "online mse")
-        st = ctx.get_state()
-        for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("S", orc.S), ("weight", orc.weight), ("hits", orc.hits)):
-            assert _same(st[k], ref), (name, sg, "online " + k)
+    # maps of at most 4096 values (Standard / Median) train the chunk in ONE launch under VSOM_BMU_AUTO
+    # (online_tiny_chunk_kernel); VSOM_BMU_EXACT keeps the per-sample kernels covered on those shapes too
+    one_launch = tr != capi.CLR and W * H * D <= 4096 and W * H <= 1024 and D <= 512
+    for mode in ((capi.BMU_AUTO, capi.BMU_EXACT) if one_launch else (capi.BMU_AUTO,)):
+        ctx.set_bmu_mode(mode)
+        for sg, fn in ((max(sigma, 1.2), capi.EXPONENTIAL), (1.0, capi.INVERSE_PROPORTIONAL)):
+            lb = np.zeros(nb, np.uint64)
+            mse_o = orc.train_online_chunk(X[:nb], lb, 0.05, sg, fn)
+            ctx.upload_chunk(X[:nb])
+            mse_g = ctx.train_online_chunk(0.05, sg, fn)
+            assert _same(ctx.get_last_bmu(), lb), (name, sg, mode, "online lastBMU")
+            assert _same(np.float32(mse_g), np.float32(mse_o)), (name, sg, mode, "online mse")
+            st = ctx.get_state()
+            for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("S", orc.S), ("weight", orc.weight), ("hits", orc.hits)):
+                assert _same(st[k], ref), (name, sg, mode, "online " + k)
+    ctx.set_bmu_mode(capi.BMU_AUTO)
     # and the same chunk once more through the image-bounded search of the chunk loop (csrc/vsom_online.hip; forced: these
     # maps are far below the size VSOM_BMU_AUTO takes it for): random shapes, scales 0.1 / 1 / 50, exact zeros
     if tr != capi.CLR and D <= 1024:

@@ -583,6 +583,16 @@ int main(int argc, char **argv)
         som.train(ds, 3, 0.05, 0.1, 3.0, 0.5, Som::WeigthDecayFunction::Exponential);
         dump(out + "/online_median.bin", som, som.getMetrics().MeanSquaredError);
     }
+    // ---- online schedules that run on into sigma <= 1 (Som.cpp:1148-1149 clamps sigma at 1, :891 then walks from lastBMU),
+    //      the shape of the reference's own training scenario (perf_tests.cpp:74-112): two and a half chunks per epoch ----
+    for (int m = 0; m < 2; ++m) {
+        ArrayDataLoader loader(rows.data(), NROWS, J, CHUNK);
+        DataSet ds(loader);
+        Som som{W, H, J, m == 0 ? Transformation::Standard({}) : Transformation::StandardMedianEstimator({})};
+        som.randomInitialize(11, 1);
+        som.train(ds, 12, 0.05, 0.1, 3.0, 0.25, m == 0 ? Som::WeigthDecayFunction::InverseProportional : Som::WeigthDecayFunction::Exponential);
+        dump(out + (m == 0 ? "/online_to_local_std.bin" : "/online_to_local_median.bin"), som, som.getMetrics().MeanSquaredError);
+    }
     // ---- online, inverse proportional, CLR through the depth constructor (perf_tests.cpp:338-339) ----
     {
         const size_t Jc = 5;
