@@ -1355,7 +1355,7 @@ static int stage_single(vsom_ctx *c, const float *v_host, bool copy = true)
 // perf_tests.cpp:74-112): two dependent launches per sample were 220-260 us per epoch there against 50 us of one CPU thread.
 // For maps of at most 4096 values (N D) and 1024 nodes, Standard / Median, sigma > 1: every thread owns up to four model
 // values (M, S) IN REGISTERS for the whole chunk, plus a copy of its node's weight -- the window update of Som.cpp:911-943 is
-// elementwise, so nothing of it crosses threads -- and per sample the workgroup meets at four barriers:
+// elementwise, so nothing of it crosses threads -- and per sample the workgroup meets at two barriers (A of the next sample shares D's):
 //   A  squares p = fl(fl(m - x)^2) of every value into LDS
 //   B  one thread per node adds its row's squares in Eigen's order (the eight accumulator classes, the tree, the tail:
 //      vsom_group_dist's arithmetic) and folds the (distance, index) key into an LDS atomic minimum
@@ -1380,6 +1380,18 @@ struct OnlTinyArgs {
     float *mse_out;          // vsom_get_mse's value
 };
 
+#ifdef VSOM_DEVELOPMENT
+// cycle stamps of one sample of the one-launch chunk (sample 5 of the chunk; s_memtime): [2 w + p] = wavefront w (0: first,
+// 1: last) at phase boundary p (tools/exp/tiny_stamps.py)
+__device__ unsigned long long vsom_tiny_stamps[64];
+#define TINY_STAMP(p) do { if (j == 5 && (tid == 0 || tid == 1023)) vsom_tiny_stamps[(tid ? 16 : 0) + (p)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int vsom_dev_tiny_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vsom_tiny_stamps), sizeof(vsom_tiny_stamps)) == hipSuccess ? 0 : -2;
+}
+#else
+#define TINY_STAMP(p) ((void)0)
+#endif
 constexpr int TINY_XBLOCK = 2048;      // values of staged rows held in LDS at a time (TINY_XBLOCK / D samples)
 
 // minimum of a u64 over the wavefront, in lane 63: four row shifts, two row broadcasts (DPP moves of both halves; the
@@ -1403,6 +1415,24 @@ __device__ __forceinline__ u64 onl_wave_min_u64(u64 v)
     return v;
 }
 
+// minimum of a u32 over the wavefront, in lane 63 (same ladder, one v_min_u32 with a DPP operand per step)
+__device__ __forceinline__ unsigned onl_wave_min_u32(unsigned v)
+{
+#define ONL_DPP_STEP32(CTRL, ROWS)                                                                  \
+    {                                                                                               \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROWS, 0xF, false); \
+        v = o < v ? o : v;                                                                          \
+    }
+    ONL_DPP_STEP32(0x111, 0xF)
+    ONL_DPP_STEP32(0x112, 0xF)
+    ONL_DPP_STEP32(0x114, 0xF)
+    ONL_DPP_STEP32(0x118, 0xF)
+    ONL_DPP_STEP32(0x142, 0xA)
+    ONL_DPP_STEP32(0x143, 0xC)
+#undef ONL_DPP_STEP32
+    return v;
+}
+
 struct OnlTinyNode {           // what a thread needs to know about the sample's BMU: its coordinates and window (Som.cpp:899-907)
     unsigned short bx, by, startX, endX, startY, endY, pad0, pad1;
 };
@@ -1412,53 +1442,77 @@ struct OnlTinyNode {           // what a thread needs to know about the sample's
 // wrap-then-clamp of :362-385 in 32 bits -- a wrapped coordinate is far above width - 1 either way)
 __device__ __forceinline__ int onl_tiny_walk(const float *s_d, const OnlTinyNode *s_win, unsigned W, unsigned H, unsigned start)
 {
+    // (the coordinates of lastMeasured / lastBMU / the running minimum travel in registers: every candidate is built from its
+    //  coordinates, so a step is ONE LDS round trip -- the candidates' distances, requested together, compared in order)
     unsigned lastBMU = start, minIndex = start, lastMeasured = start;
+    unsigned lmX = s_win[start].bx, lmY = s_win[start].by, lbX = lmX, minX = lmX, minY = lmY;
     float minDist = s_d[start];
     for (;;) {
-        const unsigned lmX = s_win[lastMeasured].bx, lmY = s_win[lastMeasured].by, lbX = s_win[lastBMU].bx;
         if (lastMeasured == lastBMU) {
+            unsigned node[8], cxs[8], cys[8];
+            float di[8];
+#pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const unsigned fsx = (g == 0 || g >= 6) ? ~0u : ((g == 1 || g == 5) ? 0u : 1u);   // firstSearchX / Y (:341-342)
                 const unsigned fsy = g <= 2 ? 1u : ((g == 3 || g == 7) ? 0u : ~0u);
                 unsigned cx = lmX + fsx, cy = lmY + fsy;
                 cx = cx < W - 1 ? cx : W - 1;
                 cy = cy < H - 1 ? cy : H - 1;
-                const unsigned node = cy * W + cx;
-                const float di = s_d[node];
-                if (di < minDist) {
-                    minDist = di;
-                    minIndex = node;
-                }
+                cxs[g] = cx;
+                cys[g] = cy;
+                node[g] = cy * W + cx;
+                di[g] = s_d[node[g]];
             }
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (di[g] < minDist) {
+                    minDist = di[g];
+                    minIndex = node[g];
+                    minX = cxs[g];
+                    minY = cys[g];
+                }
             if (minIndex == lastBMU)
                 break;
             lastMeasured = minIndex;
+            lmX = minX;
+            lmY = minY;
         } else {
             if (lmX - lbX) {                                     // moving in X: 3 nodes ahead (:390-403)
                 unsigned cx = lmX + lmX - lbX;
                 cx = cx < W - 1 ? cx : W - 1;
+                unsigned node[3], cys[3];
+                float di[3];
+#pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     unsigned cy = lmY + (unsigned)(i - 1);
                     cy = cy < H - 1 ? cy : H - 1;
-                    const unsigned node = cy * W + cx;
-                    const float di = s_d[node];
-                    if (di < minDist) {
-                        minDist = di;
-                        minIndex = node;
-                    }
+                    cys[i] = cy;
+                    node[i] = cy * W + cx;
+                    di[i] = s_d[node[i]];
                 }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (di[i] < minDist) {
+                        minDist = di[i];
+                        minIndex = node[i];
+                        minX = cx;
+                        minY = cys[i];
+                    }
             }
             // (moving in Y evaluates nothing: :406-437, vsom_local_walk)
             if (minIndex == lastMeasured)
                 break;
             lastBMU = lastMeasured;
+            lbX = lmX;
             lastMeasured = minIndex;
+            lmX = minX;
+            lmY = minY;
         }
     }
     return (int)minIndex;
 }
 
-template <int KIND, bool LOCAL>
+template <int KIND, bool LOCAL, int U>     // U = values per thread (1, 2, 4): N D <= 1024 U
 __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char tiny_onl_smem[];
@@ -1498,11 +1552,11 @@ __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
         s_win[i] = t;
     }
     // this thread's values: flattened (node, dim) indices tid + 1024 u
-    float m[4], sv[4], w[4];
-    int node[4], dim[4], nx[4], ny[4];
-    bool own[4], touched[4];
+    float m[U], sv[U], w[U];
+    int node[U], dim[U], nx[U], ny[U];
+    bool own[U], touched[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
         const int e = tid + 1024 * u;
         own[u] = e < ND;
         node[u] = own[u] ? e / D : 0;
@@ -1518,29 +1572,64 @@ __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
     if (tid < 2)
         s_key[tid] = ~0ull;
     const int L8 = D & ~7, rem = D - L8, KB = TINY_XBLOCK / D;
+    int pj = -1, pbmu = 0;                                   // the sample whose post step is owed, and its BMU
     const bool exp_decay = a.decay_fn == VSOM_EXPONENTIAL;
     for (int j0 = 0; j0 < a.B; j0 += KB) {
         const int kb = min(KB, a.B - j0);
-        __syncthreads();                                     // (the previous block's rows are no longer read; first: the tables)
+        if (j0 == 0)
+            __syncthreads();                                 // the tables (later blocks: the sample loop's last barrier -- nobody reads the old rows)
         for (int i = tid; i < kb * D; i += 1024)
             s_x[i] = a.X[(size_t)(j0 + i / D) * a.ldx + (i % D)];
         __syncthreads();
+        // A (first sample of the block): squares of the sample against every node
+        float x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (own[u]) {
+                x[u] = s_x[dim[u]];
+                const float r = m[u] - x[u];
+                s_p[node[u] * Dp + dim[u]] = r * r;
+            }
+        __syncthreads();
         for (int jj = 0; jj < kb; ++jj) {
             const int j = j0 + jj, par = j & 1;
-            float x[4];
-            // A: squares
+            TINY_STAMP(2);
+            // post step of the PREVIOUS sample (distance after the update :946, MSE :1167, addBmu :1165, lastBMU :895) by the last
+            // thread, in the shadow of phase B -- its wavefront has nothing to do there on maps of at most 960 nodes.  It reads
+            // the previous parity's squares and re-arms that parity's key, which nobody touches before sample j + 1's phase B.
+            if (tid == 1023 && pj >= 0) {
+                const int ppar = pj & 1;
+                const float *p = s_p2 + ppar * ((D + 3) & ~3);
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int d = 0; d < L8; d += 8) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (own[u]) {
-                    x[u] = s_x[jj * D + dim[u]];
-                    const float r = m[u] - x[u];
-                    s_p[node[u] * Dp + dim[u]] = r * r;
+                    for (int k = 0; k < 8; ++k)
+                        acc[k] = acc[k] + p[d + k];
                 }
-            __syncthreads();
+                float q0 = acc[0] + acc[4], q1 = acc[1] + acc[5], q2 = acc[2] + acc[6], q3 = acc[3] + acc[7];
+                int t = 0;
+                if (rem >= 4) {
+                    q0 = q0 + p[L8];
+                    q1 = q1 + p[L8 + 1];
+                    q2 = q2 + p[L8 + 2];
+                    q3 = q3 + p[L8 + 3];
+                    t = 4;
+                }
+                const float t02 = q0 + q2, t13 = q1 + q3;
+                float res = t02 + t13;
+                for (; t < rem; ++t)
+                    res = res + p[L8 + t];
+                lastdist = res;
+                const float q = res / a.fB;                      // residual.squaredNorm() / epochSize  (:1167)
+                mse = mse + q;
+                atomicAdd(&s_hits[pbmu], 1u);
+                s_last[pj] = (unsigned short)pbmu;
+                s_key[ppar] = ~0ull;
+            }
             // B: distances in Eigen's order, argmin with the reference's rules (strict <, lowest index, NaN never wins,
             //    a NaN at node 0 pins the BMU: Som.cpp:293-304 -- key 0 is below every other key and names node 0)
             if (tid < ((N + 63) & ~63)) {                        // whole wavefronts
-                u64 mykey = ~0ull;
+                unsigned mybits = 0xFFFFFFFFu;
                 if (tid < N) {
                     const float *p = s_p + tid * Dp;
                     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1562,17 +1651,24 @@ __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
                     float res = t02 + t13;
                     for (; t < rem; ++t)
                         res = res + p[L8 + t];
-                    mykey = (tid == 0 && res != res) ? 0ull : vsom_key(res, (uint32_t)tid);
+                    // (distances are sums of squares: their bit patterns order like their values; NaN -> all ones, never a
+                    //  minimum; a NaN at node 0 -> 0, below everything)
+                    mybits = (res != res) ? (tid == 0 ? 0u : 0xFFFFFFFFu) : __float_as_uint(res);
                     if (LOCAL)
                         s_d[tid] = res;
                 }
                 if (!LOCAL) {
-                    mykey = onl_wave_min_u64(mykey);             // one LDS atomic per wavefront (N same-address atomics
-                    if ((tid & 63) == 63)                        // serialise: 100 of them were 2 us of a sample)
-                        atomicMin(&s_key[par], mykey);
+                    // the wavefront's minimum, then the LOWEST lane that holds it (strict <: the lowest index wins), one LDS
+                    // atomic per wavefront (N same-address atomics serialise: 100 of them were 2 us of a sample)
+                    const unsigned wmin = (unsigned)__builtin_amdgcn_readlane((int)onl_wave_min_u32(mybits), 63);
+                    const u64 holders = __ballot(mybits == wmin);
+                    if ((tid & 63) == 0)
+                        atomicMin(&s_key[par], (u64)wmin << 32 | (u64)((tid & ~63) + (__ffsll((long long)holders) - 1)));
                 }
             }
+            TINY_STAMP(3);
             __syncthreads();
+            TINY_STAMP(4);
             if (LOCAL) {                                         // sigma <= 1: the walk from the sample's last BMU (Som.cpp:891)
                 if (tid == 1023)
                     s_key[par] = (u64)onl_tiny_walk(s_d, s_win, (unsigned)a.W, (unsigned)a.H, (unsigned)s_last[j]);
@@ -1581,9 +1677,10 @@ __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
             const int bmu = (int)(s_key[par] & 0xFFFFFFFFull);
             // C: the window of Som.cpp:899-944 around the BMU (online_window's bounds, from the table)
             const OnlTinyNode bn = s_win[bmu];
+            TINY_STAMP(5);
             const int bx = bn.bx, by = bn.by;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 if (!own[u])
                     continue;
                 if (nx[u] < (int)bn.startX || nx[u] >= (int)bn.endX || ny[u] < (int)bn.startY || ny[u] >= (int)bn.endY)
@@ -1619,20 +1716,40 @@ __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
                 w[u] = wnew;
                 touched[u] = true;
             }
+            TINY_STAMP(6);
             // D: distance of the BMU after the update (:946), MSE (:1167), addBmu (:1165), lastBMU (:895)
             float *p2 = s_p2 + par * ((D + 3) & ~3);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
                 if (own[u] && node[u] == bmu) {
                     const float r = m[u] - x[u];
                     p2[dim[u]] = r * r;
                 }
+            TINY_STAMP(7);
+            // A of the NEXT sample before the same barrier (its squares go where phase B of this sample, long done, read)
+            if (jj + 1 < kb) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (own[u]) {
+                        x[u] = s_x[(jj + 1) * D + dim[u]];
+                        const float r = m[u] - x[u];
+                        s_p[node[u] * Dp + dim[u]] = r * r;
+                    }
+            }
+            TINY_STAMP(8);
             __syncthreads();
-            // (the last thread -- its wavefront has the least to do in A and B -- works on this parity's squares and key while
-            //  the others go on to the next sample, whose phases use the other parity; it re-arms this parity for sample j + 2,
-            //  which nobody touches before two more barriers)
-            if (tid == 1023) {
-                const float *p = p2;
+            TINY_STAMP(9);
+            pj = j;
+            pbmu = bmu;
+        }
+    }
+    __syncthreads();
+    {
+        const int j = -1;                                    // (no stamps here)
+        (void)j;
+        if (tid == 1023 && pj >= 0) {
+                const int ppar = pj & 1;
+                const float *p = s_p2 + ppar * ((D + 3) & ~3);
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 for (int d = 0; d < L8; d += 8) {
 #pragma unroll
@@ -1655,17 +1772,16 @@ __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
                 lastdist = res;
                 const float q = res / a.fB;                      // residual.squaredNorm() / epochSize  (:1167)
                 mse = mse + q;
-                s_hits[bmu] += 1u;
-                s_last[j] = (unsigned short)bmu;
-                s_key[par] = ~0ull;
+                atomicAdd(&s_hits[pbmu], 1u);
+                s_last[pj] = (unsigned short)pbmu;
+                s_key[ppar] = ~0ull;
             }
-        }
     }
     __syncthreads();
     // state back: M and S of every value, weight by the node's first value, sigmaMap = sqrt(|S / w|) (:939-942) where a
     // window touched the node during this chunk
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
         if (!own[u])
             continue;
         const size_t at = (size_t)node[u] * a.pitch + dim[u];
@@ -1732,26 +1848,40 @@ static int enqueue_chunk_tiny(vsom_ctx *c, double eta, double sigma, int decay_f
     a.mse_out = c->mse;
     const size_t smem = online_tiny_lds_bytes(c);
     const bool local = !(sigma > 1);                  // SIGMA_SWITCH_TO_LOCAL (SOM.hpp:37, Som.cpp:891)
-    if (!c->tiny_lds_attr) {                          // (more than the 64 KiB a launch may ask for by default; 160 KiB per CU)
-        const void *fns[4] = {reinterpret_cast<const void *>(online_tiny_chunk_kernel<VSOM_MEDIAN, false>),
-                              reinterpret_cast<const void *>(online_tiny_chunk_kernel<VSOM_MEDIAN, true>),
-                              reinterpret_cast<const void *>(online_tiny_chunk_kernel<VSOM_STANDARD, false>),
-                              reinterpret_cast<const void *>(online_tiny_chunk_kernel<VSOM_STANDARD, true>)};
-        for (const void *fn : fns)
-            VSOM_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10));
-        c->tiny_lds_attr = true;
-    }
+    const size_t nd = (size_t)c->N * c->part_len;
+    const int upt = nd <= 1024 ? 1 : (nd <= 2048 ? 2 : 4);     // values per thread (the kernel is bound by instruction issue)
+#define VSOM_TINY_LAUNCH(KIND, LOC, UU)                                                                                             \
+    do {                                                                                                                            \
+        if (!c->tiny_lds_attr[(LOC ? 3 : 0) + (UU == 1 ? 0 : (UU == 2 ? 1 : 2))]) {                                                 \
+            /* (more than the 64 KiB a launch may ask for by default; 160 KiB per CU) */                                            \
+            VSOM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(online_tiny_chunk_kernel<KIND, LOC, UU>),             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10));                              \
+            c->tiny_lds_attr[(LOC ? 3 : 0) + (UU == 1 ? 0 : (UU == 2 ? 1 : 2))] = true;                                            \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((online_tiny_chunk_kernel<KIND, LOC, UU>), dim3(1), dim3(1024), smem, c->stream, a);                     \
+    } while (0)
+#define VSOM_TINY_LAUNCH_U(KIND, LOC)                                                                                               \
+    do {                                                                                                                            \
+        if (upt == 1)                                                                                                               \
+            VSOM_TINY_LAUNCH(KIND, LOC, 1);                                                                                         \
+        else if (upt == 2)                                                                                                          \
+            VSOM_TINY_LAUNCH(KIND, LOC, 2);                                                                                         \
+        else                                                                                                                        \
+            VSOM_TINY_LAUNCH(KIND, LOC, 4);                                                                                         \
+    } while (0)
     if (c->transform == VSOM_MEDIAN) {
         if (local)
-            hipLaunchKernelGGL((online_tiny_chunk_kernel<VSOM_MEDIAN, true>), dim3(1), dim3(1024), smem, c->stream, a);
+            VSOM_TINY_LAUNCH_U(VSOM_MEDIAN, true);
         else
-            hipLaunchKernelGGL((online_tiny_chunk_kernel<VSOM_MEDIAN, false>), dim3(1), dim3(1024), smem, c->stream, a);
+            VSOM_TINY_LAUNCH_U(VSOM_MEDIAN, false);
     } else {
         if (local)
-            hipLaunchKernelGGL((online_tiny_chunk_kernel<VSOM_STANDARD, true>), dim3(1), dim3(1024), smem, c->stream, a);
+            VSOM_TINY_LAUNCH_U(VSOM_STANDARD, true);
         else
-            hipLaunchKernelGGL((online_tiny_chunk_kernel<VSOM_STANDARD, false>), dim3(1), dim3(1024), smem, c->stream, a);
+            VSOM_TINY_LAUNCH_U(VSOM_STANDARD, false);
     }
+#undef VSOM_TINY_LAUNCH_U
+#undef VSOM_TINY_LAUNCH
     return VSOM_OK;
 }
 
