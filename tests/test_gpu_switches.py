@@ -1,6 +1,8 @@
 """GPU: every kernel-selection switch the library reads from the environment (README "Switches") is exercised here, so
 that no kernel in libvsom_hip.so is reachable only by hand:
-  VSOM_NO_TINY=1            tiny maps through the general kernels instead of the one-workgroup epoch (vsom_tiny.hip)
+  VSOM_NO_TINY=1            tiny maps through the general kernels instead of the one-workgroup batch epoch (vsom_tiny.hip)
+                            and the one-launch online chunk (online_tiny_chunk_kernel: the online goldens then take the
+                            per-sample kernels)
   VSOM_NO_CHAIN=1           small maps through the lane = node quad kernels instead of update_chain3_kernel
   VSOM_NO_COMPACT=1         no column compaction at all (the quad kernels on the full-width transposed chunk)
   VSOM_COMPACT_MIN_ROWS=1   every chunk compacted, however short
