@@ -265,7 +265,7 @@ def test_online_chunk_with_nan_rows_and_duplicates():
 @pytest.mark.parametrize("tr", [po.STANDARD, po.MEDIAN])
 def test_tiny_map_chunk_in_one_launch_with_nan_rows_and_duplicates(tr):
     """Maps of at most 4096 values train a whole chunk in ONE single-workgroup launch (online_tiny_chunk_kernel: model
-    values in registers, three barriers per sample, four when sigma <= 1 walks from the sample's last BMU).  The argmin rules on it: NaN rows never win, equal rows resolve to the
+    values in registers, two barriers per sample, three when sigma <= 1 walks from the sample's last BMU).  The argmin rules on it: NaN rows never win, equal rows resolve to the
     lowest index, a NaN at node 0 pins every BMU to node 0 (Som.cpp:293-304); depths with every remainder class of Eigen's
     reduction; chunks continued with the running MSE; the per-sample forms (fp32 scan, image-bounded search) beside it."""
     for W, H, J, B in ((12, 10, 9, 61), (16, 16, 13, 40), (31, 33, 4, 50), (8, 8, 24, 33), (20, 10, 20, 17)):

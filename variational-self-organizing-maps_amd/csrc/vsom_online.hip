@@ -1353,18 +1353,23 @@ static int stage_single(vsom_ctx *c, const float *v_host, bool copy = true)
 //
 // The reference's own performance scenario trains a 10 x 10 map on 20 nine-dimensional rows (tests/performance/
 // perf_tests.cpp:74-112): two dependent launches per sample were 220-260 us per epoch there against 50 us of one CPU thread.
-// For maps of at most 4096 values (N D) and 1024 nodes, Standard / Median, sigma > 1: every thread owns up to four model
-// values (M, S) IN REGISTERS for the whole chunk, plus a copy of its node's weight -- the window update of Som.cpp:911-943 is
-// elementwise, so nothing of it crosses threads -- and per sample the workgroup meets at two barriers (A of the next sample shares D's):
-//   A  squares p = fl(fl(m - x)^2) of every value into LDS
+// For maps of at most 4096 values (N D) and 1024 nodes, Standard / Median: every thread owns U = 1, 2 or 4 model values
+// (M, S) IN REGISTERS for the whole chunk, plus a copy of its node's weight -- the window update of Som.cpp:911-943 is
+// elementwise, so nothing of it crosses threads -- and per sample the workgroup meets at two barriers:
 //   B  one thread per node adds its row's squares in Eigen's order (the eight accumulator classes, the tree, the tail:
-//      vsom_group_dist's arithmetic) and folds the (distance, index) key into an LDS atomic minimum
-//   C  every thread reads the BMU, applies online_window / the neighbourhood table and updates its values with
-//      online_node_update's operations (same expressions, same order: same bits)
-//   D  the BMU's threads publish their new squares; thread 0 adds them (the distance after the update, :946), the MSE
-//      running sum (:1167), addBmu, lastBMU
+//      vsom_group_dist's arithmetic); per wavefront a DPP minimum of the distances' bit patterns, the lowest lane that holds
+//      it (strict <: the lowest index wins), one LDS atomic minimum of the (distance, index) key.  Meanwhile the LAST thread
+//      finishes the PREVIOUS sample: the distance after the update (:946), the MSE running sum (:1167), addBmu, lastBMU.
+//      sigma <= 1 (:891): the distances go to LDS and, behind one more barrier, one thread walks findLocalBmu over them.
+//   -- barrier --
+//   C  every thread reads the BMU, applies online_window's bounds (a per-BMU table) and the neighbourhood table and updates
+//      its values with online_node_update's operations (same expressions, same order: same bits)
+//   D  the BMU's threads publish their new squares (double-buffered: read by the post step beside the next sample's B)
+//   A  squares p = fl(fl(m - x)^2) of the NEXT sample against every value, into LDS
+//   -- barrier --
 // sigmaMap is written once at the end, from the final S and weight, for the nodes some window touched (the value of the
 // node's last update: onl_sigma_kernel's argument).  Results are bit-identical to the per-sample kernels and the oracle.
+// The kernel is bound by instruction issue (16 wavefronts on 4 SIMDs) and LDS latency: 0.95 us per sample at 10 x 10 x 9.
 struct OnlTinyArgs {
     const float *X;          // staged rows
     int ldx, B, N, W, H, D, pitch;
