@@ -65,7 +65,7 @@ def test_pipelined_chunks_match_oracle(pinned, tr, J):
 
 
 @pytest.mark.parametrize("source", ["host", "device"])
-@pytest.mark.parametrize("tr,W", [(po.STANDARD, 48), (po.MEDIAN, 48), (po.STANDARD, 64)])
+@pytest.mark.parametrize("tr,W", [(po.STANDARD, 48), (po.MEDIAN, 48), (po.STANDARD, 64), (po.STANDARD, 80)])
 def test_chunks_staged_beside_the_running_epoch_match_oracle(source, tr, W):
     """On a map large enough for the lane = node chain kernels a prefetch that follows an asynchronous epoch also
     STAGES the next chunk -- on the copy stream, beside the chains of the current one (include/vsom_hip.h "Staging
@@ -75,8 +75,10 @@ def test_chunks_staged_beside_the_running_epoch_match_oracle(source, tr, W):
     current chunk's lastBMU / MSE stay readable between prefetch and commit."""
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")                # the runtime libvsom_hip.so already runs on (plain device buffers)
-    # (W = 64: the 2200-row chunk is large enough for the G-less ring kernel of the search)
-    H, J = W, 196
+    # (W = 64: the 2200-row chunk is large enough for the G-less ring kernel of the search; W = 80 with rows of 784 values:
+    #  more than two rounds of chain workgroups -- the staging kernels then wait for the chains and run beside the
+    #  expansion pass that follows them, csrc/vsom_update.hip "Larger maps")
+    H, J = W, (784 if W == 80 else 196)
     sizes = [1100, 1280, 77, 1100, 1500, 1024, 2200, 1100]
     kinds = ["u8", "u8", "u8", "f", "dense", "u8", "f", "u8"]
     chunks = []
