@@ -625,10 +625,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "update_arithmetic": arith,
-            "staging": ("chunk i+1 handed over right after the epoch of chunk i is enqueued (vsom_stage_next_device + "
-                        "vsom_commit_chunk): its staging kernels run beside that epoch's chains on small maps, behind them -- "
-                        "beside the expansion pass -- on large ones (C3); every step still stages exactly one chunk"
-                        if pipelined else "every chunk staged at the start of its own step"),
+            "staging": ("chunk i+1 staged beside the chains of chunk i (vsom_stage_next_device + vsom_commit_chunk; every step "
+                        "still stages exactly one chunk)" if pipelined else "every chunk staged at the start of its own step"),
             "staged_in_step": ({"value": round(steps * units_of(split) / dt_in_step, 3),
                                 "ms_per_step": round(dt_in_step / steps * 1e3, 4),
                                 "note": "the same steps with every chunk staged at the start of its own step (--no-stage-ahead: "

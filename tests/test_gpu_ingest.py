@@ -76,8 +76,8 @@ def test_chunks_staged_beside_the_running_epoch_match_oracle(source, tr, W):
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")                # the runtime libvsom_hip.so already runs on (plain device buffers)
     # (W = 64: the 2200-row chunk is large enough for the G-less ring kernel of the search; W = 80 with rows of 784 values:
-    #  more than two rounds of chain workgroups -- the staging kernels then wait for the chains and run beside the
-    #  expansion pass that follows them, csrc/vsom_update.hip "Larger maps")
+    #  more than two rounds of chain workgroups -- staging ahead is not offered there (csrc/vsom_update.hip): the chunk handed
+    #  over ahead is copied beside the epoch and staged at its commit)
     H, J = W, (784 if W == 80 else 196)
     sizes = [1100, 1280, 77, 1100, 1500, 1024, 2200, 1100]
     kinds = ["u8", "u8", "u8", "f", "dense", "u8", "f", "u8"]

@@ -7,7 +7,6 @@ that no kernel in libvsom_hip.so is reachable only by hand:
   VSOM_NO_COMPACT=1         no column compaction at all (the quad kernels on the full-width transposed chunk)
   VSOM_COMPACT_MIN_ROWS=1   every chunk compacted, however short
   VSOM_NO_DEDUPE=1          the exact search over every node, duplicate rows included (no representatives pass)
-  VSOM_NO_LATE_AHEAD=1      large maps: the next chunk staged at its commit instead of behind the chains of the running epoch
 Each switch is read once per process, hence a fresh child interpreter per setting (a child process, never a re-exec),
 running parity tests that compare the HIP path with the oracle bit for bit."""
 import os
@@ -54,7 +53,3 @@ def test_every_chunk_compacted():
 
 def test_exact_search_without_the_duplicate_row_pass():
     _child({"VSOM_NO_DEDUPE": "1"}, ["test_gpu_dedupe.py", "test_gpu_shortlist.py"], kexpr="duplicate or redo or ties")
-
-
-def test_large_maps_staged_at_commit():
-    _child({"VSOM_NO_LATE_AHEAD": "1"}, ["test_gpu_ingest.py"], kexpr="staged_beside and 80")

@@ -270,8 +270,6 @@ int vsom_create(vsom_ctx **out, int device, uint32_t width, uint32_t height, uin
     c->xpitch = roundup(c->J, VSOM_TK);
     if (const char *e = std::getenv("VSOM_NO_TINY"))
         c->use_tiny = !(e[0] == '1');
-    if (const char *e = std::getenv("VSOM_NO_LATE_AHEAD"))
-        c->late_ahead = !(e[0] == '1');
     if (const char *e = std::getenv("VSOM_COMPACT_MIN_ROWS"))     // development: initial vsom_set_column_compaction
         c->cc_min_rows = std::atol(e);
     if (const char *e = std::getenv("VSOM_NO_DEDUPE"))

@@ -104,7 +104,6 @@ struct vsom_ctx {
     void *dd_hash = nullptr; int *dd_rep = nullptr, *dd_list = nullptr;
     bool dedupe = true;             // VSOM_NO_DEDUPE=1 switches it off (A/B measurements)
     double dd_min_work = 2.0e10;    // exact searches of at least this many (sample, node, value) triples (vsom_set_row_dedupe)
-    bool late_ahead = true;         // chunks of large maps staged ahead behind the chains (VSOM_NO_LATE_AHEAD=1: at commit, as before)
     bool tiny_lds_attr[12] = {};    // online_tiny_chunk_kernel<kind, local, U>: dynamic LDS limit raised (per context: its device, its kind)
 
     // MFMA shortlist scratch

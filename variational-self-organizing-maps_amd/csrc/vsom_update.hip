@@ -722,8 +722,7 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
             // at 80x80 / 96x96 and LOSES 1 % at 112x112 / 128x128 (six full rounds: 0.05 ms of staging kernels cost the
             // chains 0.09 ms).  So the event is offered only when the chain launch is at most two rounds.
             const size_t chain_wgs = (size_t)gx * (((c->cc_valid ? c->cpitch / 4 : (c->D + 3) / 4) + 7) / 8);
-            const bool beside_chains = chain_wgs <= 2048;
-            if (beside_chains) {
+            if (chain_wgs <= 2048) {
                 VSOM_HIP_CHECK(hipEventRecord(c->ev_rows_free, c->stream));
                 c->rows_free_valid = true;
             }
@@ -754,13 +753,6 @@ int launch_phase2(vsom_ctx *c, double sigma, size_t n0, size_t n1)
             void *fn = c->upd_nt[med ? 3 : (fma ? 1 : (sfma ? 2 : 0))];
             VSOM_HIP_CHECK(hipModuleLaunchKernel((hipFunction_t)fn, 8 * ((quads + 7) / 8), (gx + 7) / 8, 1, 512, 1, 1, 0,
                                                  c->stream, nullptr, extra));
-            // Larger maps: the next chunk's staging kernels BEHIND the chains instead -- beside the expansion pass and
-            // sqrt(S / W) that follow on this stream (0.05 ms of single passes over the map; the staging kernels are
-            // 0.04 ms of single passes over the chunk), off the step's critical path without taking anything from the chains
-            if (!beside_chains && c->late_ahead) {
-                VSOM_HIP_CHECK(hipEventRecord(c->ev_rows_free, c->stream));
-                c->rows_free_valid = true;
-            }
             sig_cols = compact ? -1 : (int)(quads * 4);
         }
         VSOM_HIP_CHECK(hipGetLastError());
