@@ -163,6 +163,11 @@ int vsom_get_state(vsom_ctx *ctx, float *map, float *sigma, float *S, float *wei
 /* ---- chunk (DataSet::loadNextDataFromStream, DataSet.cpp:118-160) ----------------------
  * Stages B samples and zeroes lastBMU (DataSet.cpp:136-137).                              */
 int vsom_upload_chunk(vsom_ctx *ctx, const float *x_host, size_t B);
+/* same without the final wait: copy and staging kernels are enqueued on the context's stream and the call returns; x_host
+ * must be pinned (vsom_host_alloc; from pageable memory the copy degrades to a blocking one) and stay unchanged until a
+ * call that synchronises the context (vsom_get_mse, vsom_get_last_bmu, vsom_train_online_chunk_fetch ...) has returned.
+ * For the first chunk of an epoch, when nothing runs that a prefetch on the copy stream could overlap with. */
+int vsom_upload_chunk_async(vsom_ctx *ctx, const float *x_host, size_t B);
 /* same, samples already resident in HBM (no PCIe copy) */
 int vsom_set_chunk_device(vsom_ctx *ctx, const float *x_dev, size_t B);
 /* Double-buffered ingest: the reference reloads every chunk from its loader each
@@ -265,6 +270,14 @@ int vsom_train_online_chunk(vsom_ctx *ctx, double eta, double sigma, int decay_f
  * vsom_train_online_chunk = first_chunk 1. */
 int vsom_train_online_chunk_acc(vsom_ctx *ctx, double eta, double sigma, int decay_fn, int first_chunk,
                                 float *mse_out);
+/* The same as ONE synchronising call that also hands back what Som::trainBasicSom reads after the sample loop of an
+ * epoch's last chunk: the chunk's lastBMU (trainSingle writes data.getLastBMU(s) as it goes, Som.cpp:895,1163) and the
+ * running MSE (:1167,1175).  lastbmu_out: B values (NULL: not wanted); mse_out: the running value after this chunk
+ * (NULL: not wanted).  Equivalent to vsom_train_online_chunk_acc(..., NULL) + vsom_get_last_bmu + vsom_get_mse; on
+ * maps small enough for the one-launch chunk kernel the results come back through pinned memory the kernel itself
+ * stores into -- one launch and one stream wait per chunk (the reference's own 10 x 10 x 9 scenario). */
+int vsom_train_online_chunk_fetch(vsom_ctx *ctx, double eta, double sigma, int decay_fn, int first_chunk,
+                                  uint64_t *lastbmu_out, float *mse_out);
 /* diagnostics of the chunk loop's image-bounded search (csrc/vsom_online.hip; synchronises): out[0] = samples searched
  * through the image since the last reset, out[1] = nodes evaluated exactly for them (the candidates that survived the
  * bound), out[2] = refinement workgroups that had a candidate, out[3] = 0.  All zero while the exact scan is in use. */

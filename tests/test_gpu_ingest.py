@@ -201,6 +201,45 @@ def test_search_between_staged_ahead_prefetch_and_commit_is_refused():
         b.free()
 
 
+def test_upload_without_the_wait():
+    """vsom_upload_chunk_async: copy and staging enqueued on the context's stream, no wait (the first chunk of an epoch in the
+    C++ mirror's online driver) -- the state it leaves is vsom_upload_chunk's: a batch epoch and an online chunk on chunks
+    handed over that way are the oracle's, also when the next chunk follows without any synchronising call in between."""
+    W, H, J = 20, 16, 24
+    chunks = [gen.blobs(b, J, 5, 1, 50 + i, sigma=0.4) for i, b in enumerate((300, 41, 300))]
+    init = gen.random_map(W * H, J, seed=42)
+    orc = po.OracleSom(W, H, J, po.STANDARD)
+    orc.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, po.STANDARD)
+    ctx.set_state(map=init)
+    bufs = []
+    for x in chunks:
+        pb = capi.PinnedBuffer(x.shape)
+        pb.array[...] = x
+        bufs.append(pb)
+    # chunk 0 handed over and replaced by chunk 1 at once (nothing read it), then an epoch on chunk 1
+    ctx.upload_chunk_async(bufs[0].array)
+    ctx.upload_chunk_async(bufs[1].array)
+    assert ctx.chunk_size == chunks[1].shape[0]
+    lb = np.zeros(chunks[1].shape[0], np.uint64)
+    mse_o = orc.batch_epoch(chunks[1], lb, 5.0, True)
+    mse_g = ctx.batch_epoch(5.0, True)
+    assert np.float32(mse_g) == np.float32(mse_o) and (ctx.get_last_bmu() == lb).all()
+    # an online chunk with its results fetched in the same call, on a chunk handed over without a wait
+    ctx.upload_chunk_async(bufs[2].array)
+    lb = np.zeros(chunks[2].shape[0], np.uint64)
+    run_o = orc.train_online_chunk(chunks[2], lb, 0.05, 3.0, capi.EXPONENTIAL)
+    run_g, lb_g = ctx.train_online_chunk_fetch(0.05, 3.0, capi.EXPONENTIAL)
+    assert np.float32(run_g) == np.float32(run_o) and (lb_g == lb).all()
+    st = ctx.get_state()
+    for k, ref in (("map", orc.map), ("sigma", orc.sigma), ("S", orc.S), ("weight", orc.weight)):
+        assert (_bits(st[k]) == _bits(ref)).all(), k
+    assert (st["hits"] == orc.hits).all()
+    ctx.close()
+    for b in bufs:
+        b.free()
+
+
 def test_commit_without_prefetch_is_an_error():
     ctx = vsom_amd.Context(4, 4, 8)
     with pytest.raises(capi.VsomError):

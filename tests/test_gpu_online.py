@@ -308,6 +308,39 @@ def test_tiny_map_chunk_in_one_launch_with_nan_rows_and_duplicates(tr):
                 ctx.close()
 
 
+@pytest.mark.parametrize("W,H,J,tr", [(10, 10, 9, po.STANDARD), (12, 9, 20, po.MEDIAN), (24, 24, 48, po.STANDARD), (7, 7, 6, po.CLR)])
+def test_chunk_with_results_fetched_in_the_same_call(W, H, J, tr):
+    """vsom_train_online_chunk_fetch = the chunk's sample loop + its lastBMU + the running MSE in one synchronising call (what
+    Som::trainBasicSom reads after the last chunk of an epoch, Som.cpp:895,1163,1167).  On maps of at most 4096 values the
+    one-launch kernel stores the results into pinned memory itself; elsewhere the call falls back to the separate getters.
+    Two chunks of an epoch (MSE carried), sigma above and at 1, and vsom_get_last_bmu / vsom_get_mse agree afterwards."""
+    D = po.length(tr, J)
+    B = 37
+    X = gen.correlated(B, J, 5) if tr == po.CLR else gen.blobs(B, J, 4, 1, 2, sigma=0.3)
+    init = gen.random_map(W * H, D, seed=9)
+    o = po.OracleSom(W, H, J, tr)
+    o.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    ctx.set_state(map=init)
+    run_o = np.float32(0)
+    lb_prev = np.zeros(B, np.uint64)
+    for ci, (sigma, fn) in enumerate(((2.5, capi.EXPONENTIAL), (1.0, capi.INVERSE_PROPORTIONAL), (4.0, capi.INVERSE_PROPORTIONAL))):
+        lb = lb_prev.copy() if sigma <= 1 else np.zeros(B, np.uint64)
+        start = lb.copy()
+        run_o = o.train_online_chunk(X, lb, 0.05, sigma, fn, mse_start=0.0 if ci == 0 else float(run_o))
+        ctx.upload_chunk(X)
+        ctx.set_last_bmu(start)
+        run_g, lb_g = ctx.train_online_chunk_fetch(0.05, sigma, fn, first_chunk=(ci == 0))
+        assert beq(lb_g, lb), (ci, "lastBMU from the call")
+        assert beq(np.float32(run_g), np.float32(run_o)), (ci, run_g, run_o)
+        assert beq(ctx.get_last_bmu(), lb) and beq(np.float32(ctx.get_mse()), np.float32(run_o)), ci
+        st = ctx.get_state()
+        for k in ("map", "S", "sigma", "weight", "hits"):
+            assert beq(st[k], getattr(o, k)), (ci, k)
+        lb_prev = lb
+    ctx.close()
+
+
 @pytest.mark.parametrize("tr,fn,sigma", [(0, 0, 3.0), (1, 1, 2.0), (2, 0, 1.5), (0, 1, 1.0)])
 def test_train_single_api(tr, fn, sigma):
     W, H, J = 11, 9, 6

@@ -33,7 +33,7 @@ SYMBOLS = [
     "vsom_set_last_bmu", "vsom_get_sqres", "vsom_bmu_batch", "vsom_find_bmu", "vsom_dist_single", "vsom_find_local_bmu", "vsom_find_restricted_bmu", "vsom_distances_single", "vsom_bmu_local_batch",
     "vsom_distances", "vsom_bmu_restricted_batch", "vsom_distances_row", "vsom_distances_raw", "vsom_batch_phase1_async", "vsom_batch_finish_async",
     "vsom_batch_phase2_async", "vsom_batch_epoch_async", "vsom_batch_epoch", "vsom_get_mse",
-    "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk", "vsom_train_online_chunk_acc", "vsom_get_online_search_stats",
+    "vsom_residual_len", "vsom_train_single", "vsom_train_online_chunk", "vsom_train_online_chunk_acc", "vsom_train_online_chunk_fetch", "vsom_upload_chunk_async", "vsom_get_online_search_stats",
     "vsom_neighbourhood_weight", "vsom_device_ptr", "vsom_chunk_size", "vsom_pitch",
     "vsom_chunk_pitch", "vsom_small_map_chains", "vsom_enable_timing", "vsom_enable_timing_of", "vsom_get_timing",
     "vsom_group_create", "vsom_group_destroy", "vsom_group_size", "vsom_group_ctx", "vsom_group_transport",
@@ -128,6 +128,7 @@ def lib():
     L.vsom_set_state.argtypes = [vp, fp, fp, fp, fp, u64p]
     L.vsom_get_state.argtypes = [vp, fp, fp, fp, fp, u64p]
     L.vsom_upload_chunk.argtypes = [vp, fp, C.c_size_t]
+    L.vsom_upload_chunk_async.argtypes = [vp, fp, C.c_size_t]
     L.vsom_set_chunk_device.argtypes = [vp, vp, C.c_size_t]
     L.vsom_host_alloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.vsom_host_free.argtypes = [vp]
@@ -159,6 +160,7 @@ def lib():
     L.vsom_distances_single.argtypes = [vp, fp, fp]
     L.vsom_train_online_chunk.argtypes = [vp, C.c_double, C.c_double, C.c_int, fp]
     L.vsom_train_online_chunk_acc.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int, fp]
+    L.vsom_train_online_chunk_fetch.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_uint64), fp]
     L.vsom_neighbourhood_weight.argtypes = [C.c_size_t] * 4 + [C.c_double]
     L.vsom_neighbourhood_weight.restype = C.c_double
     L.vsom_device_ptr.argtypes = [vp, C.c_int]
@@ -338,6 +340,11 @@ class Context:
         assert X.ndim == 2 and X.shape[1] == self.in_len, (X.shape, self.in_len)
         check(lib().vsom_upload_chunk(self._h, _f(X), X.shape[0]))
 
+    def upload_chunk_async(self, X_pinned):
+        """copy + staging enqueued, no wait: X_pinned (a PinnedBuffer's array) must stay unchanged until a synchronising call"""
+        assert X_pinned.ndim == 2 and X_pinned.shape[1] == self.in_len and X_pinned.dtype == np.float32
+        check(lib().vsom_upload_chunk_async(self._h, _f(X_pinned), X_pinned.shape[0]))
+
     def set_chunk_device(self, dev_ptr, B):
         check(lib().vsom_set_chunk_device(self._h, C.c_void_p(int(dev_ptr)), int(B)))
 
@@ -492,6 +499,14 @@ class Context:
         check(lib().vsom_train_online_chunk_acc(self._h, float(eta), float(sigma), int(decay_fn),
                                                 int(bool(first_chunk)), C.byref(mse)))
         return np.float32(mse.value)
+
+    def train_online_chunk_fetch(self, eta, sigma, decay_fn, first_chunk=True):
+        """the same as one synchronising call that also hands back the chunk's lastBMU: (running MSE, lastBMU)"""
+        mse = C.c_float()
+        lb = np.zeros(self.chunk_size, np.uint64)
+        check(lib().vsom_train_online_chunk_fetch(self._h, float(eta), float(sigma), int(decay_fn), int(bool(first_chunk)),
+                                                  _u(lb), C.byref(mse)))
+        return np.float32(mse.value), lb
 
     def online_search_stats(self, reset=False):
         """image-bounded search of the online chunk loop: samples searched, nodes evaluated exactly, refinement workgroups

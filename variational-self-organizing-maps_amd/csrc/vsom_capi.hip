@@ -588,7 +588,7 @@ int vsom_set_chunk_device(vsom_ctx *c, const float *x_dev, size_t B)
     return launch_stage_chunk(c, x_dev, B);
 }
 
-int vsom_upload_chunk(vsom_ctx *c, const float *x_host, size_t B)
+static int upload_chunk_impl(vsom_ctx *c, const float *x_host, size_t B, bool wait)
 {
     CHECK_CTX(c);
     if (B > 0 && !x_host)
@@ -608,9 +608,16 @@ int vsom_upload_chunk(vsom_ctx *c, const float *x_host, size_t B)
     int rc = vsom_set_chunk_device(c, c->Xraw, B);
     if (rc)
         return rc;
-    VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));   // x_host may be reused by the caller
+    if (wait)
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));   // x_host may be reused by the caller
     return VSOM_OK;
 }
+
+int vsom_upload_chunk(vsom_ctx *c, const float *x_host, size_t B) { return upload_chunk_impl(c, x_host, B, true); }
+
+// copy and staging enqueued on the context's stream, no wait: x_host (pinned: vsom_host_alloc) stays the caller's to keep
+// unchanged until a call that synchronises the context has returned
+int vsom_upload_chunk_async(vsom_ctx *c, const float *x_host, size_t B) { return upload_chunk_impl(c, x_host, B, false); }
 
 int vsom_host_alloc(void **out, size_t bytes)
 {

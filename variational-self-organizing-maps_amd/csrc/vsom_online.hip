@@ -1383,6 +1383,7 @@ struct OnlTinyArgs {
     float fB;
     int keep_mse;            // 0: first chunk of an epoch, the running MSE starts at 0 (online_init_kernel's argument)
     float *mse_out;          // vsom_get_mse's value
+    u64 *lastbmu_host;       // pinned host copy of lastBMU (vsom_train_online_chunk_fetch), or NULL
 };
 
 #ifdef VSOM_DEVELOPMENT
@@ -1805,6 +1806,9 @@ __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
             a.hits[i] += (u64)s_hits[i];
     for (int i = tid; i < a.B; i += 1024)
         a.lastbmu[i] = (u64)s_last[i];
+    if (a.lastbmu_host)
+        for (int i = tid; i < a.B; i += 1024)
+            a.lastbmu_host[i] = (u64)s_last[i];
     if (tid == 1023) {
         a.fstate[0] = lastdist;
         a.fstate[1] = mse;
@@ -1825,7 +1829,8 @@ static bool online_tiny_applies(const vsom_ctx *c, double sigma)
            (size_t)c->N * c->part_len <= 4096 && c->part_len <= 512 && c->B <= 4096 && c->bmu_mode == VSOM_BMU_AUTO;   // (EXACT / SHORTLIST name the per-sample forms)
 }
 
-static int enqueue_chunk_tiny(vsom_ctx *c, double eta, double sigma, int decay_fn, const double *lutd, int lutw, int first_chunk)
+static int enqueue_chunk_tiny(vsom_ctx *c, double eta, double sigma, int decay_fn, const double *lutd, int lutw, int first_chunk,
+                              u64 *lastbmu_host)
 {
     OnlTinyArgs a;
     a.X = c->Xs;
@@ -1851,6 +1856,7 @@ static int enqueue_chunk_tiny(vsom_ctx *c, double eta, double sigma, int decay_f
     a.fB = (float)c->B;
     a.keep_mse = first_chunk ? 0 : 1;
     a.mse_out = c->mse;
+    a.lastbmu_host = lastbmu_host;
     const size_t smem = online_tiny_lds_bytes(c);
     const bool local = !(sigma > 1);                  // SIGMA_SWITCH_TO_LOCAL (SOM.hpp:37, Som.cpp:891)
     const size_t nd = (size_t)c->N * c->part_len;
@@ -2322,9 +2328,13 @@ int vsom_find_local_bmu(vsom_ctx *c, const float *v_host, uint64_t last_bmu, uin
     return single_query(c, v_host, last_bmu, 1, bmu_out, dist_out);
 }
 
-int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay_fn, int first_chunk,
-                                float *mse_out)
+// lb_host != NULL: the caller wants lastBMU back in this call -- *lb_in_pinned = the one-launch kernel has stored it into
+// c->out_pinned itself (else the caller fetches it with vsom_get_last_bmu)
+static int train_online_chunk_impl(vsom_ctx *c, double eta, double sigma, int decay_fn, int first_chunk, float *mse_out,
+                                   bool want_lb, bool *lb_in_pinned)
 {
+    if (lb_in_pinned)
+        *lb_in_pinned = false;
     if (!c)
         return vsom_fail(VSOM_ERR_INVALID, "null context");
     VSOM_HIP_CHECK(hipSetDevice(c->device));
@@ -2352,8 +2362,16 @@ int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay
             hipLaunchKernelGGL(online_init_kernel, dim3(1), dim3(1), 0, c->stream, c->onl_state, c->onl_f,
                                first_chunk ? 0 : 1);
         if (tiny) {
-            if ((rc = enqueue_chunk_tiny(c, eta, sigma, decay_fn, lutd, lutw, first_chunk)) || (rc = lutd_host_used(c, lslot)))
+            u64 *lbh = nullptr;
+            if (want_lb && c->B <= 8192) {
+                if (!c->out_pinned)
+                    VSOM_HIP_CHECK(hipHostMalloc(&c->out_pinned, 8192 * sizeof(uint64_t)));
+                lbh = static_cast<u64 *>(c->out_pinned);
+            }
+            if ((rc = enqueue_chunk_tiny(c, eta, sigma, decay_fn, lutd, lutw, first_chunk, lbh)) || (rc = lutd_host_used(c, lslot)))
                 return rc;
+            if (lbh && lb_in_pinned)
+                *lb_in_pinned = true;
         } else if (onl_i8_applies(c, sigma)) {
             if ((rc = enqueue_chunk_i8(c, eta, sigma, decay_fn, lutd, lutw)))
                 return rc;
@@ -2386,6 +2404,32 @@ int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay
         VSOM_HIP_CHECK(hipMemcpyAsync(mse_out, c->onl_f + 1, 4, hipMemcpyDeviceToHost, c->stream));
         VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
+    return VSOM_OK;
+}
+
+int vsom_train_online_chunk_acc(vsom_ctx *c, double eta, double sigma, int decay_fn, int first_chunk,
+                                float *mse_out)
+{
+    return train_online_chunk_impl(c, eta, sigma, decay_fn, first_chunk, mse_out, false, nullptr);
+}
+
+int vsom_train_online_chunk_fetch(vsom_ctx *c, double eta, double sigma, int decay_fn, int first_chunk,
+                                  uint64_t *lastbmu_out, float *mse_out)
+{
+    bool in_pinned = false;
+    int rc = train_online_chunk_impl(c, eta, sigma, decay_fn, first_chunk, nullptr, lastbmu_out != nullptr, &in_pinned);
+    if (rc)
+        return rc;
+    if (lastbmu_out && !in_pinned) {
+        if ((rc = vsom_get_last_bmu(c, lastbmu_out)))      // (synchronises)
+            return rc;
+    } else {
+        VSOM_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (lastbmu_out)
+            std::memcpy(lastbmu_out, c->out_pinned, c->B * sizeof(uint64_t));
+    }
+    if (mse_out)
+        *mse_out = *static_cast<volatile float *>(c->mse);  // pinned host memory; written in stream order before the wait above
     return VSOM_OK;
 }
 

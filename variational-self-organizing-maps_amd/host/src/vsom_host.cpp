@@ -1170,38 +1170,51 @@ void Som::trainBasicSom(DataSet &data, size_t numberOfEpochs, double eta0, doubl
         std::cout << "Epoch: " << i + 1 << "/" << numberOfEpochs << "\teta: " << eta << "\tsigma: " << sigma << "\n";
         float meanSquareError{0.0};
         size_t countDataChunks{0};
+        std::vector<uint64_t> lbScratch;
         // same software pipeline as trainBatchSom: chunk k+1 is loaded and copied while the device
         // walks the B sequential trainSingle steps of chunk k (:1161-1171)
-        bool have = false;
+        bool have = false, staged = false;
         size_t B = 0;
         if (!data.hasReadWholeDataStream()) {
             data.loadNextDataFromStream();
             B = data.size();
-            check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+            // the epoch's first chunk: the previous epoch has been waited for, nothing runs that a prefetch on the copy
+            // stream could overlap with -- copy and staging go straight onto the context's stream, no events, no wait (the
+            // DataSet's pinned buffer is not rewritten before the chunk after next is loaded)
+            check(vsom_upload_chunk_async(ctx, data.contiguous(), B), "vsom_upload_chunk_async");
             have = true;
+            staged = true;
         }
         while (have) {
             const size_t Bcur = B;
             // meanSquareError is ONE running float over all chunks of the epoch (:1153,1167): the device
             // keeps it across chunks (first chunk starts at 0); an empty chunk adds nothing
-            check(vsom_commit_chunk(ctx), "vsom_commit_chunk");
-            check(vsom_train_online_chunk_acc(ctx, eta, sigma, decay_code(weightDecayFunction), countDataChunks == 0 ? 1 : 0,
-                                              nullptr),
-                  "vsom_train_online_chunk_acc");
+            if (!staged)
+                check(vsom_commit_chunk(ctx), "vsom_commit_chunk");
+            staged = false;
             have = false;
             const bool last = data.hasReadWholeDataStream();
             if (last && Bcur > 0) {
-                std::vector<uint64_t> lb(Bcur);
-                check(vsom_get_last_bmu(ctx, lb.data()), "vsom_get_last_bmu");
+                // the epoch's last chunk: the sample loop, its lastBMU (:895,1163) and the running MSE in ONE call and one
+                // synchronisation (the reference's own 20-row scenario is such a chunk every epoch)
+                lbScratch.resize(Bcur);
+                check(vsom_train_online_chunk_fetch(ctx, eta, sigma, decay_code(weightDecayFunction), countDataChunks == 0 ? 1 : 0,
+                                                    lbScratch.data(), &meanSquareError),
+                      "vsom_train_online_chunk_fetch");
                 for (size_t s = 0; s < Bcur; ++s)
-                    data.getLastBMU(s) = (size_t)lb[s];
-            } else if (!last) {
-                data.loadNextDataFromStream();
-                B = data.size();
-                check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
-                have = true;
+                    data.getLastBMU(s) = (size_t)lbScratch[s];
+            } else {
+                check(vsom_train_online_chunk_acc(ctx, eta, sigma, decay_code(weightDecayFunction), countDataChunks == 0 ? 1 : 0,
+                                                  nullptr),
+                      "vsom_train_online_chunk_acc");
+                if (!last) {
+                    data.loadNextDataFromStream();
+                    B = data.size();
+                    check(vsom_prefetch_chunk(ctx, data.contiguous(), B), "vsom_prefetch_chunk");
+                    have = true;
+                }
+                check(vsom_get_mse(ctx, &meanSquareError), "vsom_get_mse");   // the running value so far
             }
-            check(vsom_get_mse(ctx, &meanSquareError), "vsom_get_mse");   // the running value so far
             ++countDataChunks;
         }
         meanSquareError /= static_cast<float>(countDataChunks);   // :1175
