@@ -1518,6 +1518,32 @@ __device__ __forceinline__ int onl_tiny_walk(const float *s_d, const OnlTinyNode
     return (int)minIndex;
 }
 
+// a row of squares added in Eigen's order: the eight accumulator classes, the packet tree, the scalar tail (vsom_group_dist's
+// arithmetic by one thread)
+__device__ __forceinline__ float onl_tiny_row_sum(const float *p, int L8, int rem)
+{
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < L8; d += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            acc[k] = acc[k] + p[d + k];
+    }
+    float q0 = acc[0] + acc[4], q1 = acc[1] + acc[5], q2 = acc[2] + acc[6], q3 = acc[3] + acc[7];
+    int t = 0;
+    if (rem >= 4) {
+        q0 = q0 + p[L8];
+        q1 = q1 + p[L8 + 1];
+        q2 = q2 + p[L8 + 2];
+        q3 = q3 + p[L8 + 3];
+        t = 4;
+    }
+    const float t02 = q0 + q2, t13 = q1 + q3;
+    float res = t02 + t13;
+    for (; t < rem; ++t)
+        res = res + p[L8 + t];
+    return res;
+}
+
 template <int KIND, bool LOCAL, int U>     // U = values per thread (1, 2, 4): N D <= 1024 U
 __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
 {
@@ -1579,6 +1605,18 @@ __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
         s_key[tid] = ~0ull;
     const int L8 = D & ~7, rem = D - L8, KB = TINY_XBLOCK / D;
     int pj = -1, pbmu = 0;                                   // the sample whose post step is owed, and its BMU
+    // post step of a sample (one thread): the distance of its BMU after the update (:946) from the squares the BMU's threads
+    // left in that sample's parity, the MSE running sum (:1167), addBmu (:1165), lastBMU (:895); re-arms the parity's key
+    auto post = [&](int sj, int sbmu) {
+        const int ppar = sj & 1;
+        const float res = onl_tiny_row_sum(s_p2 + ppar * ((D + 3) & ~3), L8, rem);
+        lastdist = res;
+        const float q = res / a.fB;                          // residual.squaredNorm() / epochSize  (:1167)
+        mse = mse + q;
+        atomicAdd(&s_hits[sbmu], 1u);
+        s_last[sj] = (unsigned short)sbmu;
+        s_key[ppar] = ~0ull;
+    };
     const bool exp_decay = a.decay_fn == VSOM_EXPONENTIAL;
     for (int j0 = 0; j0 < a.B; j0 += KB) {
         const int kb = min(KB, a.B - j0);
@@ -1603,60 +1641,14 @@ __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
             // post step of the PREVIOUS sample (distance after the update :946, MSE :1167, addBmu :1165, lastBMU :895) by the last
             // thread, in the shadow of phase B -- its wavefront has nothing to do there on maps of at most 960 nodes.  It reads
             // the previous parity's squares and re-arms that parity's key, which nobody touches before sample j + 1's phase B.
-            if (tid == 1023 && pj >= 0) {
-                const int ppar = pj & 1;
-                const float *p = s_p2 + ppar * ((D + 3) & ~3);
-                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int d = 0; d < L8; d += 8) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        acc[k] = acc[k] + p[d + k];
-                }
-                float q0 = acc[0] + acc[4], q1 = acc[1] + acc[5], q2 = acc[2] + acc[6], q3 = acc[3] + acc[7];
-                int t = 0;
-                if (rem >= 4) {
-                    q0 = q0 + p[L8];
-                    q1 = q1 + p[L8 + 1];
-                    q2 = q2 + p[L8 + 2];
-                    q3 = q3 + p[L8 + 3];
-                    t = 4;
-                }
-                const float t02 = q0 + q2, t13 = q1 + q3;
-                float res = t02 + t13;
-                for (; t < rem; ++t)
-                    res = res + p[L8 + t];
-                lastdist = res;
-                const float q = res / a.fB;                      // residual.squaredNorm() / epochSize  (:1167)
-                mse = mse + q;
-                atomicAdd(&s_hits[pbmu], 1u);
-                s_last[pj] = (unsigned short)pbmu;
-                s_key[ppar] = ~0ull;
-            }
+            if (tid == 1023 && pj >= 0)
+                post(pj, pbmu);
             // B: distances in Eigen's order, argmin with the reference's rules (strict <, lowest index, NaN never wins,
             //    a NaN at node 0 pins the BMU: Som.cpp:293-304 -- key 0 is below every other key and names node 0)
             if (tid < ((N + 63) & ~63)) {                        // whole wavefronts
                 unsigned mybits = 0xFFFFFFFFu;
                 if (tid < N) {
-                    const float *p = s_p + tid * Dp;
-                    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    for (int d = 0; d < L8; d += 8) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            acc[k] = acc[k] + p[d + k];
-                    }
-                    float q0 = acc[0] + acc[4], q1 = acc[1] + acc[5], q2 = acc[2] + acc[6], q3 = acc[3] + acc[7];
-                    int t = 0;
-                    if (rem >= 4) {
-                        q0 = q0 + p[L8];
-                        q1 = q1 + p[L8 + 1];
-                        q2 = q2 + p[L8 + 2];
-                        q3 = q3 + p[L8 + 3];
-                        t = 4;
-                    }
-                    const float t02 = q0 + q2, t13 = q1 + q3;
-                    float res = t02 + t13;
-                    for (; t < rem; ++t)
-                        res = res + p[L8 + t];
+                    const float res = onl_tiny_row_sum(s_p + tid * Dp, L8, rem);
                     // (distances are sums of squares: their bit patterns order like their values; NaN -> all ones, never a
                     //  minimum; a NaN at node 0 -> 0, below everything)
                     mybits = (res != res) ? (tid == 0 ? 0u : 0xFFFFFFFFu) : __float_as_uint(res);
@@ -1750,39 +1742,8 @@ __global__ __launch_bounds__(1024) void online_tiny_chunk_kernel(OnlTinyArgs a)
         }
     }
     __syncthreads();
-    {
-        const int j = -1;                                    // (no stamps here)
-        (void)j;
-        if (tid == 1023 && pj >= 0) {
-                const int ppar = pj & 1;
-                const float *p = s_p2 + ppar * ((D + 3) & ~3);
-                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int d = 0; d < L8; d += 8) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        acc[k] = acc[k] + p[d + k];
-                }
-                float q0 = acc[0] + acc[4], q1 = acc[1] + acc[5], q2 = acc[2] + acc[6], q3 = acc[3] + acc[7];
-                int t = 0;
-                if (rem >= 4) {
-                    q0 = q0 + p[L8];
-                    q1 = q1 + p[L8 + 1];
-                    q2 = q2 + p[L8 + 2];
-                    q3 = q3 + p[L8 + 3];
-                    t = 4;
-                }
-                const float t02 = q0 + q2, t13 = q1 + q3;
-                float res = t02 + t13;
-                for (; t < rem; ++t)
-                    res = res + p[L8 + t];
-                lastdist = res;
-                const float q = res / a.fB;                      // residual.squaredNorm() / epochSize  (:1167)
-                mse = mse + q;
-                atomicAdd(&s_hits[pbmu], 1u);
-                s_last[pj] = (unsigned short)pbmu;
-                s_key[ppar] = ~0ull;
-            }
-    }
+    if (tid == 1023 && pj >= 0)                               // the chunk's last sample
+        post(pj, pbmu);
     __syncthreads();
     // state back: M and S of every value, weight by the node's first value, sigmaMap = sqrt(|S / w|) (:939-942) where a
     // window touched the node during this chunk
