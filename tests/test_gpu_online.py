@@ -308,6 +308,34 @@ def test_tiny_map_chunk_in_one_launch_with_nan_rows_and_duplicates(tr):
                 ctx.close()
 
 
+@pytest.mark.parametrize("W,H,J,B,tr", [(32, 32, 4, 4096, po.STANDARD), (4, 2, 512, 131, po.MEDIAN), (1, 1, 7, 30, po.STANDARD),
+                                        (2, 1, 1, 9, po.STANDARD), (32, 16, 8, 4095, po.MEDIAN)])
+def test_one_launch_chunk_at_its_limits(W, H, J, B, tr):
+    """online_tiny_chunk_kernel at the edges of what it takes: 1024 nodes with the largest chunk (4096 rows: the most LDS it
+    asks for), rows of 512 values (four samples per staged block), a single node, one-value rows, a chunk one short of the
+    limit with four values per thread; above and at sigma 1."""
+    X = gen.blobs(B, J, 3, 1, 2, sigma=0.3)
+    init = gen.random_map(W * H, J, seed=4)
+    o = po.OracleSom(W, H, J, tr)
+    o.set_state(map=init)
+    ctx = vsom_amd.Context(W, H, J, tr)
+    ctx.set_state(map=init)
+    lb = np.zeros(B, np.uint64)
+    run_o = np.float32(0)
+    for ci, (sigma, fn) in enumerate(((3.0, capi.EXPONENTIAL), (1.0, capi.INVERSE_PROPORTIONAL))):
+        lb = lb.copy() if sigma <= 1 else np.zeros(B, np.uint64)
+        start = lb.copy()
+        run_o = o.train_online_chunk(X, lb, 0.02, sigma, fn, mse_start=0.0 if ci == 0 else float(run_o))
+        ctx.upload_chunk(X)
+        ctx.set_last_bmu(start)
+        run_g, lb_g = ctx.train_online_chunk_fetch(0.02, sigma, fn, first_chunk=(ci == 0))
+        assert beq(lb_g, lb) and beq(np.float32(run_g), np.float32(run_o)), ci
+        st = ctx.get_state()
+        for k in ("map", "S", "sigma", "weight", "hits"):
+            assert beq(st[k], getattr(o, k)), (ci, k)
+    ctx.close()
+
+
 @pytest.mark.parametrize("W,H,J,tr", [(10, 10, 9, po.STANDARD), (12, 9, 20, po.MEDIAN), (24, 24, 48, po.STANDARD), (7, 7, 6, po.CLR)])
 def test_chunk_with_results_fetched_in_the_same_call(W, H, J, tr):
     """vsom_train_online_chunk_fetch = the chunk's sample loop + its lastBMU + the running MSE in one synchronising call (what
